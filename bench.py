@@ -1,0 +1,210 @@
+#!/usr/bin/env python3
+"""bench.py -- Mk-mers/s of the k-mer-set hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W
+
+Workload at N = 1 (BASELINE.json configs[1]): 4 synthetic canonical k=23 sets of
+10^7 k-mers each (seeded phylogeny family), resident in HBM as
+bucketed sorted keys; one step = the pair algebra of all 6 pairs -- for each pair
+(A, B): A&B, A\\B, B\\A with their bucket offsets and the three counts (what one
+KmerSetSet iteration asks for, lib/core/kmer_set_set.h:339-343), Diff = |A\\B| +
+|B\\A| derived from them.  Units = sum over pairs of (|A| + |B|) k-mers.
+
+N > 1 (one process per GPU, launched by torch.distributed.run): every rank runs
+the same-size batch on its own family (weak scaling), then the per-pair diff
+sizes are all-gathered over RCCL (the exchange step north_star names).
+
+Prints ONE JSON line on rank 0.  `roofline` is the write-pass merge kernel
+(k_tile_merge<.., true>): algorithmic bytes (|A| + |B| + |A u B|) * key_bytes per
+launch over its HIP-event duration, against the 8 TB/s HBM peak.  `cpu_baseline`
+times the oracle's restatement of the reference's hash-set algebra on the host
+(rank 0, N = 1 only, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "kmer-sets-compression_amd"), os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--k", type=int, default=23)
+    ap.add_argument("--bucket-bits", type=int, default=14)
+    ap.add_argument("--sets", type=int, default=4)
+    ap.add_argument("--size", type=float, default=1e7, help="k-mers per set")
+    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus %d needs one process per GPU: launch with "
+                             "python -m torch.distributed.run --nproc-per-node %d ..." % (args.gpus, args.gpus))
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from kmersets import capi, synth
+
+    k, nbits, n_sets, size = args.k, args.bucket_bits, args.sets, int(args.size)
+    g = capi.geom(k, nbits)
+    ctx = capi.Context(local_rank)
+    dev = ctx.device
+
+    # ---- inputs, resident in HBM before anything is timed
+    host_sets = synth.phylogeny_sets(k, n_sets, size, seed=args.seed + 1000 * rank)
+    sets = [capi.DeviceSet.from_kmers(g, s, dev) for s in host_sets]
+    pairs = [(i, j) for i in range(n_sets) for j in range(i + 1, n_sets)]
+    units_per_step = sum(sets[i].n_keys + sets[j].n_keys for i, j in pairs)
+
+    diff_local = torch.zeros(len(pairs), dtype=torch.int64, device=dev)
+    gathered = [torch.zeros_like(diff_local) for _ in range(world)] if world > 1 else None
+    algo_bytes = [0.0]
+
+    def step(record):
+        diffs = []
+        for (i, j) in pairs:
+            inter, amb, bma = ctx.pair_algebra(sets[i], sets[j])
+            diffs.append(amb.n_keys + bma.n_keys)
+            if record:
+                union = sets[i].n_keys + bma.n_keys
+                algo_bytes[0] += (sets[i].n_keys + sets[j].n_keys + union) * g.key_bytes
+        if world > 1:
+            diff_local.copy_(torch.tensor(diffs, dtype=torch.int64), non_blocking=False)
+            dist.all_gather(gathered, diff_local)
+        return diffs
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    ctx.enable_timing(True)
+    ctx.timing_reset()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        diffs = step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    write_ms, write_launches = ctx.timing_read(0)
+    count_ms, count_launches = ctx.timing_read(1)
+    ctx.enable_timing(False)
+
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        u = torch.tensor([units_per_step], dtype=torch.int64, device=dev)
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        total_units_per_step = int(u.item())
+    else:
+        total_units_per_step = units_per_step
+
+    value = total_units_per_step * args.steps / elapsed / 1e6
+
+    cpu_baseline = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle_lib as ol
+
+        # The reference's algebra for one merge (kmer_set_set.h:339-343) on hash-bucket
+        # sets: Intersection(j, k) [two by-value copies + two Sub], then j.Sub(n), k.Sub(n).
+        done_units, spent = 0, 0.0
+        used = []
+        for (i, j) in pairs:
+            a = ol.Set.from_kmers(k, nbits, g.key_bytes, host_sets[i])
+            b = ol.Set.from_kmers(k, nbits, g.key_bytes, host_sets[j])
+            c0 = time.perf_counter()
+            n = a.intersection(b)
+            a.sub_set(n)
+            b.sub_set(n)
+            spent += time.perf_counter() - c0
+            done_units += host_sets[i].size + host_sets[j].size
+            used.append((i, j))
+            assert a.size() + b.size() == diffs[pairs.index((i, j))]
+            if spent >= args.cpu_baseline_seconds:
+                break
+        cpu_baseline = {
+            "value": done_units / spent / 1e6,
+            "unit": "Mk-mers/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": "oracle hash-set algebra (Intersection + 2 Sub) on pairs %s of the same "
+                      "workload, full size, set construction excluded, %.1f s of CPU" % (used, spent),
+        }
+
+    if rank == 0:
+        achieved = algo_bytes[0] / (write_ms * 1e-3) / 1e9 if write_ms > 0 else 0.0
+        out = {
+            "metric": "Mk-mers/s processed in kmerset-multiple-compress (pair set-algebra stage); "
+                      "bytes/k-mer after SPSS not yet measured",
+            "value": value,
+            "unit": "Mk-mers/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32" if g.key_bytes == 4 else "u64",
+            "data": "synthetic",
+            "config": {
+                "workload": "configs[1]: %d canonical k=%d sets of %d k-mers (seeded phylogeny family), "
+                            "all %d pairs: A&B, A\\B, B\\A + counts per pair" % (n_sets, k, size, len(pairs)),
+                "k": k, "n_bucket_bits": nbits, "key_bytes": g.key_bytes,
+                "sets_per_gpu": n_sets, "kmers_per_set": [s.n_keys for s in sets],
+                "pairs_per_step": len(pairs), "units_per_step": total_units_per_step,
+                "parallelism": "1 process per GPU, pairs sharded by rank, RCCL all-gather of "
+                               "per-pair diff sizes" if world > 1 else "1 GPU",
+            },
+            "roofline": {
+                "bound": "hbm",
+                "kernel": "k_tile_merge<write>",
+                "achieved": achieved,
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS,
+                "traffic": None,
+                "launches": int(write_launches),
+                "avg_launch_ms": write_ms / max(write_launches, 1),
+                "algorithmic_bytes_per_launch": algo_bytes[0] / max(write_launches, 1),
+                "count_pass_avg_launch_ms": count_ms / max(count_launches, 1),
+            },
+            "cpu_baseline": cpu_baseline,
+        }
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

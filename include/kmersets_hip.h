@@ -1,0 +1,128 @@
+/*
+ * kmersets_hip.h -- C ABI of the MI355X (gfx950) k-mer-set hot path.
+ *
+ * The reference (kkty/kmer-sets-compression) has no FFI: its hot path is a set of
+ * header-only C++17 templates (the lib/core headers).  This header is the boundary the
+ * build introduces underneath them: flat extern "C" functions over
+ * plain device pointers and sizes, parameterised at run time by
+ * (k, n_bucket_bits, key_bytes) instead of the reference's template parameters
+ * <K, N, KeyType>.  The C++17 class templates in
+ * kmer-sets-compression_amd/cpp/core/ (KmerSet / KmerSetCompact / KmerSetSet, same
+ * names and argument meaning as the reference) are thin wrappers over these calls;
+ * INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Device layout of a k-mer set (replaces 2^N absl::flat_hash_set<KeyType>,
+ * lib/core/kmer_set.h:247-251):
+ *     offsets : int64[2^N + 1]   bucket b holds keys[offsets[b] .. offsets[b+1])
+ *     keys    : u32 or u64       low (2K - N) bits of the k-mer, ascending inside
+ *                                a bucket; key_bytes = 4 when 2K-N <= 32, else 8
+ * i.e. the set is one ascending array of 2K-bit k-mers with a bucket index.
+ *
+ * All pointers named d_* are device pointers on the context's GPU.  Functions
+ * that return host scalars synchronise the context's stream before returning;
+ * the others only enqueue work.  There is no CPU fallback anywhere behind this
+ * header: without a usable HIP device every call fails with KSH_INTERNAL.
+ *
+ * Status codes mirror the three absl codes the reference uses
+ * (lib/core/io.h:26,43,63; lib/core/kmer_set_set.h:465,525,610).
+ */
+#ifndef KMERSETS_HIP_H_
+#define KMERSETS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define KSH_OK 0
+#define KSH_INVALID_ARGUMENT 3
+#define KSH_FAILED_PRECONDITION 9
+#define KSH_INTERNAL 13
+
+typedef struct ksh_ctx ksh_ctx;
+
+/* <K, N, KeyType> of the reference, as run-time values. */
+typedef struct ksh_geom {
+  int32_t k;             /* k-mer length, 2 <= k <= 31                         */
+  int32_t n_bucket_bits; /* N: top N bits of the 2K-bit k-mer pick the bucket  */
+  int32_t key_bytes;     /* device key width: 4 or 8                           */
+  int32_t reserved;
+} ksh_geom;
+
+/* One k-mer set resident in HBM. */
+typedef struct ksh_set_view {
+  const int64_t* d_offsets; /* int64[2^N + 1]                */
+  const void* d_keys;       /* key_bytes * n_keys bytes      */
+  int64_t n_keys;
+} ksh_set_view;
+
+/* ---- library / errors --------------------------------------------------------- */
+int ksh_version(void);
+/* Message of the last failing call on this thread ("" if none). */
+const char* ksh_last_error(void);
+
+/* ---- device plumbing (so that host C++ needs no HIP headers) ---------------------- */
+int ksh_device_count(int* count);
+int ksh_malloc(int device, size_t bytes, void** d_ptr);
+int ksh_free(int device, void* d_ptr);
+int ksh_memcpy_h2d(int device, void* d_dst, const void* src, size_t bytes);
+int ksh_memcpy_d2h(int device, void* dst, const void* d_src, size_t bytes);
+
+/* A context = one GPU + one HIP stream + a scratch arena.  `stream` may be an
+ * existing hipStream_t (e.g. torch's current stream) or NULL for a new one.
+ * Contexts are not thread-safe; use one per host thread (the reference calls its
+ * set operations concurrently from pool threads, lib/core/kmer_set_set.h:146-149). */
+int ksh_ctx_create(int device, void* stream, ksh_ctx** out);
+int ksh_ctx_destroy(ksh_ctx* ctx);
+int ksh_ctx_sync(ksh_ctx* ctx);
+/* Pre-sizes the scratch arena (otherwise it grows on demand). */
+int ksh_ctx_reserve(ksh_ctx* ctx, size_t bytes);
+/* Kernel timing for bench.py's roofline leg.  While enabled, every launch of a
+ * timed kernel kind is bracketed by its own pair of HIP events on the context's
+ * stream; ksh_ctx_timing_read synchronises the stream and returns the summed
+ * duration and the number of launches since the last reset.
+ * kinds: 0 = pair merge, write pass   1 = pair merge, count pass
+ *        2 = sampled-bucket weight count pass */
+int ksh_ctx_enable_timing(ksh_ctx* ctx, int enable);
+int ksh_ctx_timing_reset(ksh_ctx* ctx);
+int ksh_ctx_timing_read(ksh_ctx* ctx, int kind, float* total_ms, int64_t* launches);
+
+/* ---- KmerSet::Size / Hash  (lib/core/kmer_set.h:65-71, :224-244) --------------------- */
+/* XOR of all k-mer bit patterns in the set. */
+int ksh_set_hash(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* s, uint64_t* hash);
+
+/* ---- set algebra  (lib/core/kmer_set.h:164-187, :286-305; the loop needs
+ *      A&B, A\B and B\A of one pair, lib/core/kmer_set_set.h:339-343) ------------------ */
+/* Pass 1.  Counts |A & B| per bucket and derives the bucket offsets of the three
+ * results: d_off_i / d_off_amb / d_off_bma are int64[2^N + 1] outputs.
+ * totals = { |A & B|, |A \ B|, |B \ A| } (host).  The plan stays valid for the
+ * next ksh_pair_write on the same context with the same A and B. */
+int ksh_pair_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
+                  int64_t* d_off_i, int64_t* d_off_amb, int64_t* d_off_bma, int64_t totals[3]);
+/* Pass 2.  Writes the keys of the three results (buffers sized from `totals`;
+ * any of them may be NULL to skip that result). */
+int ksh_pair_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
+                   void* d_keys_i, void* d_keys_amb, void* d_keys_bma);
+
+/* ---- KmerSet::Diff / Equals  (lib/core/kmer_set.h:191-219) ----------------------------- */
+/* |A \ B| + |B \ A|. */
+int ksh_set_diff(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
+                 int64_t* diff);
+
+/* ---- GetEdgeWeight over sampled buckets  (lib/core/kmer_set_set.h:158-219,385-425) ----- */
+/* weights[p] = sum over the listed buckets of |bucket(sets[pairs[2p]]) &
+ * bucket(sets[pairs[2p+1]])|.  A "sampled set" of the reference
+ * (KmerSetCompact::GetSampledKmerSet, kmer_set_compact.h:120-203) is a slice of
+ * the resident sorted buckets here, so no separate structure is built.
+ * sets, bucket_ids, pairs and weights are HOST arrays. */
+int ksh_pair_weights(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sets, int32_t n_sets,
+                     const int32_t* bucket_ids, int32_t n_ids, const int32_t* pairs,
+                     int32_t n_pairs, int64_t* weights);
+
+#ifdef __cplusplus
+}
+#endif
+
+#endif /* KMERSETS_HIP_H_ */

@@ -1,0 +1,395 @@
+// Context, errors, device plumbing, prefix sum and the XOR-hash reduction.
+// gfx950 only; wavefront = 64.
+#include "ksh_internal.h"
+
+#include <algorithm>
+#include <cstring>
+#include <type_traits>
+
+namespace ksh {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+int check_geom(const ksh_geom* g) {
+  if (!g) return fail(KSH_INVALID_ARGUMENT, "geometry is NULL");
+  if (g->k < 2 || g->k > 31) return fail(KSH_INVALID_ARGUMENT, "k = %d is outside [2, 31]", g->k);
+  if (g->n_bucket_bits < 1 || g->n_bucket_bits > 24 || g->n_bucket_bits >= 2 * g->k)
+    return fail(KSH_INVALID_ARGUMENT, "n_bucket_bits = %d is not usable with k = %d",
+                g->n_bucket_bits, g->k);
+  const int kb = 2 * g->k - g->n_bucket_bits;
+  if (g->key_bytes != 4 && g->key_bytes != 8)
+    return fail(KSH_INVALID_ARGUMENT, "key_bytes = %d (device keys are 4 or 8 bytes)", g->key_bytes);
+  if (kb > 8 * g->key_bytes)
+    return fail(KSH_INVALID_ARGUMENT, "%d key bits do not fit %d key bytes", kb, g->key_bytes);
+  return KSH_OK;
+}
+
+int arena_reserve(ksh_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->arena_bytes) return KSH_OK;
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->arena) KSH_HIP(hipFree(ctx->arena));
+  ctx->arena = nullptr;
+  ctx->arena_bytes = 0;
+  size_t want = bytes + (bytes >> 2) + (1u << 20);
+  KSH_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->arena), want));
+  ctx->arena_bytes = want;
+  ctx->arena_used = 0;
+  return KSH_OK;
+}
+
+void* arena_alloc(ksh_ctx* ctx, size_t bytes) {
+  size_t at = (ctx->arena_used + 255) & ~size_t(255);
+  if (at + bytes > ctx->arena_bytes) return nullptr;
+  ctx->arena_used = at + bytes;
+  return ctx->arena + at;
+}
+
+hipEvent_t timer_event(ksh_ctx* ctx, size_t* index) {
+  if (ctx->ev_next == ctx->ev_pool.size()) {
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    ctx->ev_pool.push_back(e);
+  }
+  *index = ctx->ev_next;
+  return ctx->ev_pool[ctx->ev_next++];
+}
+
+int plan_reserve(ksh_ctx* ctx, size_t bytes) {
+  if (bytes <= ctx->plan_bytes) return KSH_OK;
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->plan) KSH_HIP(hipFree(ctx->plan));
+  ctx->plan = nullptr;
+  ctx->plan_bytes = 0;
+  size_t want = bytes + (bytes >> 2) + (1u << 16);
+  KSH_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->plan), want));
+  ctx->plan_bytes = want;
+  return KSH_OK;
+}
+
+// ------------------------------------------------------------------------------ scan
+// Three-kernel exclusive scan: 256 threads x 8 items per block, block totals
+// scanned recursively.  Inputs here are small (bucket and tile counts), so this
+// is launch-bound, not bandwidth-bound.
+constexpr int kScanThreads = 256;
+constexpr int kScanItems = 8;
+constexpr int kScanTile = kScanThreads * kScanItems;
+
+__device__ inline int64_t wave_inclusive_scan(int64_t v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    int64_t o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// Exclusive scan of one value per thread across a 256-thread block.
+__device__ inline int64_t block_exclusive_scan(int64_t v, int64_t* total, int64_t* lds4) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int64_t inc = wave_inclusive_scan(v);
+  if (lane == 63) lds4[wave] = inc;
+  __syncthreads();
+  int64_t base = 0;
+#pragma unroll
+  for (int w = 0; w < kScanThreads / 64; w++) {
+    if (w < wave) base += lds4[w];
+  }
+  *total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+  __syncthreads();
+  return base + inc - v;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_tiles(const int64_t* __restrict__ in,
+                                                              int64_t* __restrict__ out,
+                                                              int64_t* __restrict__ block_sums,
+                                                              int64_t n) {
+  __shared__ int64_t lds4[4];
+  const int64_t base = int64_t(blockIdx.x) * kScanTile + int64_t(threadIdx.x) * kScanItems;
+  int64_t v[kScanItems];
+  int64_t sum = 0;
+#pragma unroll
+  for (int i = 0; i < kScanItems; i++) {
+    v[i] = (base + i < n) ? in[base + i] : 0;
+    sum += v[i];
+  }
+  int64_t total;
+  int64_t excl = block_exclusive_scan(sum, &total, lds4);
+#pragma unroll
+  for (int i = 0; i < kScanItems; i++) {
+    if (base + i < n) out[base + i] = excl;
+    excl += v[i];
+  }
+  if (threadIdx.x == 0) block_sums[blockIdx.x] = total;
+}
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_add(int64_t* __restrict__ out,
+                                                            const int64_t* __restrict__ block_prefix,
+                                                            int64_t n) {
+  const int64_t base = int64_t(blockIdx.x) * kScanTile + int64_t(threadIdx.x) * kScanItems;
+  const int64_t add = block_prefix[blockIdx.x];
+#pragma unroll
+  for (int i = 0; i < kScanItems; i++) {
+    if (base + i < n) out[base + i] += add;
+  }
+}
+
+__global__ void k_store_total(const int64_t* __restrict__ block_prefix_last,
+                              const int64_t* __restrict__ block_sums_last, int64_t* total) {
+  *total = *block_prefix_last + *block_sums_last;
+}
+
+int scan_exclusive_i64(ksh_ctx* ctx, const int64_t* d_in, int64_t* d_out, int64_t n,
+                       int64_t* d_total) {
+  if (n <= 0) {
+    if (d_total) KSH_HIP(hipMemsetAsync(d_total, 0, sizeof(int64_t), ctx->stream));
+    return KSH_OK;
+  }
+  const int64_t blocks = (n + kScanTile - 1) / kScanTile;
+  int64_t* sums = static_cast<int64_t*>(arena_alloc(ctx, size_t(blocks) * sizeof(int64_t)));
+  int64_t* sums_total = static_cast<int64_t*>(arena_alloc(ctx, sizeof(int64_t)));
+  if (!sums || !sums_total) return fail(KSH_INTERNAL, "scan: scratch arena too small");
+  hipLaunchKernelGGL(k_scan_tiles, dim3(unsigned(blocks)), dim3(kScanThreads), 0, ctx->stream, d_in,
+                     d_out, sums, n);
+  if (blocks > 1) {
+    // sums -> exclusive prefix (in place), recursively
+    KSH_TRY(scan_exclusive_i64(ctx, sums, sums, blocks, sums_total));
+    hipLaunchKernelGGL(k_scan_add, dim3(unsigned(blocks)), dim3(kScanThreads), 0, ctx->stream, d_out,
+                       sums, n);
+    if (d_total)
+      KSH_HIP(hipMemcpyAsync(d_total, sums_total, sizeof(int64_t), hipMemcpyDeviceToDevice,
+                             ctx->stream));
+  } else if (d_total) {
+    KSH_HIP(hipMemcpyAsync(d_total, sums, sizeof(int64_t), hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  KSH_HIP(hipGetLastError());
+  return KSH_OK;
+}
+
+// ------------------------------------------------------------------------------ hash
+// KmerSet::Hash (lib/core/kmer_set.h:224-244) = XOR of every k-mer's bit pattern
+// = XOR of all keys  ^  XOR over buckets with an odd key count of (b << key_bits).
+// The first term is a streaming reduction over the key array (16 B per lane).
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_xor_keys(const KeyT* __restrict__ keys, int64_t n,
+                                                   unsigned long long* __restrict__ out) {
+  constexpr int kPer = 16 / sizeof(KeyT);
+  using Vec = typename std::conditional<sizeof(KeyT) == 4, uint4, ulonglong2>::type;
+  unsigned long long acc = 0;
+  const int64_t n_vec = n / kPer;
+  const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+  const Vec* vp = reinterpret_cast<const Vec*>(keys);
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
+    Vec v = vp[i];
+    if constexpr (sizeof(KeyT) == 4) {
+      acc ^= (unsigned long long)(v.x ^ v.y ^ v.z ^ v.w);
+    } else {
+      acc ^= v.x ^ v.y;
+    }
+  }
+  for (int64_t i = n_vec * kPer + int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n; i += stride)
+    acc ^= (unsigned long long)keys[i];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc ^= __shfl_xor(acc, d, 64);
+  if ((threadIdx.x & 63) == 0 && acc) atomicXor(out, acc);
+}
+
+__global__ __launch_bounds__(256) void k_xor_buckets(const int64_t* __restrict__ offsets,
+                                                      int64_t n_buckets, int key_bits,
+                                                      unsigned long long* __restrict__ out) {
+  unsigned long long acc = 0;
+  for (int64_t b = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; b < n_buckets;
+       b += int64_t(gridDim.x) * blockDim.x) {
+    if ((offsets[b + 1] - offsets[b]) & 1) acc ^= (unsigned long long)b << key_bits;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc ^= __shfl_xor(acc, d, 64);
+  if ((threadIdx.x & 63) == 0 && acc) atomicXor(out, acc);
+}
+
+}  // namespace ksh
+
+using namespace ksh;
+
+extern "C" {
+
+int ksh_version(void) { return 1; }
+
+const char* ksh_last_error(void) { return g_last_error.c_str(); }
+
+int ksh_device_count(int* count) {
+  if (!count) return fail(KSH_INVALID_ARGUMENT, "count is NULL");
+  *count = 0;
+  hipError_t e = hipGetDeviceCount(count);
+  if (e != hipSuccess) {
+    *count = 0;
+    return fail(KSH_INTERNAL, "hipGetDeviceCount failed: %s", hipGetErrorString(e));
+  }
+  return KSH_OK;
+}
+
+int ksh_malloc(int device, size_t bytes, void** d_ptr) {
+  if (!d_ptr) return fail(KSH_INVALID_ARGUMENT, "d_ptr is NULL");
+  *d_ptr = nullptr;
+  KSH_HIP(hipSetDevice(device));
+  if (bytes == 0) bytes = 16;
+  KSH_HIP(hipMalloc(d_ptr, bytes));
+  return KSH_OK;
+}
+
+int ksh_free(int device, void* d_ptr) {
+  if (!d_ptr) return KSH_OK;
+  KSH_HIP(hipSetDevice(device));
+  KSH_HIP(hipFree(d_ptr));
+  return KSH_OK;
+}
+
+int ksh_memcpy_h2d(int device, void* d_dst, const void* src, size_t bytes) {
+  KSH_HIP(hipSetDevice(device));
+  if (bytes) KSH_HIP(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+  return KSH_OK;
+}
+
+int ksh_memcpy_d2h(int device, void* dst, const void* d_src, size_t bytes) {
+  KSH_HIP(hipSetDevice(device));
+  if (bytes) KSH_HIP(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+  return KSH_OK;
+}
+
+int ksh_ctx_create(int device, void* stream, ksh_ctx** out) {
+  if (!out) return fail(KSH_INVALID_ARGUMENT, "out is NULL");
+  *out = nullptr;
+  int count = 0;
+  KSH_TRY(ksh_device_count(&count));
+  if (device < 0 || device >= count)
+    return fail(KSH_INTERNAL, "no HIP device %d (%d visible); this library has no CPU path", device,
+                count);
+  KSH_HIP(hipSetDevice(device));
+  ksh_ctx* ctx = new ksh_ctx;
+  ctx->device = device;
+  if (stream) {
+    ctx->stream = static_cast<hipStream_t>(stream);
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) {
+      delete ctx;
+      return fail(KSH_INTERNAL, "hipStreamCreate failed: %s", hipGetErrorString(e));
+    }
+    ctx->own_stream = true;
+  }
+  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pinned), 64 * sizeof(int64_t));
+  if (e != hipSuccess) {
+    delete ctx;
+    return fail(KSH_INTERNAL, "hipHostMalloc failed: %s", hipGetErrorString(e));
+  }
+  int rc = arena_reserve(ctx, size_t(8) << 20);
+  if (rc != KSH_OK) {
+    delete ctx;
+    return rc;
+  }
+  *out = ctx;
+  return KSH_OK;
+}
+
+int ksh_ctx_destroy(ksh_ctx* ctx) {
+  if (!ctx) return KSH_OK;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->arena) (void)hipFree(ctx->arena);
+  if (ctx->plan) (void)hipFree(ctx->plan);
+  if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  for (hipEvent_t ev : ctx->ev_pool)
+    if (ev) (void)hipEventDestroy(ev);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  delete ctx;
+  return KSH_OK;
+}
+
+int ksh_ctx_sync(ksh_ctx* ctx) {
+  if (!ctx) return fail(KSH_INVALID_ARGUMENT, "ctx is NULL");
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  return KSH_OK;
+}
+
+int ksh_ctx_reserve(ksh_ctx* ctx, size_t bytes) {
+  if (!ctx) return fail(KSH_INVALID_ARGUMENT, "ctx is NULL");
+  KSH_HIP(hipSetDevice(ctx->device));
+  return arena_reserve(ctx, bytes);
+}
+
+int ksh_ctx_enable_timing(ksh_ctx* ctx, int enable) {
+  if (!ctx) return fail(KSH_INVALID_ARGUMENT, "ctx is NULL");
+  ctx->timing = enable != 0;
+  return KSH_OK;
+}
+
+int ksh_ctx_timing_reset(ksh_ctx* ctx) {
+  if (!ctx) return fail(KSH_INVALID_ARGUMENT, "ctx is NULL");
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->ev_next = 0;
+  for (int i = 0; i < kNumTimers; i++) ctx->ev_spans[i].clear();
+  return KSH_OK;
+}
+
+int ksh_ctx_timing_read(ksh_ctx* ctx, int kind, float* total_ms, int64_t* launches) {
+  if (!ctx || !total_ms || !launches) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  if (kind < 0 || kind >= kNumTimers) return fail(KSH_INVALID_ARGUMENT, "no timer kind %d", kind);
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  double sum = 0;
+  for (const auto& span : ctx->ev_spans[kind]) {
+    float ms = 0;
+    KSH_HIP(hipEventElapsedTime(&ms, ctx->ev_pool[span.first], ctx->ev_pool[span.second]));
+    sum += ms;
+  }
+  *total_ms = float(sum);
+  *launches = int64_t(ctx->ev_spans[kind].size());
+  return KSH_OK;
+}
+
+int ksh_set_hash(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* s, uint64_t* hash) {
+  if (!ctx || !s || !hash) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  KSH_TRY(check_geom(g));
+  KSH_HIP(hipSetDevice(ctx->device));
+  arena_reset(ctx);
+  unsigned long long* d_acc = static_cast<unsigned long long*>(arena_alloc(ctx, 8));
+  KSH_HIP(hipMemsetAsync(d_acc, 0, 8, ctx->stream));
+  const int64_t nb = n_buckets(g);
+  if (s->n_keys > 0) {
+    const int64_t per_block = 256 * 16;
+    unsigned blocks = unsigned(std::min<int64_t>((s->n_keys + per_block - 1) / per_block, 2048));
+    if (g->key_bytes == 4)
+      hipLaunchKernelGGL(k_xor_keys<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+                         static_cast<const uint32_t*>(s->d_keys), s->n_keys, d_acc);
+    else
+      hipLaunchKernelGGL(k_xor_keys<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
+                         static_cast<const uint64_t*>(s->d_keys), s->n_keys, d_acc);
+  }
+  hipLaunchKernelGGL(k_xor_buckets, dim3(unsigned(std::min<int64_t>((nb + 255) / 256, 1024))),
+                     dim3(256), 0, ctx->stream, s->d_offsets, nb, key_bits(g), d_acc);
+  KSH_HIP(hipGetLastError());
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, d_acc, 8, hipMemcpyDeviceToHost, ctx->stream));
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  *hash = static_cast<uint64_t>(ctx->h_pinned[0]);
+  return KSH_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,107 @@
+// Internal declarations shared by the HIP translation units behind
+// include/kmersets_hip.h.  gfx950 only.
+#ifndef KSH_INTERNAL_H_
+#define KSH_INTERNAL_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <string>
+#include <vector>
+
+#include "kmersets_hip.h"
+
+namespace ksh {
+
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+
+#define KSH_HIP(expr)                                                                   \
+  do {                                                                                  \
+    hipError_t err__ = (expr);                                                          \
+    if (err__ != hipSuccess)                                                            \
+      return ::ksh::fail(KSH_INTERNAL, "%s failed: %s (%s:%d)", #expr,                  \
+                         hipGetErrorString(err__), __FILE__, __LINE__);                 \
+  } while (0)
+
+#define KSH_TRY(expr)              \
+  do {                             \
+    int rc__ = (expr);             \
+    if (rc__ != KSH_OK) return rc__; \
+  } while (0)
+
+constexpr int kNumTimers = 4;
+
+}  // namespace ksh
+
+// Scratch arena: one growing device buffer, carved by bump allocation and reset
+// at the start of every public call that needs scratch.  The pair plan keeps its
+// own buffers (they must survive until ksh_pair_write).
+struct ksh_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+
+  char* arena = nullptr;
+  size_t arena_bytes = 0;
+  size_t arena_used = 0;
+
+  // pinned host staging for small read-backs
+  int64_t* h_pinned = nullptr;  // 64 int64
+
+  // pair plan (ksh_pair_plan -> ksh_pair_write)
+  char* plan = nullptr;
+  size_t plan_bytes = 0;
+  int64_t plan_tiles = 0;
+  const void* plan_a_keys = nullptr;
+  const void* plan_b_keys = nullptr;
+  int64_t plan_buckets = 0;
+
+  // kernel timers: when enabled, every launch of a timed kind gets its own event
+  // pair from a pool; ksh_ctx_timing_read sums them after a stream sync.
+  bool timing = false;
+  std::vector<hipEvent_t> ev_pool;                       // all events ever created
+  size_t ev_next = 0;                                    // next unused event in ev_pool
+  std::vector<std::pair<size_t, size_t>> ev_spans[ksh::kNumTimers];  // (start, stop) indices
+};
+
+namespace ksh {
+
+int arena_reserve(ksh_ctx* ctx, size_t bytes);
+inline void arena_reset(ksh_ctx* ctx) { ctx->arena_used = 0; }
+// Returns nullptr when the arena is too small (callers reserve first).
+void* arena_alloc(ksh_ctx* ctx, size_t bytes);
+int plan_reserve(ksh_ctx* ctx, size_t bytes);
+
+int check_geom(const ksh_geom* g);
+inline int64_t n_buckets(const ksh_geom* g) { return int64_t(1) << g->n_bucket_bits; }
+inline int key_bits(const ksh_geom* g) { return 2 * g->k - g->n_bucket_bits; }
+
+hipEvent_t timer_event(ksh_ctx* ctx, size_t* index);
+
+struct Timer {
+  ksh_ctx* ctx;
+  int kind;
+  size_t i0 = 0;
+  Timer(ksh_ctx* c, int k) : ctx(c), kind(k) {
+    if (ctx->timing) (void)hipEventRecord(timer_event(ctx, &i0), ctx->stream);
+  }
+  ~Timer() {
+    if (ctx->timing) {
+      size_t i1;
+      (void)hipEventRecord(timer_event(ctx, &i1), ctx->stream);
+      ctx->ev_spans[kind].emplace_back(i0, i1);
+    }
+  }
+};
+
+// Exclusive prefix sum of n int64 values on the context's stream; `total`
+// (device, one int64, may be nullptr) receives the sum.  in may equal out.
+int scan_exclusive_i64(ksh_ctx* ctx, const int64_t* d_in, int64_t* d_out, int64_t n,
+                       int64_t* d_total);
+
+}  // namespace ksh
+
+#endif

@@ -1,0 +1,573 @@
+// Pair kernels over bucketed sorted key arrays: intersection / both differences
+// (KmerSet::Sub / Intersection, lib/core/kmer_set.h:164-187,286-305), the
+// symmetric-difference count (KmerSet::Diff, :191-219) and the sampled-bucket
+// pair weights (GetEdgeWeight, lib/core/kmer_set_set.h:158-184).
+//
+// A set is one ascending array of k-mers with a bucket index, so every one of
+// these is a merge of two sorted ranges per bucket.  The work is cut into
+// *segments* (one per bucket of a pair, or one per (pair, sampled bucket)) and each
+// segment into *tiles* of at most kTileCap merged keys by merge-path; a workgroup
+// of 256 threads stages one tile's two key ranges in LDS with coalesced loads,
+// every thread merges kVT keys from LDS, and the three result streams are
+// compacted in LDS and written back coalesced.  HBM-bound integer work; no MFMA.
+//
+// Tie rule: on equal keys the A key is merged first, so a common key shows up as
+// "a, b" adjacent in the merged order.  The tile split never separates such a
+// pair (the split kernel moves the B boundary by one when it would), which makes
+// every tile self-contained: matches are decided from LDS only.
+#include "ksh_internal.h"
+
+#include <algorithm>
+#include <vector>
+
+namespace ksh {
+
+constexpr int kThreads = 256;
+constexpr int kVT = 8;                     // merged keys per thread
+constexpr int kTile = kThreads * kVT - 1;  // diagonal spacing (the +1 is the tie fix-up)
+constexpr int kTileCap = kThreads * kVT;   // LDS capacity in keys
+
+// ---- segment sources -------------------------------------------------------------
+// One segment per bucket of a pair of sets.
+template <typename KeyT>
+struct BucketSegs {
+  const KeyT* a_keys;
+  const int64_t* a_off;
+  const KeyT* b_keys;
+  const int64_t* b_off;
+  __device__ void get(int64_t s, const KeyT*& a, int64_t& a_lo, int64_t& a_hi, const KeyT*& b,
+                      int64_t& b_lo, int64_t& b_hi) const {
+    a = a_keys;
+    b = b_keys;
+    a_lo = a_off[s];
+    a_hi = a_off[s + 1];
+    b_lo = b_off[s];
+    b_hi = b_off[s + 1];
+  }
+};
+
+struct SetPtrs {
+  const void* keys;
+  const int64_t* off;
+};
+
+// One segment per (pair p, sampled bucket i): s = p * n_ids + i.
+template <typename KeyT>
+struct PairSegs {
+  const SetPtrs* sets;
+  const int32_t* bucket_ids;
+  const int32_t* pairs;
+  int32_t n_ids;
+  __device__ void get(int64_t s, const KeyT*& a, int64_t& a_lo, int64_t& a_hi, const KeyT*& b,
+                      int64_t& b_lo, int64_t& b_hi) const {
+    const int64_t p = s / n_ids;
+    const int32_t bucket = bucket_ids[s - p * n_ids];
+    const SetPtrs sa = sets[pairs[2 * p]];
+    const SetPtrs sb = sets[pairs[2 * p + 1]];
+    a = static_cast<const KeyT*>(sa.keys);
+    b = static_cast<const KeyT*>(sb.keys);
+    a_lo = sa.off[bucket];
+    a_hi = sa.off[bucket + 1];
+    b_lo = sb.off[bucket];
+    b_hi = sb.off[bucket + 1];
+  }
+};
+
+// ---- tile plan --------------------------------------------------------------------------
+template <typename KeyT, typename Segs>
+__global__ __launch_bounds__(256) void k_seg_tiles(Segs segs, int64_t n_segs,
+                                                    int64_t* __restrict__ tiles_per_seg) {
+  const int64_t s = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (s >= n_segs) return;
+  const KeyT *a, *b;
+  int64_t a_lo, a_hi, b_lo, b_hi;
+  segs.get(s, a, a_lo, a_hi, b, b_lo, b_hi);
+  const int64_t len = (a_hi - a_lo) + (b_hi - b_lo);
+  tiles_per_seg[s] = (len + kTile - 1) / kTile;
+}
+
+// One thread per tile: which segment, and where the tile starts in A and in B.
+template <typename KeyT, typename Segs>
+__global__ __launch_bounds__(256) void k_tile_split(Segs segs, int64_t n_segs,
+                                                     const int64_t* __restrict__ tile_base,
+                                                     int32_t* __restrict__ tile_seg,
+                                                     int64_t* __restrict__ tile_a,
+                                                     int64_t* __restrict__ tile_b) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t total = tile_base[n_segs];
+  if (t >= total) return;
+  // last s with tile_base[s] <= t
+  int64_t lo = 0, hi = n_segs;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (tile_base[mid] <= t) lo = mid + 1; else hi = mid;
+  }
+  const int64_t s = lo - 1;
+  const KeyT *a, *b;
+  int64_t a_lo, a_hi, b_lo, b_hi;
+  segs.get(s, a, a_lo, a_hi, b, b_lo, b_hi);
+  const int64_t na = a_hi - a_lo, nb = b_hi - b_lo;
+  const int64_t diag = (t - tile_base[s]) * kTile;
+  int64_t i_lo = diag > nb ? diag - nb : 0;
+  int64_t i_hi = diag < na ? diag : na;
+  while (i_lo < i_hi) {
+    const int64_t mid = (i_lo + i_hi) >> 1;
+    if (a[a_lo + mid] <= b[b_lo + diag - 1 - mid]) i_lo = mid + 1; else i_hi = mid;
+  }
+  int64_t i = i_lo, j = diag - i_lo;
+  if (i > 0 && j < nb && a[a_lo + i - 1] == b[b_lo + j]) j += 1;  // keep a common key's pair together
+  tile_seg[t] = int32_t(s);
+  tile_a[t] = a_lo + i;
+  tile_b[t] = b_lo + j;
+}
+
+// ---- block helpers ----------------------------------------------------------------------------
+__device__ inline uint64_t wave_inclusive_scan_u64(uint64_t v) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint64_t o = __shfl_up(v, d, 64);
+    if (lane >= d) v += o;
+  }
+  return v;
+}
+
+// Exclusive scan of one packed value per thread; returns the exclusive prefix and
+// the block total.  lds4 = 4 uint64 of scratch.
+__device__ inline uint64_t block_exclusive_scan_u64(uint64_t v, uint64_t* total, uint64_t* lds4) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const uint64_t inc = wave_inclusive_scan_u64(v);
+  if (lane == 63) lds4[wave] = inc;
+  __syncthreads();
+  uint64_t base = 0;
+#pragma unroll
+  for (int w = 0; w < kThreads / 64; w++)
+    if (w < wave) base += lds4[w];
+  *total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+  return base + inc - v;
+}
+
+// ---- the merge kernel ------------------------------------------------------------------------
+// kWrite == false: tile_m[t] = number of common keys in tile t.
+// kWrite == true : compacts the tile's A&B / A\B / B\A keys and writes them at
+//                  tile_ioff[t], tile_a[t] - tile_ioff[t], tile_b[t] - tile_ioff[t].
+template <typename KeyT, typename Segs, bool kWrite>
+__global__ __launch_bounds__(kThreads) void k_tile_merge(
+    Segs segs, int64_t n_segs, const int64_t* __restrict__ tile_base,
+    const int32_t* __restrict__ tile_seg, const int64_t* __restrict__ tile_a,
+    const int64_t* __restrict__ tile_b, int64_t* __restrict__ tile_m,
+    const int64_t* __restrict__ tile_ioff, KeyT* __restrict__ out_i, KeyT* __restrict__ out_amb,
+    KeyT* __restrict__ out_bma) {
+  __shared__ KeyT lds[kTileCap];
+  __shared__ uint64_t lds4[4];
+
+  const int64_t t = blockIdx.x;
+  const int64_t total = tile_base[n_segs];
+  if (t >= total) {
+    if (!kWrite && threadIdx.x == 0) tile_m[t] = 0;
+    return;
+  }
+  const int64_t s = tile_seg[t];
+  const KeyT *a, *b;
+  int64_t a_lo, a_hi, b_lo, b_hi;
+  segs.get(s, a, a_lo, a_hi, b, b_lo, b_hi);
+  const int64_t a0 = tile_a[t], b0 = tile_b[t];
+  int64_t a1 = a_hi, b1 = b_hi;
+  if (t + 1 < total && tile_seg[t + 1] == s) {
+    a1 = tile_a[t + 1];
+    b1 = tile_b[t + 1];
+  }
+  const int ca = int(a1 - a0), cb = int(b1 - b0);
+  KeyT* sa = lds;
+  KeyT* sb = lds + ca;
+  for (int x = threadIdx.x; x < ca; x += kThreads) sa[x] = a[a0 + x];
+  for (int x = threadIdx.x; x < cb; x += kThreads) sb[x] = b[b0 + x];
+  __syncthreads();
+
+  const int n = ca + cb;
+  const int d0 = min(int(threadIdx.x) * kVT, n);
+  const int d1 = min(d0 + kVT, n);
+  // merge-path split of this thread's diagonal (A first on ties)
+  int lo = max(0, d0 - cb), hi = min(d0, ca);
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (sa[mid] <= sb[d0 - 1 - mid]) lo = mid + 1; else hi = mid;
+  }
+  int i = lo, j = d0 - lo;
+
+  KeyT vals[kVT];
+  int cls[kVT];  // 0 = A&B, 1 = A\B, 2 = B\A, 3 = nothing
+  int n_i = 0, n_a = 0, n_b = 0;
+#pragma unroll
+  for (int step = 0; step < kVT; step++) {
+    int c = 3;
+    KeyT v = KeyT(0);
+    if (d0 + step < d1) {
+      const bool has_a = i < ca, has_b = j < cb;
+      const KeyT av = has_a ? sa[i] : KeyT(0);
+      const KeyT bv = has_b ? sb[j] : KeyT(0);
+      if (has_a && (!has_b || av <= bv)) {
+        v = av;
+        c = (has_b && av == bv) ? 0 : 1;
+        i++;
+      } else {
+        v = bv;
+        c = (i > 0 && sa[i - 1] == bv) ? 3 : 2;
+        j++;
+      }
+    }
+    vals[step] = v;
+    cls[step] = c;
+    n_i += c == 0;
+    n_a += c == 1;
+    n_b += c == 2;
+  }
+
+  const uint64_t packed = uint64_t(n_i) | (uint64_t(n_a) << 20) | (uint64_t(n_b) << 40);
+  uint64_t tot;
+  const uint64_t excl = block_exclusive_scan_u64(packed, &tot, lds4);
+  const int tot_i = int(tot & 0xFFFFF), tot_a = int((tot >> 20) & 0xFFFFF), tot_b = int(tot >> 40);
+
+  if (!kWrite) {
+    if (threadIdx.x == 0) tile_m[t] = tot_i;
+    return;
+  }
+
+  // every thread has finished reading sa/sb (the scan's barrier): reuse the LDS
+  int p_i = int(excl & 0xFFFFF);
+  int p_a = tot_i + int((excl >> 20) & 0xFFFFF);
+  int p_b = tot_i + tot_a + int(excl >> 40);
+  __syncthreads();
+#pragma unroll
+  for (int step = 0; step < kVT; step++) {
+    if (cls[step] == 0) lds[p_i++] = vals[step];
+    else if (cls[step] == 1) lds[p_a++] = vals[step];
+    else if (cls[step] == 2) lds[p_b++] = vals[step];
+  }
+  __syncthreads();
+  const int64_t ioff = tile_ioff[t];
+  if (out_i) {
+    KeyT* o = out_i + ioff;
+    for (int x = threadIdx.x; x < tot_i; x += kThreads) o[x] = lds[x];
+  }
+  if (out_amb) {
+    KeyT* o = out_amb + (a0 - ioff);
+    for (int x = threadIdx.x; x < tot_a; x += kThreads) o[x] = lds[tot_i + x];
+  }
+  if (out_bma) {
+    KeyT* o = out_bma + (b0 - ioff);
+    for (int x = threadIdx.x; x < tot_b; x += kThreads) o[x] = lds[tot_i + tot_a + x];
+  }
+}
+
+// Bucket offsets of the three results from the per-tile prefix of common keys.
+__global__ __launch_bounds__(256) void k_result_offsets(
+    const int64_t* __restrict__ a_off, const int64_t* __restrict__ b_off,
+    const int64_t* __restrict__ tile_base, const int64_t* __restrict__ tile_ioff,
+    const int64_t* __restrict__ total_m, int64_t n_buckets, int64_t* __restrict__ off_i,
+    int64_t* __restrict__ off_amb, int64_t* __restrict__ off_bma, int64_t* __restrict__ totals3) {
+  const int64_t s = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (s > n_buckets) return;
+  const int64_t total_tiles = tile_base[n_buckets];
+  const int64_t first = tile_base[s];
+  const int64_t m = first < total_tiles ? tile_ioff[first] : *total_m;
+  off_i[s] = m;
+  off_amb[s] = a_off[s] - m;
+  off_bma[s] = b_off[s] - m;
+  if (s == n_buckets) {
+    totals3[0] = m;
+    totals3[1] = a_off[s] - m;
+    totals3[2] = b_off[s] - m;
+  }
+}
+
+// weights[p] = common keys over the segments [p * n_ids, (p + 1) * n_ids).
+__global__ __launch_bounds__(256) void k_pair_weight_gather(
+    const int64_t* __restrict__ tile_base, const int64_t* __restrict__ tile_ioff,
+    const int64_t* __restrict__ total_m, int64_t n_segs, int32_t n_ids, int32_t n_pairs,
+    int64_t* __restrict__ weights) {
+  const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= n_pairs) return;
+  const int64_t total_tiles = tile_base[n_segs];
+  const int64_t t0 = tile_base[int64_t(p) * n_ids];
+  const int64_t t1 = tile_base[int64_t(p + 1) * n_ids];
+  const int64_t m0 = t0 < total_tiles ? tile_ioff[t0] : *total_m;
+  const int64_t m1 = t1 < total_tiles ? tile_ioff[t1] : *total_m;
+  weights[p] = m1 - m0;
+}
+
+// ---- host-side plan ------------------------------------------------------------------------------
+struct Plan {
+  int64_t n_segs = 0;
+  int64_t max_tiles = 0;
+  int64_t* tile_base = nullptr;  // n_segs + 1
+  int32_t* tile_seg = nullptr;   // max_tiles
+  int64_t* tile_a = nullptr;     // max_tiles
+  int64_t* tile_b = nullptr;     // max_tiles
+  int64_t* tile_ioff = nullptr;  // max_tiles (count, then exclusive prefix in place)
+  int64_t* total_m = nullptr;    // 1
+};
+
+inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+
+inline size_t plan_bytes(int64_t n_segs, int64_t max_tiles) {
+  return align256(size_t(n_segs + 1) * 8) + align256(size_t(max_tiles) * 4) +
+         3 * align256(size_t(max_tiles) * 8) + 256;
+}
+
+inline void plan_carve(char* base, int64_t n_segs, int64_t max_tiles, Plan* p) {
+  p->n_segs = n_segs;
+  p->max_tiles = max_tiles;
+  char* at = base;
+  p->tile_base = reinterpret_cast<int64_t*>(at);
+  at += align256(size_t(n_segs + 1) * 8);
+  p->tile_seg = reinterpret_cast<int32_t*>(at);
+  at += align256(size_t(max_tiles) * 4);
+  p->tile_a = reinterpret_cast<int64_t*>(at);
+  at += align256(size_t(max_tiles) * 8);
+  p->tile_b = reinterpret_cast<int64_t*>(at);
+  at += align256(size_t(max_tiles) * 8);
+  p->tile_ioff = reinterpret_cast<int64_t*>(at);
+  at += align256(size_t(max_tiles) * 8);
+  p->total_m = reinterpret_cast<int64_t*>(at);
+}
+
+inline unsigned blocks_for(int64_t n, int per) { return unsigned(std::max<int64_t>(1, (n + per - 1) / per)); }
+
+// Tiles per segment -> tile_base (exclusive prefix, total at [n_segs]).
+template <typename KeyT, typename Segs>
+int plan_tile_base(ksh_ctx* ctx, const Segs& segs, int64_t n_segs, int64_t* tile_base) {
+  hipLaunchKernelGGL((k_seg_tiles<KeyT, Segs>), dim3(blocks_for(n_segs, 256)), dim3(256), 0,
+                     ctx->stream, segs, n_segs, tile_base);
+  KSH_TRY(scan_exclusive_i64(ctx, tile_base, tile_base, n_segs, tile_base + n_segs));
+  return KSH_OK;
+}
+
+// Splits + count pass + prefix of the per-tile counts.
+template <typename KeyT, typename Segs>
+int plan_count(ksh_ctx* ctx, const Segs& segs, const Plan& p, int timer_kind) {
+  hipLaunchKernelGGL((k_tile_split<KeyT, Segs>), dim3(blocks_for(p.max_tiles, 256)), dim3(256), 0,
+                     ctx->stream, segs, p.n_segs, p.tile_base, p.tile_seg, p.tile_a, p.tile_b);
+  {
+    Timer timer(ctx, timer_kind);
+    hipLaunchKernelGGL((k_tile_merge<KeyT, Segs, false>), dim3(unsigned(p.max_tiles)),
+                       dim3(kThreads), 0, ctx->stream, segs, p.n_segs, p.tile_base, p.tile_seg,
+                       p.tile_a, p.tile_b, p.tile_ioff, nullptr, nullptr, nullptr, nullptr);
+  }
+  KSH_TRY(scan_exclusive_i64(ctx, p.tile_ioff, p.tile_ioff, p.max_tiles, p.total_m));
+  KSH_HIP(hipGetLastError());
+  return KSH_OK;
+}
+
+int check_view(const ksh_set_view* v, const char* name) {
+  if (!v) return fail(KSH_INVALID_ARGUMENT, "%s is NULL", name);
+  if (!v->d_offsets) return fail(KSH_INVALID_ARGUMENT, "%s.d_offsets is NULL", name);
+  if (v->n_keys < 0) return fail(KSH_INVALID_ARGUMENT, "%s.n_keys < 0", name);
+  if (v->n_keys > 0 && !v->d_keys) return fail(KSH_INVALID_ARGUMENT, "%s.d_keys is NULL", name);
+  if (reinterpret_cast<uintptr_t>(v->d_keys) & 15)
+    return fail(KSH_INVALID_ARGUMENT, "%s.d_keys must be 16-byte aligned", name);
+  return KSH_OK;
+}
+
+template <typename KeyT>
+int pair_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
+                int64_t* d_off_i, int64_t* d_off_amb, int64_t* d_off_bma, int64_t totals[3]) {
+  const int64_t nb = n_buckets(g);
+  const int64_t max_tiles = nb + (a->n_keys + b->n_keys) / kTile + 1;
+  if (max_tiles > int64_t(0x7FFFFFF0)) return fail(KSH_INVALID_ARGUMENT, "pair too large for one launch");
+  KSH_TRY(plan_reserve(ctx, plan_bytes(nb, max_tiles)));
+  KSH_TRY(arena_reserve(ctx, size_t(max_tiles / 256 + 4096) * 8 + (1u << 16)));
+  arena_reset(ctx);
+  Plan p;
+  plan_carve(ctx->plan, nb, max_tiles, &p);
+  BucketSegs<KeyT> segs{static_cast<const KeyT*>(a->d_keys), a->d_offsets,
+                        static_cast<const KeyT*>(b->d_keys), b->d_offsets};
+  KSH_TRY((plan_tile_base<KeyT>(ctx, segs, nb, p.tile_base)));
+  KSH_TRY((plan_count<KeyT>(ctx, segs, p, 1)));
+  int64_t* d_totals = static_cast<int64_t*>(arena_alloc(ctx, 3 * sizeof(int64_t)));
+  if (!d_totals) return fail(KSH_INTERNAL, "scratch arena too small");
+  hipLaunchKernelGGL(k_result_offsets, dim3(blocks_for(nb + 1, 256)), dim3(256), 0, ctx->stream,
+                     a->d_offsets, b->d_offsets, p.tile_base, p.tile_ioff, p.total_m, nb, d_off_i,
+                     d_off_amb, d_off_bma, d_totals);
+  KSH_HIP(hipGetLastError());
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, d_totals, 3 * sizeof(int64_t), hipMemcpyDeviceToHost,
+                         ctx->stream));
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  totals[0] = ctx->h_pinned[0];
+  totals[1] = ctx->h_pinned[1];
+  totals[2] = ctx->h_pinned[2];
+  ctx->plan_tiles = max_tiles;
+  ctx->plan_buckets = nb;
+  ctx->plan_a_keys = a->d_keys;
+  ctx->plan_b_keys = b->d_keys;
+  return KSH_OK;
+}
+
+template <typename KeyT>
+int pair_write_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
+                 void* d_keys_i, void* d_keys_amb, void* d_keys_bma) {
+  const int64_t nb = n_buckets(g);
+  if (!ctx->plan || ctx->plan_buckets != nb || ctx->plan_a_keys != a->d_keys ||
+      ctx->plan_b_keys != b->d_keys)
+    return fail(KSH_FAILED_PRECONDITION, "ksh_pair_write without a matching ksh_pair_plan");
+  Plan p;
+  plan_carve(ctx->plan, nb, ctx->plan_tiles, &p);
+  BucketSegs<KeyT> segs{static_cast<const KeyT*>(a->d_keys), a->d_offsets,
+                        static_cast<const KeyT*>(b->d_keys), b->d_offsets};
+  {
+    Timer timer(ctx, 0);
+    hipLaunchKernelGGL((k_tile_merge<KeyT, BucketSegs<KeyT>, true>), dim3(unsigned(p.max_tiles)),
+                       dim3(kThreads), 0, ctx->stream, segs, p.n_segs, p.tile_base, p.tile_seg,
+                       p.tile_a, p.tile_b, nullptr, p.tile_ioff, static_cast<KeyT*>(d_keys_i),
+                       static_cast<KeyT*>(d_keys_amb), static_cast<KeyT*>(d_keys_bma));
+  }
+  KSH_HIP(hipGetLastError());
+  return KSH_OK;
+}
+
+template <typename KeyT>
+int set_diff_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
+               int64_t* diff) {
+  const int64_t nb = n_buckets(g);
+  const int64_t max_tiles = nb + (a->n_keys + b->n_keys) / kTile + 1;
+  if (max_tiles > int64_t(0x7FFFFFF0)) return fail(KSH_INVALID_ARGUMENT, "pair too large for one launch");
+  KSH_TRY(arena_reserve(ctx, plan_bytes(nb, max_tiles) + size_t(max_tiles / 256 + 4096) * 8 + (1u << 16)));
+  arena_reset(ctx);
+  char* base = static_cast<char*>(arena_alloc(ctx, plan_bytes(nb, max_tiles)));
+  Plan p;
+  plan_carve(base, nb, max_tiles, &p);
+  BucketSegs<KeyT> segs{static_cast<const KeyT*>(a->d_keys), a->d_offsets,
+                        static_cast<const KeyT*>(b->d_keys), b->d_offsets};
+  KSH_TRY((plan_tile_base<KeyT>(ctx, segs, nb, p.tile_base)));
+  KSH_TRY((plan_count<KeyT>(ctx, segs, p, 1)));
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, p.total_m, sizeof(int64_t), hipMemcpyDeviceToHost,
+                         ctx->stream));
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  *diff = a->n_keys + b->n_keys - 2 * ctx->h_pinned[0];
+  return KSH_OK;
+}
+
+template <typename KeyT>
+int pair_weights_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sets, int32_t n_sets,
+                   const int32_t* bucket_ids, int32_t n_ids, const int32_t* pairs, int32_t n_pairs,
+                   int64_t* weights) {
+  (void)g;
+  const int64_t n_segs = int64_t(n_pairs) * n_ids;
+  // stage the descriptors
+  const size_t desc_bytes = align256(size_t(n_sets) * sizeof(SetPtrs)) +
+                            align256(size_t(n_ids) * 4) + align256(size_t(n_pairs) * 8) +
+                            align256(size_t(n_pairs) * 8);
+  const size_t base_bytes = align256(size_t(n_segs + 1) * 8);
+  KSH_TRY(arena_reserve(ctx, desc_bytes + base_bytes + size_t(n_segs / 256 + 4096) * 8 + (1u << 16)));
+  arena_reset(ctx);
+  SetPtrs* d_sets = static_cast<SetPtrs*>(arena_alloc(ctx, size_t(n_sets) * sizeof(SetPtrs)));
+  int32_t* d_ids = static_cast<int32_t*>(arena_alloc(ctx, size_t(n_ids) * 4));
+  int32_t* d_pairs = static_cast<int32_t*>(arena_alloc(ctx, size_t(n_pairs) * 8));
+  int64_t* d_weights = static_cast<int64_t*>(arena_alloc(ctx, size_t(n_pairs) * 8));
+  int64_t* tile_base = static_cast<int64_t*>(arena_alloc(ctx, size_t(n_segs + 1) * 8));
+  if (!d_sets || !d_ids || !d_pairs || !d_weights || !tile_base)
+    return fail(KSH_INTERNAL, "scratch arena too small");
+  std::vector<SetPtrs> h_sets(static_cast<size_t>(n_sets));
+  for (int32_t i = 0; i < n_sets; i++) h_sets[i] = SetPtrs{sets[i].d_keys, sets[i].d_offsets};
+  KSH_HIP(hipMemcpyAsync(d_sets, h_sets.data(), size_t(n_sets) * sizeof(SetPtrs),
+                         hipMemcpyHostToDevice, ctx->stream));
+  KSH_HIP(hipMemcpyAsync(d_ids, bucket_ids, size_t(n_ids) * 4, hipMemcpyHostToDevice, ctx->stream));
+  KSH_HIP(hipMemcpyAsync(d_pairs, pairs, size_t(n_pairs) * 8, hipMemcpyHostToDevice, ctx->stream));
+  PairSegs<KeyT> segs{d_sets, d_ids, d_pairs, n_ids};
+  KSH_TRY((plan_tile_base<KeyT>(ctx, segs, n_segs, tile_base)));
+  // exact tile count (the sampled slices are ~2 % of each set; no useful bound without it)
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, tile_base + n_segs, sizeof(int64_t), hipMemcpyDeviceToHost,
+                         ctx->stream));
+  KSH_HIP(hipStreamSynchronize(ctx->stream));  // also keeps h_sets alive long enough
+  const int64_t n_tiles = std::max<int64_t>(ctx->h_pinned[0], 1);
+  if (n_tiles > int64_t(0x7FFFFFF0)) return fail(KSH_INVALID_ARGUMENT, "too many tiles for one launch");
+  // the remaining plan arrays: keep what is already in the arena, so grow by allocating a second
+  // block if needed
+  const size_t rest = plan_bytes(0, n_tiles) + size_t(n_tiles / 256 + 4096) * 8 + (1u << 16);
+  if (ctx->arena_used + rest > ctx->arena_bytes) {
+    // re-run with a bigger arena (descriptors are re-staged); rare: first call at a new size
+    KSH_TRY(arena_reserve(ctx, ctx->arena_used + rest + desc_bytes + base_bytes));
+    return pair_weights_t<KeyT>(ctx, g, sets, n_sets, bucket_ids, n_ids, pairs, n_pairs, weights);
+  }
+  char* base = static_cast<char*>(arena_alloc(ctx, plan_bytes(0, n_tiles)));
+  Plan p;
+  plan_carve(base, 0, n_tiles, &p);
+  p.n_segs = n_segs;
+  p.tile_base = tile_base;
+  KSH_TRY((plan_count<KeyT>(ctx, segs, p, 2)));
+  hipLaunchKernelGGL(k_pair_weight_gather, dim3(blocks_for(n_pairs, 256)), dim3(256), 0,
+                     ctx->stream, p.tile_base, p.tile_ioff, p.total_m, n_segs, n_ids, n_pairs,
+                     d_weights);
+  KSH_HIP(hipGetLastError());
+  KSH_HIP(hipMemcpyAsync(weights, d_weights, size_t(n_pairs) * 8, hipMemcpyDeviceToHost,
+                         ctx->stream));
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  return KSH_OK;
+}
+
+}  // namespace ksh
+
+using namespace ksh;
+
+extern "C" {
+
+int ksh_pair_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
+                  int64_t* d_off_i, int64_t* d_off_amb, int64_t* d_off_bma, int64_t totals[3]) {
+  if (!ctx || !d_off_i || !d_off_amb || !d_off_bma || !totals)
+    return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  KSH_TRY(check_geom(g));
+  KSH_TRY(check_view(a, "a"));
+  KSH_TRY(check_view(b, "b"));
+  KSH_HIP(hipSetDevice(ctx->device));
+  return g->key_bytes == 4 ? pair_plan_t<uint32_t>(ctx, g, a, b, d_off_i, d_off_amb, d_off_bma, totals)
+                           : pair_plan_t<uint64_t>(ctx, g, a, b, d_off_i, d_off_amb, d_off_bma, totals);
+}
+
+int ksh_pair_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
+                   void* d_keys_i, void* d_keys_amb, void* d_keys_bma) {
+  if (!ctx) return fail(KSH_INVALID_ARGUMENT, "ctx is NULL");
+  KSH_TRY(check_geom(g));
+  KSH_TRY(check_view(a, "a"));
+  KSH_TRY(check_view(b, "b"));
+  KSH_HIP(hipSetDevice(ctx->device));
+  return g->key_bytes == 4 ? pair_write_t<uint32_t>(ctx, g, a, b, d_keys_i, d_keys_amb, d_keys_bma)
+                           : pair_write_t<uint64_t>(ctx, g, a, b, d_keys_i, d_keys_amb, d_keys_bma);
+}
+
+int ksh_set_diff(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
+                 int64_t* diff) {
+  if (!ctx || !diff) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  KSH_TRY(check_geom(g));
+  KSH_TRY(check_view(a, "a"));
+  KSH_TRY(check_view(b, "b"));
+  KSH_HIP(hipSetDevice(ctx->device));
+  return g->key_bytes == 4 ? set_diff_t<uint32_t>(ctx, g, a, b, diff)
+                           : set_diff_t<uint64_t>(ctx, g, a, b, diff);
+}
+
+int ksh_pair_weights(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sets, int32_t n_sets,
+                     const int32_t* bucket_ids, int32_t n_ids, const int32_t* pairs,
+                     int32_t n_pairs, int64_t* weights) {
+  if (!ctx || !sets || !weights) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  KSH_TRY(check_geom(g));
+  if (n_pairs <= 0) return KSH_OK;
+  if (n_ids <= 0) {
+    for (int32_t p = 0; p < n_pairs; p++) weights[p] = 0;
+    return KSH_OK;
+  }
+  if (!bucket_ids || !pairs) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  const int64_t nb = n_buckets(g);
+  for (int32_t i = 0; i < n_ids; i++)
+    if (bucket_ids[i] < 0 || bucket_ids[i] >= nb)
+      return fail(KSH_INVALID_ARGUMENT, "bucket_ids[%d] = %d is outside [0, 2^N)", i, bucket_ids[i]);
+  for (int32_t p = 0; p < 2 * n_pairs; p++)
+    if (pairs[p] < 0 || pairs[p] >= n_sets)
+      return fail(KSH_INVALID_ARGUMENT, "pairs[%d] = %d is outside [0, n_sets)", p, pairs[p]);
+  for (int32_t i = 0; i < n_sets; i++) KSH_TRY(check_view(&sets[i], "sets[i]"));
+  KSH_HIP(hipSetDevice(ctx->device));
+  return g->key_bytes == 4
+             ? pair_weights_t<uint32_t>(ctx, g, sets, n_sets, bucket_ids, n_ids, pairs, n_pairs, weights)
+             : pair_weights_t<uint64_t>(ctx, g, sets, n_sets, bucket_ids, n_ids, pairs, n_pairs, weights);
+}
+
+}  // extern "C"

@@ -1,0 +1,254 @@
+"""ctypes binding of include/kmersets_hip.h (libkmersets_hip.so, HIP/gfx950).
+
+Device memory is owned by torch tensors (plumbing); the C ABI only ever sees raw
+device pointers.  There is no CPU fallback: if the library is missing or no GPU is
+visible, calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC_DIR = os.path.join(PKG_DIR, "csrc")
+LIB_PATH = os.path.join(CSRC_DIR, "libkmersets_hip.so")
+ROOT = os.path.dirname(PKG_DIR)
+HEADER = os.path.join(ROOT, "include", "kmersets_hip.h")
+
+KSH_OK, KSH_INVALID_ARGUMENT, KSH_FAILED_PRECONDITION, KSH_INTERNAL = 0, 3, 9, 13
+
+
+class KshError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__("ksh error %d: %s" % (code, message))
+        self.code = code
+
+
+class Geom(C.Structure):
+    _fields_ = [("k", C.c_int32), ("n_bucket_bits", C.c_int32), ("key_bytes", C.c_int32),
+                ("reserved", C.c_int32)]
+
+
+class SetView(C.Structure):
+    _fields_ = [("d_offsets", C.c_void_p), ("d_keys", C.c_void_p), ("n_keys", C.c_int64)]
+
+
+def build(force=False):
+    """Compiles the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
+    srcs = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith((".hip", ".h"))]
+    srcs.append(HEADER)
+    if force or not os.path.exists(LIB_PATH) or any(
+            os.path.getmtime(s) > os.path.getmtime(LIB_PATH) for s in srcs):
+        subprocess.check_call(["make", "-C", CSRC_DIR, "-s", "-j4"])
+    return LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "%s is missing: run __graft_entry__.build() (make -C %s). "
+            "The k-mer set hot path has no CPU fallback." % (LIB_PATH, CSRC_DIR))
+    # torch ships its own libamdhip64; load it first so that this library binds to the
+    # same HIP runtime (two runtimes in one process cannot both open the device).
+    import torch  # noqa: F401
+
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
+    GP, SP = C.POINTER(Geom), C.POINTER(SetView)
+    sig = {
+        "ksh_version": (C.c_int, []),
+        "ksh_last_error": (C.c_char_p, []),
+        "ksh_device_count": (C.c_int, [C.POINTER(C.c_int)]),
+        "ksh_malloc": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(vp)]),
+        "ksh_free": (C.c_int, [C.c_int, vp]),
+        "ksh_memcpy_h2d": (C.c_int, [C.c_int, vp, vp, C.c_size_t]),
+        "ksh_memcpy_d2h": (C.c_int, [C.c_int, vp, vp, C.c_size_t]),
+        "ksh_ctx_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
+        "ksh_ctx_destroy": (C.c_int, [vp]),
+        "ksh_ctx_sync": (C.c_int, [vp]),
+        "ksh_ctx_reserve": (C.c_int, [vp, C.c_size_t]),
+        "ksh_ctx_enable_timing": (C.c_int, [vp, C.c_int]),
+        "ksh_ctx_timing_reset": (C.c_int, [vp]),
+        "ksh_ctx_timing_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(i64)]),
+        "ksh_set_hash": (C.c_int, [vp, GP, SP, C.POINTER(C.c_uint64)]),
+        "ksh_pair_plan": (C.c_int, [vp, GP, SP, SP, vp, vp, vp, C.POINTER(i64)]),
+        "ksh_pair_write": (C.c_int, [vp, GP, SP, SP, vp, vp, vp]),
+        "ksh_set_diff": (C.c_int, [vp, GP, SP, SP, C.POINTER(i64)]),
+        "ksh_pair_weights": (C.c_int, [vp, GP, SP, i32, C.POINTER(i32), i32, C.POINTER(i32), i32,
+                                       C.POINTER(i64)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def exported_symbols():
+    """Names declared in include/kmersets_hip.h (parsed from the header)."""
+    import re
+
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ksh_[a-z0-9_]+)\s*\(", text)))
+
+
+def check(rc):
+    if rc != KSH_OK:
+        raise KshError(rc, lib().ksh_last_error().decode())
+
+
+def geom(k, n_bucket_bits, key_bytes=None):
+    if key_bytes is None:
+        key_bytes = 4 if 2 * k - n_bucket_bits <= 32 else 8
+    return Geom(k, n_bucket_bits, 4 if key_bytes <= 4 else 8, 0)
+
+
+class DeviceSet:
+    """A k-mer set resident in HBM: offsets int64[2^N+1] + sorted keys (u32/u64 bytes)."""
+
+    def __init__(self, g, offsets, keys_bytes, n_keys):
+        self.g, self.offsets, self.keys, self.n_keys = g, offsets, keys_bytes, int(n_keys)
+
+    @classmethod
+    def from_numpy(cls, g, offsets, keys, device):
+        import torch
+
+        kdt = np.uint32 if g.key_bytes == 4 else np.uint64
+        keys = np.ascontiguousarray(keys, dtype=kdt)
+        off_t = torch.from_numpy(np.ascontiguousarray(offsets, dtype=np.int64)).to(device)
+        raw = torch.from_numpy(keys.view(np.uint8).copy()) if keys.size else torch.zeros(0, dtype=torch.uint8)
+        key_t = torch.empty(max(raw.numel(), 16), dtype=torch.uint8, device=device)
+        key_t[: raw.numel()] = raw.to(device)
+        return cls(g, off_t, key_t, keys.size)
+
+    @classmethod
+    def from_kmers(cls, g, kmers, device):
+        from . import synth
+
+        offsets, keys = synth.to_bucketed(kmers, g.k, g.n_bucket_bits, g.key_bytes)
+        return cls.from_numpy(g, offsets, keys, device)
+
+    @classmethod
+    def empty_like_offsets(cls, g, n_keys, device):
+        import torch
+
+        off = torch.empty((1 << g.n_bucket_bits) + 1, dtype=torch.int64, device=device)
+        keys = torch.empty(max(int(n_keys) * g.key_bytes, 16), dtype=torch.uint8, device=device)
+        return cls(g, off, keys, n_keys)
+
+    def view(self):
+        return SetView(self.offsets.data_ptr(), self.keys.data_ptr(), self.n_keys)
+
+    def to_numpy(self):
+        kdt = np.uint32 if self.g.key_bytes == 4 else np.uint64
+        keys = self.keys[: self.n_keys * self.g.key_bytes].cpu().numpy().view(kdt)
+        return self.offsets.cpu().numpy(), keys
+
+    def kmers(self):
+        from . import synth
+
+        off, keys = self.to_numpy()
+        return synth.from_bucketed(off, keys, self.g.k, self.g.n_bucket_bits)
+
+
+class Context:
+    """ksh_ctx on one GPU, bound to torch's current stream on that device."""
+
+    def __init__(self, device_index=0, use_torch_stream=True):
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("no GPU visible: the k-mer set hot path has no CPU fallback")
+        self.device = torch.device("cuda", device_index)
+        torch.cuda.set_device(self.device)
+        stream = torch.cuda.current_stream(self.device).cuda_stream if use_torch_stream else 0
+        h = C.c_void_p()
+        check(lib().ksh_ctx_create(device_index, C.c_void_p(stream), C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ksh_ctx_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def sync(self):
+        check(lib().ksh_ctx_sync(self.h))
+
+    def enable_timing(self, on=True):
+        check(lib().ksh_ctx_enable_timing(self.h, int(on)))
+
+    def timing_reset(self):
+        check(lib().ksh_ctx_timing_reset(self.h))
+
+    def timing_read(self, kind):
+        """(summed ms, launches) of the timed kernel kind since the last reset."""
+        ms, n = C.c_float(), C.c_int64()
+        check(lib().ksh_ctx_timing_read(self.h, kind, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
+
+    # KmerSet::Hash / Size -------------------------------------------------------
+    def set_hash(self, s):
+        out = C.c_uint64()
+        v = s.view()
+        check(lib().ksh_set_hash(self.h, C.byref(s.g), C.byref(v), C.byref(out)))
+        return out.value
+
+    # Intersection / Sub -----------------------------------------------------------
+    def pair_plan(self, a, b, out_i, out_amb, out_bma):
+        totals = (C.c_int64 * 3)()
+        va, vb = a.view(), b.view()
+        check(lib().ksh_pair_plan(self.h, C.byref(a.g), C.byref(va), C.byref(vb),
+                                  out_i.offsets.data_ptr(), out_amb.offsets.data_ptr(),
+                                  out_bma.offsets.data_ptr(), totals))
+        return [int(x) for x in totals]
+
+    def pair_write(self, a, b, out_i, out_amb, out_bma):
+        va, vb = a.view(), b.view()
+        check(lib().ksh_pair_write(self.h, C.byref(a.g), C.byref(va), C.byref(vb),
+                                   out_i.keys.data_ptr() if out_i is not None else None,
+                                   out_amb.keys.data_ptr() if out_amb is not None else None,
+                                   out_bma.keys.data_ptr() if out_bma is not None else None))
+
+    def pair_algebra(self, a, b):
+        """(A & B, A \\ B, B \\ A) as new DeviceSets (exact-size key buffers)."""
+        import torch
+
+        g = a.g
+        outs = [DeviceSet.empty_like_offsets(g, 0, self.device) for _ in range(3)]
+        totals = self.pair_plan(a, b, *outs)
+        for o, n in zip(outs, totals):
+            o.n_keys = n
+            o.keys = torch.empty(max(n * g.key_bytes, 16), dtype=torch.uint8, device=self.device)
+        self.pair_write(a, b, *outs)
+        return outs
+
+    def set_diff(self, a, b):
+        out = C.c_int64()
+        va, vb = a.view(), b.view()
+        check(lib().ksh_set_diff(self.h, C.byref(a.g), C.byref(va), C.byref(vb), C.byref(out)))
+        return out.value
+
+    def pair_weights(self, sets, bucket_ids, pairs):
+        g = sets[0].g
+        views = (SetView * len(sets))(*[s.view() for s in sets])
+        ids = np.ascontiguousarray(bucket_ids, dtype=np.int32)
+        prs = np.ascontiguousarray(pairs, dtype=np.int32).reshape(-1)
+        n_pairs = prs.size // 2
+        out = np.zeros(max(n_pairs, 1), dtype=np.int64)
+        check(lib().ksh_pair_weights(
+            self.h, C.byref(g), views, len(sets),
+            ids.ctypes.data_as(C.POINTER(C.c_int32)), ids.size,
+            prs.ctypes.data_as(C.POINTER(C.c_int32)), n_pairs,
+            out.ctypes.data_as(C.POINTER(C.c_int64))))
+        return out[:n_pairs]

@@ -1,0 +1,186 @@
+"""GPU parity tests: the HIP path, called through the C ABI (include/kmersets_hip.h),
+against the oracle (CPU restatement) on the same seeded inputs, against the
+reference's known answers (tests/golden), and -- at BASELINE config-2 size --
+through size-independent properties.  Bit-exact: integer / index work only.
+
+Run with `pytest -m gpu` on an MI355X.
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from kmersets import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "reference_known_answers.json")
+GEOMS = [(5, 3, 1), (9, 10, 1), (15, 14, 2), (19, 10, 4), (23, 14, 4), (31, 14, 8)]
+
+
+@pytest.fixture(scope="module")
+def ctx(gpu):
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def dev_set(ctx, k, n, kmers):
+    return capi.DeviceSet.from_kmers(capi.geom(k, n), np.asarray(kmers, dtype=np.uint64), ctx.device)
+
+
+def check_algebra(ctx, k, n, kb, ka, kbm, use_oracle=True):
+    """A&B, A\\B, B\\A, Diff, Hash of one pair: GPU vs numpy set algebra (+ oracle)."""
+    a, b = dev_set(ctx, k, n, ka), dev_set(ctx, k, n, kbm)
+    i_d, amb_d, bma_d = ctx.pair_algebra(a, b)
+    want_i = np.intersect1d(ka, kbm)
+    want_amb = np.setdiff1d(ka, kbm)
+    want_bma = np.setdiff1d(kbm, ka)
+    for got, want in ((i_d, want_i), (amb_d, want_amb), (bma_d, want_bma)):
+        assert got.n_keys == want.size
+        off, keys = got.to_numpy()
+        w_off, w_keys = synth.to_bucketed(want, k, n, got.g.key_bytes)
+        assert np.array_equal(off, w_off)
+        assert np.array_equal(keys, w_keys)
+    assert ctx.set_diff(a, b) == want_amb.size + want_bma.size
+    for d, want in ((a, ka), (b, kbm), (i_d, want_i)):
+        h = 0
+        if want.size:
+            h = int(np.bitwise_xor.reduce(want.astype(np.uint64)))
+        assert ctx.set_hash(d) == h
+    if use_oracle:
+        oa, ob = ol.Set.from_kmers(k, n, kb, ka), ol.Set.from_kmers(k, n, kb, kbm)
+        oi = oa.intersection(ob)
+        assert oi.size() == i_d.n_keys and oi.hash() == ctx.set_hash(i_d)
+        assert np.array_equal(oi.kmers(), i_d.kmers())
+        assert np.array_equal(oa.copy().sub_set(oi).kmers(), amb_d.kmers())
+        assert np.array_equal(ob.copy().sub_set(oi).kmers(), bma_d.kmers())
+        assert oa.diff(ob) == ctx.set_diff(a, b)
+        assert oa.hash() == ctx.set_hash(a)
+
+
+def test_reference_known_answers(ctx):
+    """test/kmer_set.cc:72-124 through the HIP path."""
+    g = json.load(open(GOLDEN))
+    op = g["kmer_set_operators"]
+    k, n = op["k"], op["n"]
+    s1 = np.array(sorted(ol.kmer(x) for x in op["set1"]), dtype=np.uint64)
+    s2 = np.array(sorted(ol.kmer(x) for x in op["set2"]), dtype=np.uint64)
+    a, b = dev_set(ctx, k, n, s1), dev_set(ctx, k, n, s2)
+    i_d, amb_d, bma_d = ctx.pair_algebra(a, b)
+    assert i_d.n_keys == op["intersection_size"]
+    assert amb_d.n_keys == op["sub12_size"] and bma_d.n_keys == op["sub21_size"]
+    assert a.n_keys + bma_d.n_keys == op["add_size"]
+    eq = g["kmer_set_equals"]
+    sets = [np.array(sorted(ol.kmer(x) for x in eq[nm]), dtype=np.uint64) for nm in ("set1", "set2", "set3")]
+    d = [dev_set(ctx, k, n, s) for s in sets]
+    assert ctx.set_diff(d[0], d[1]) == 0 and ctx.set_diff(d[1], d[0]) == 0
+    assert ctx.set_diff(d[0], d[2]) != 0 and ctx.set_diff(d[2], d[0]) != 0
+    for x in d:
+        assert ctx.set_diff(x, x) == 0
+    sv = g["survey_known_answers"]
+    for case in sv["cases"]:
+        seq = synth.bases_of_string(case["sequence"])
+        km = synth.canonical_set_of_bases(seq, sv["k"])
+        s = dev_set(ctx, sv["k"], sv["n"], km)
+        assert s.n_keys == case["size"] and ctx.set_hash(s) == case["hash"]
+
+
+@pytest.mark.parametrize("geom", GEOMS)
+def test_pair_algebra_vs_oracle(ctx, geom):
+    k, n, kb = geom
+    size = 150 if k == 5 else 20000
+    sets = synth.phylogeny_sets(k, 4, size, seed=k)
+    for (x, y) in [(0, 1), (0, 3), (2, 2)]:
+        check_algebra(ctx, k, n, kb, sets[x], sets[y])
+    ua, ub = synth.uniform_pair(k, min(size, 4 ** k // 4), 0.5, seed=3 * k)
+    check_algebra(ctx, k, n, kb, ua, ub)
+
+
+@pytest.mark.parametrize("geom", [(23, 14, 4), (31, 14, 8)])
+def test_pair_algebra_edge_cases(ctx, geom):
+    k, n, kb = geom
+    empty = np.zeros(0, dtype=np.uint64)
+    some = synth.phylogeny_sets(k, 1, 5000, seed=1)[0]
+    check_algebra(ctx, k, n, kb, empty, empty)
+    check_algebra(ctx, k, n, kb, empty, some)
+    check_algebra(ctx, k, n, kb, some, empty)
+    check_algebra(ctx, k, n, kb, some, some)
+    check_algebra(ctx, k, n, kb, some[::2].copy(), some[1::2].copy())   # disjoint, interleaved
+    # one heavy bucket, far more keys than one tile, with every kind of tile boundary:
+    # dense runs of common keys so that tile splits land inside "a, b" pairs.
+    kbits = 2 * k - n
+    base = np.uint64(5) << np.uint64(kbits)
+    dense = base + np.arange(0, 40000, dtype=np.uint64)
+    check_algebra(ctx, k, n, kb, dense, dense, use_oracle=False)
+    check_algebra(ctx, k, n, kb, dense[dense % np.uint64(3) != 0], dense[dense % np.uint64(5) != 0],
+                  use_oracle=False)
+    check_algebra(ctx, k, n, kb, dense[:30000], dense[10000:], use_oracle=False)
+    # max key values in the last bucket
+    top = (np.uint64(1) << np.uint64(2 * k)) - np.uint64(1)
+    hi = top - np.arange(0, 3000, dtype=np.uint64)[::-1]
+    check_algebra(ctx, k, n, kb, hi, hi[::3].copy(), use_oracle=False)
+
+
+def test_pair_weights_vs_oracle(ctx):
+    """GetEdgeWeight over sampled buckets (kmer_set_set.h:158-219): the initial weight
+    table of the oracle's KmerSetSet == ksh_pair_weights on resident sets."""
+    k, n, kb = 15, 14, 2
+    sets = synth.phylogeny_sets(k, 6, 30000, seed=21)
+    ids = synth.sample_bucket_ids(n, seed=4)
+    osets = [ol.Set.from_kmers(k, n, kb, s) for s in sets]
+    kss = ol.KmerSetSet([s.compact() for s in osets], ids, max_iterations=0)
+    want = kss.initial_weights(len(sets))
+    dsets = [dev_set(ctx, k, n, s) for s in sets]
+    pairs = [(i, j) for i in range(len(sets)) for j in range(i + 1, len(sets))]
+    got = ctx.pair_weights(dsets, ids, pairs)
+    assert np.array_equal(got, want)
+    assert got.sum() > 0
+    # a pair list with repeats, self pairs and reversed order
+    pairs2 = [(3, 3), (5, 0), (0, 5), (1, 2)]
+    got2 = ctx.pair_weights(dsets, ids, pairs2)
+    want_self = sum(np.count_nonzero((sets[3] >> np.uint64(2 * k - n)) == np.uint64(b)) for b in ids)
+    assert got2[0] == want_self and got2[1] == got2[2] == want[pairs.index((0, 5))]
+    assert got2[3] == want[pairs.index((1, 2))]
+
+
+def test_config2_properties(ctx):
+    """BASELINE config 2 (4 x 10^7 canonical k=23 sets, all 6 pairs) through
+    size-independent properties; sized down by KMERSETS_TEST_SCALE if set."""
+    import torch
+
+    k, n = 23, 14
+    size = int(float(os.environ.get("KMERSETS_TEST_SIZE", "2e6")))
+    sets = synth.phylogeny_sets(k, 4, size, seed=2)
+    d = [dev_set(ctx, k, n, s) for s in sets]
+    hashes = [ctx.set_hash(x) for x in d]
+    for i in range(4):
+        assert hashes[i] == int(np.bitwise_xor.reduce(sets[i]))
+    for i in range(4):
+        for j in range(i + 1, 4):
+            a, b = d[i], d[j]
+            inter, amb, bma = ctx.pair_algebra(a, b)
+            assert inter.n_keys + amb.n_keys == a.n_keys
+            assert inter.n_keys + bma.n_keys == b.n_keys
+            assert ctx.set_hash(inter) ^ ctx.set_hash(amb) == hashes[i]
+            assert ctx.set_hash(inter) ^ ctx.set_hash(bma) == hashes[j]
+            assert ctx.set_diff(a, b) == amb.n_keys + bma.n_keys
+            assert ctx.set_diff(amb, bma) == amb.n_keys + bma.n_keys      # disjoint
+            assert ctx.set_diff(inter, amb) == inter.n_keys + amb.n_keys  # disjoint
+            # idempotence: (A & B) & B == A & B, (A \ B) \ B == A \ B
+            i2, r, _ = ctx.pair_algebra(inter, b)
+            assert i2.n_keys == inter.n_keys and r.n_keys == 0
+            assert ctx.set_diff(i2, inter) == 0
+            _, amb2, _ = ctx.pair_algebra(amb, b)
+            assert ctx.set_diff(amb2, amb) == 0
+            # sortedness inside every bucket and consistent offsets
+            for s in (inter, amb, bma):
+                off = s.offsets
+                assert int(off[0]) == 0 and int(off[-1]) == s.n_keys
+                assert bool(torch.all(off[1:] >= off[:-1]))
+                km = torch.from_numpy(s.kmers().astype(np.int64))
+                assert bool(torch.all(km[1:] > km[:-1]))
+            # exact membership against numpy on this pair
+            assert np.array_equal(inter.kmers(), np.intersect1d(sets[i], sets[j]))

@@ -172,3 +172,24 @@ def from_bucketed(offsets, keys, k, n_bits):
     counts = np.diff(offsets)
     buckets = np.repeat(np.arange(counts.size, dtype=U), counts)
     return (buckets << U(key_bits)) | np.asarray(keys, dtype=U)
+
+
+def circular_with_tails(k, length, n_tails, tail_len, seed):
+    """Canonical k-mers of a circular genome with short branches hanging off it.
+
+    Loops are what the reference's serial passes exist for (spss.h:585-610 for
+    non-branching loops of k-mers, :1578-1644 for loops in the path cover); tails
+    turn one loop of k-mers into a loop of several unitigs.
+    """
+    g = random_genome(length, 0xC1AC0000 + seed)
+    circ = np.concatenate([g, g[:k - 1]])
+    parts = [kmers_of_bases(circ, k)]
+    for t in range(n_tails):
+        r = int(mix64(U((seed << 16) + t + 1)))
+        p = r % length
+        out_going = (r >> 32) & 1
+        tail = random_genome(tail_len, 0x7A110000 + (seed << 8) + t)
+        anchor = circ[p:p + k - 1]
+        seq = np.concatenate([anchor, tail]) if out_going else np.concatenate([tail, anchor])
+        parts.append(kmers_of_bases(seq, k))
+    return np.unique(canonical(np.concatenate(parts), k))

@@ -121,6 +121,51 @@ int ksh_pair_weights(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sets, 
                      const int32_t* bucket_ids, int32_t n_ids, const int32_t* pairs,
                      int32_t n_pairs, int64_t* weights);
 
+/* ---- SPSS container and decode -------------------------------------------------------
+ * KmerSetCompact (lib/core/kmer_set_compact.h:339-347) on device: the strings'
+ * bases, 2 bits each (A=0 C=1 G=2 T=3), concatenated without separators in 64-bit
+ * words -- base j of the stream at bits [63-2(j%32), 62-2(j%32)] of word j/32, i.e.
+ * the reference's vector<bool> index 2j is the high bit (:236-251) -- plus
+ * len - K per string (:222-223). */
+typedef struct ksh_spss_view {
+  const uint64_t* d_words; /* ceil(n_bases / 32) words            */
+  const uint32_t* d_lens;  /* len - K per string                  */
+  int64_t n_strings;
+  int64_t n_bases;         /* = KmerSetCompact::Weight() (:115)   */
+} ksh_spss_view;
+
+/* KmerSetCompact::Size (kmer_set_compact.h:90-112): sum of (len - K + 1). */
+int ksh_spss_size(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int64_t* n_kmers);
+
+/* KmerSetCompact::ToKmerSet = ToStrings + GetKmerSetFromSPSS
+ * (kmer_set_compact.h:52-55,290-336; lib/core/spss.h:1861-1941).
+ * plan : bucket histogram -> d_offsets (int64[2^N + 1]); n_keys = k-mer positions
+ *        (an upper bound on the set size: repeated k-mers collapse in write).
+ * write: scatter + per-bucket sort, duplicates dropped; d_keys holds n_keys(plan)
+ *        keys; d_offsets is rewritten if duplicates were dropped; n_keys = set size. */
+int ksh_spss_decode_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int canonical,
+                         int64_t* d_offsets, int64_t* n_keys);
+int ksh_spss_decode_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int canonical,
+                          int64_t* d_offsets, void* d_keys, int64_t* n_keys);
+
+/* ---- SPSS encode ----------------------------------------------------------------------
+ * mode 0: KmerSetCompact::FromKmerSet(set, canonical = true, fast = true)
+ *         = GetSPSSCanonical (lib/core/spss.h:1835-1858: unitigs, greedy path cover,
+ *         loop cut, stitch) + the 2-bit packing constructor
+ *         (lib/core/kmer_set_compact.h:36-47,206-266).
+ * mode 1: GetUnitigsCanonical (lib/core/spss.h:230-615), every unitig a string.
+ * The strings and their order are the oracle's (the reference's n_workers == 1
+ * control flow with ascending iteration).  Only canonical sets.
+ * plan : everything up to the string layout; returns the container's sizes.
+ * write: d_words = ceil(n_bases / 32) words, d_lens = n_strings values (len - K). */
+int ksh_spss_encode_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* set, int canonical,
+                         int mode, int64_t* n_strings, int64_t* n_bases);
+int ksh_spss_encode_write(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens);
+/* stats = { unitigs, matching rounds, strings, bases } of the current plan. */
+int ksh_spss_encode_stats(ksh_ctx* ctx, int64_t stats[4]);
+/* Frees the current plan's device memory (also done by the next plan / ctx_destroy). */
+int ksh_spss_encode_release(ksh_ctx* ctx);
+
 #ifdef __cplusplus
 }
 #endif

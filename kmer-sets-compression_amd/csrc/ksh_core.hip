@@ -63,6 +63,18 @@ void* arena_alloc(ksh_ctx* ctx, size_t bytes) {
   return ctx->arena + at;
 }
 
+int slot_reserve(ksh_ctx* ctx, int which, size_t bytes) {
+  if (bytes <= ctx->slot_bytes[which]) return KSH_OK;
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->slot[which]) KSH_HIP(hipFree(ctx->slot[which]));
+  ctx->slot[which] = nullptr;
+  ctx->slot_bytes[which] = 0;
+  size_t want = bytes + (bytes >> 3) + (1u << 16);
+  KSH_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->slot[which]), want));
+  ctx->slot_bytes[which] = want;
+  return KSH_OK;
+}
+
 hipEvent_t timer_event(ksh_ctx* ctx, size_t* index) {
   if (ctx->ev_next == ctx->ev_pool.size()) {
     hipEvent_t e = nullptr;
@@ -314,8 +326,11 @@ int ksh_ctx_destroy(ksh_ctx* ctx) {
   if (!ctx) return KSH_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  free_plan(ctx);
   if (ctx->arena) (void)hipFree(ctx->arena);
   if (ctx->plan) (void)hipFree(ctx->plan);
+  for (int i = 0; i < 2; i++)
+    if (ctx->slot[i]) (void)hipFree(ctx->slot[i]);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   for (hipEvent_t ev : ctx->ev_pool)
     if (ev) (void)hipEventDestroy(ev);

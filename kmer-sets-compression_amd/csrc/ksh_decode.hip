@@ -1,0 +1,436 @@
+// SPSS decode: packed 2-bit strings -> bucketed sorted key set.
+//
+// Replaces KmerSetCompact::ToKmerSet = ToStrings + GetKmerSetFromSPSS
+// (lib/core/kmer_set_compact.h:52-55,290-336; lib/core/spss.h:1861-1941), which
+// rebuilds a std::string per SPSS string, parses every k-mer from a substr and
+// inserts it into 2^N hash sets behind try_lock spins.  Here:
+//
+//   k_str_bases      lens (len - K) -> bases per string; scan -> string starts
+//   k_mark_ends      one bit per base position: "last base of a string"
+//   k_decode<false>  every thread owns one 64-bit word (32 positions), builds the
+//                    forward and reverse-complement k-mers by rolling, keeps the
+//                    canonical one, counts buckets in an LDS histogram;
+//                    per-workgroup histograms go to a [groups][2^N] matrix
+//   k_hist_columns   column sums -> bucket offsets, and per-(group, bucket) bases
+//   k_decode<true>   same walk again, scatters the key into its bucket slot
+//   k_bucket_sort    one workgroup per bucket: bitonic sort in LDS, duplicates dropped
+//                    (GetKmerSetFromSPSS inserts into sets, so repeated k-mers of a
+//                    hand-written input collapse; a real SPSS has none)
+//
+// Compulsory HBM traffic per k-mer: w/4 bytes of bases read twice + the key written,
+// read and written once more = about 3 * key_bytes + w/2.
+#include "ksh_internal.h"
+#include "ksh_kmer.h"
+
+#include <algorithm>
+
+namespace ksh {
+
+constexpr int kDecThreads = 256;
+constexpr int kMaxLdsBuckets = 16384;   // 64 KiB of u32 counters
+constexpr int kSortLdsBytes = 61440;   // + a few static bytes stays under 64 KiB
+
+__global__ __launch_bounds__(256) void k_str_bases(const uint32_t* __restrict__ lens, int64_t n,
+                                                    int k, int64_t* __restrict__ bases) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) bases[i] = int64_t(lens[i]) + k;
+}
+
+// end_bits: bit (p & 63) of word p >> 6 is set iff base p is the last base of a string.
+__global__ __launch_bounds__(256) void k_mark_ends(const int64_t* __restrict__ str_start,
+                                                    int64_t n_strings,
+                                                    unsigned long long* __restrict__ end_bits) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_strings) return;
+  const int64_t p = str_start[i + 1] - 1;
+  atomicOr(&end_bits[p >> 6], 1ull << (p & 63));
+}
+
+// Sum of (len - K + 1) = number of k-mers = KmerSetCompact::Size (kmer_set_compact.h:90-112).
+__global__ __launch_bounds__(256) void k_sum_lens(const uint32_t* __restrict__ lens, int64_t n,
+                                                   unsigned long long* __restrict__ out) {
+  unsigned long long acc = 0;
+  for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n;
+       i += int64_t(gridDim.x) * blockDim.x)
+    acc += lens[i];
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if ((threadIdx.x & 63) == 0 && acc) atomicAdd(out, acc);
+}
+
+// kScatter == false: hist_matrix[group][bucket] = k-mers of this group's words in that bucket.
+// kScatter == true : hist_matrix holds the exclusive per-bucket base of each group; keys go to
+//                    keys[offsets[bucket] + base + rank].
+template <typename KeyT, bool kScatter>
+__global__ __launch_bounds__(kDecThreads) void k_decode(
+    const uint64_t* __restrict__ words, int64_t n_words, int64_t n_bases,
+    const unsigned long long* __restrict__ end_bits, int64_t n_end_words, int k, int key_bits,
+    int n_buckets, int canonical_flag, int64_t words_per_group, uint32_t* __restrict__ hist_matrix,
+    const int64_t* __restrict__ offsets, KeyT* __restrict__ keys) {
+  extern __shared__ uint32_t lds_hist[];
+  uint32_t* my_row = hist_matrix + int64_t(blockIdx.x) * n_buckets;
+  for (int b = threadIdx.x; b < n_buckets; b += kDecThreads) lds_hist[b] = kScatter ? my_row[b] : 0u;
+  __syncthreads();
+
+  const int64_t w_begin = int64_t(blockIdx.x) * words_per_group;
+  const int64_t w_end = min(w_begin + words_per_group, n_words);
+  const uint64_t mask = kmer_mask(k);
+  const uint64_t key_mask = (uint64_t(1) << key_bits) - 1;
+  const uint64_t no_end_mask = (uint64_t(1) << (k - 1)) - 1;  // bits p .. p+K-2 must be clear
+
+  for (int64_t w = w_begin + threadIdx.x; w < w_end; w += kDecThreads) {
+    const uint64_t w0 = words[w];
+    const uint64_t w1 = (w + 1 < n_words) ? words[w + 1] : 0;
+    // end bits for positions 32w .. 32w + 63
+    const int64_t p0 = w << 5;
+    const int64_t ew = p0 >> 6;
+    const int esh = int(p0 & 63);
+    uint64_t eb = end_bits[ew] >> esh;
+    if (esh && ew + 1 < n_end_words) eb |= end_bits[ew + 1] << (64 - esh);
+
+    // first k-mer of the word: bases p0 .. p0+K-1 = top 2K bits of w0:w1
+    uint64_t fw = (k <= 32) ? (w0 >> (64 - 2 * k)) : 0;  // k <= 31 always
+    uint64_t rc = revcomp(fw, k);
+#pragma unroll 4
+    for (int j = 0; j < 32; j++) {
+      const int64_t p = p0 + j;
+      const bool valid = (p + k <= n_bases) && (((eb >> j) & no_end_mask) == 0);
+      if (valid) {
+        const uint64_t cn = (canonical_flag && rc < fw) ? rc : fw;
+        const uint32_t bucket = uint32_t(cn >> key_bits);
+        if (kScatter) {
+          const uint32_t rel = atomicAdd(&lds_hist[bucket], 1u);
+          keys[offsets[bucket] + rel] = KeyT(cn & key_mask);
+        } else {
+          atomicAdd(&lds_hist[bucket], 1u);
+        }
+      }
+      // roll: the base entering is base p + K
+      const int q = j + k;  // position inside the 64-base window w0:w1
+      const uint64_t nb = q < 32 ? (w0 >> (62 - 2 * q)) & 3 : (w1 >> (62 - 2 * (q - 32))) & 3;
+      fw = ((fw << 2) & mask) | nb;
+      rc = (rc >> 2) | ((3 - nb) << (2 * (k - 1)));
+    }
+  }
+  if (!kScatter) {
+    __syncthreads();
+    for (int b = threadIdx.x; b < n_buckets; b += kDecThreads) my_row[b] = lds_hist[b];
+  }
+}
+
+// One thread per bucket: exclusive running sum down the groups; totals[b] = column sum.
+__global__ __launch_bounds__(256) void k_hist_columns(uint32_t* __restrict__ hist_matrix,
+                                                       int64_t n_groups, int n_buckets,
+                                                       int64_t* __restrict__ totals) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= n_buckets) return;
+  uint32_t run = 0;
+  for (int64_t g = 0; g < n_groups; g++) {
+    uint32_t* cell = hist_matrix + g * n_buckets + b;
+    const uint32_t c = *cell;
+    *cell = run;
+    run += c;
+  }
+  totals[b] = run;
+}
+
+// Sorts keys[lo, hi) ascending and drops duplicates; uniq[b] = number kept.
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_bucket_sort(const int64_t* __restrict__ offsets,
+                                                      KeyT* __restrict__ keys,
+                                                      int64_t* __restrict__ uniq) {
+  extern __shared__ unsigned char lds_raw[];
+  __shared__ int lds_cnt[4];
+  KeyT* lds = reinterpret_cast<KeyT*>(lds_raw);
+  constexpr int kCap = kSortLdsBytes / int(sizeof(KeyT));
+  const int64_t b = blockIdx.x;
+  const int64_t lo = offsets[b], hi = offsets[b + 1];
+  const int64_t cnt64 = hi - lo;
+  if (cnt64 == 0) {
+    if (threadIdx.x == 0) uniq[b] = 0;
+    return;
+  }
+  KeyT* g = keys + lo;
+  const bool in_lds = cnt64 <= kCap;
+  int64_t padded = 1;
+  while (padded < cnt64) padded <<= 1;
+  KeyT* buf = in_lds ? lds : g;
+  if (in_lds) {
+    for (int64_t i = threadIdx.x; i < cnt64; i += 256) lds[i] = g[i];
+    __syncthreads();
+  }
+  // Bitonic network in its all-ascending form (each merge starts with a mirror step), so
+  // the slots in [cnt64, padded) can stay virtual: a real key never moves above them.
+  const int64_t half = padded >> 1;
+  for (int64_t size = 2; size <= padded; size <<= 1) {
+    const int64_t hs = size >> 1;
+    for (int64_t p = threadIdx.x; p < half; p += 256) {
+      const int64_t block = p / hs, o = p - block * hs;
+      const int64_t i = block * size + o, j = block * size + size - 1 - o;
+      if (j < cnt64) {
+        const KeyT x = buf[i], y = buf[j];
+        if (x > y) {
+          buf[i] = y;
+          buf[j] = x;
+        }
+      }
+    }
+    __syncthreads();
+    for (int64_t stride = size >> 2; stride > 0; stride >>= 1) {
+      for (int64_t p = threadIdx.x; p < half; p += 256) {
+        const int64_t i = 2 * stride * (p / stride) + (p % stride), j = i + stride;
+        if (j < cnt64) {
+          const KeyT x = buf[i], y = buf[j];
+          if (x > y) {
+            buf[i] = y;
+            buf[j] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+  // duplicates
+  int kept_before = 0;
+  int64_t total = 0;
+  if (in_lds) {
+    // each thread owns a contiguous chunk
+    const int64_t per = (cnt64 + 255) / 256;
+    const int64_t c0 = min(int64_t(threadIdx.x) * per, cnt64), c1 = min(c0 + per, cnt64);
+    int mine = 0;
+    for (int64_t i = c0; i < c1; i++) mine += (i == 0 || buf[i] != buf[i - 1]);
+    // block exclusive scan of `mine`
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      int o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) lds_cnt[wave] = inc;
+    __syncthreads();
+    for (int w = 0; w < wave; w++) kept_before += lds_cnt[w];
+    total = lds_cnt[0] + lds_cnt[1] + lds_cnt[2] + lds_cnt[3];
+    kept_before += inc - mine;
+    int64_t at = kept_before;
+    for (int64_t i = c0; i < c1; i++)
+      if (i == 0 || buf[i] != buf[i - 1]) g[at++] = buf[i];
+  } else {
+    // serial compaction by one thread (oversize buckets are rare and already slow)
+    if (threadIdx.x == 0) {
+      int64_t at = 0;
+      for (int64_t i = 0; i < cnt64; i++)
+        if (i == 0 || g[i] != g[i - 1]) g[at++] = g[i];
+      lds_cnt[0] = 0;
+      uniq[b] = at;
+    }
+    return;
+  }
+  if (threadIdx.x == 0) uniq[b] = total;
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_compact_buckets(const int64_t* __restrict__ old_off,
+                                                          const int64_t* __restrict__ new_off,
+                                                          const KeyT* __restrict__ src,
+                                                          KeyT* __restrict__ dst) {
+  const int64_t b = blockIdx.x;
+  const int64_t cnt = new_off[b + 1] - new_off[b];
+  const KeyT* s = src + old_off[b];
+  KeyT* d = dst + new_off[b];
+  for (int64_t i = threadIdx.x; i < cnt; i += 256) d[i] = s[i];
+}
+
+struct DecodeState {
+  uint32_t* hist;       // [groups][n_buckets]
+  unsigned long long* end_bits;
+  int64_t* str_start;   // [n_strings + 1]
+  int64_t* totals;      // [n_buckets + 1]
+};
+
+inline size_t a256(size_t x) { return (x + 255) & ~size_t(255); }
+
+int check_spss(const ksh_spss_view* s) {
+  if (!s) return fail(KSH_INVALID_ARGUMENT, "spss is NULL");
+  if (s->n_strings < 0 || s->n_bases < 0) return fail(KSH_INVALID_ARGUMENT, "negative spss size");
+  if (s->n_strings > 0 && (!s->d_words || !s->d_lens))
+    return fail(KSH_INVALID_ARGUMENT, "spss pointers are NULL");
+  return KSH_OK;
+}
+
+void decode_geometry(const ksh_spss_view* s, int64_t* n_words, int64_t* n_end_words, int64_t* groups,
+                     int64_t* words_per_group) {
+  *n_words = (s->n_bases + 31) / 32;
+  *n_end_words = (s->n_bases + 63) / 64 + 1;
+  int64_t g = std::min<int64_t>(512, (*n_words + 255) / 256);
+  if (g < 1) g = 1;
+  *groups = g;
+  *words_per_group = (*n_words + g - 1) / g;
+}
+
+void decode_carve(ksh_ctx* ctx, int64_t groups, int64_t nb, int64_t n_end_words, int64_t n_strings,
+                  DecodeState* st) {
+  char* at = ctx->slot[kSlotDecode];
+  st->hist = reinterpret_cast<uint32_t*>(at);
+  at += a256(size_t(groups) * nb * 4);
+  st->end_bits = reinterpret_cast<unsigned long long*>(at);
+  at += a256(size_t(n_end_words) * 8);
+  st->str_start = reinterpret_cast<int64_t*>(at);
+  at += a256(size_t(n_strings + 1) * 8);
+  st->totals = reinterpret_cast<int64_t*>(at);
+}
+
+template <typename KeyT>
+int decode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int canonical_flag,
+                  int64_t* d_offsets, int64_t* n_keys) {
+  const int64_t nb = n_buckets(g);
+  if (s->n_strings == 0 || s->n_bases == 0) {
+    KSH_HIP(hipMemsetAsync(d_offsets, 0, size_t(nb + 1) * 8, ctx->stream));
+    *n_keys = 0;
+    ctx->dec_kmers = 0;
+    ctx->dec_src = s->d_words;
+    return KSH_OK;
+  }
+  int64_t n_words, n_end_words, groups, wpg;
+  decode_geometry(s, &n_words, &n_end_words, &groups, &wpg);
+  const size_t bytes = a256(size_t(groups) * nb * 4) + a256(size_t(n_end_words) * 8) +
+                       a256(size_t(s->n_strings + 1) * 8) + a256(size_t(nb + 1) * 8);
+  KSH_TRY(slot_reserve(ctx, kSlotDecode, bytes));
+  KSH_TRY(arena_reserve(ctx, size_t(s->n_strings / 256 + 4096) * 8 + (1u << 16)));
+  arena_reset(ctx);
+  DecodeState st;
+  decode_carve(ctx, groups, nb, n_end_words, s->n_strings, &st);
+
+  const unsigned sb = unsigned((s->n_strings + 255) / 256);
+  hipLaunchKernelGGL(k_str_bases, dim3(sb), dim3(256), 0, ctx->stream, s->d_lens, s->n_strings, g->k,
+                     st.str_start);
+  KSH_TRY(scan_exclusive_i64(ctx, st.str_start, st.str_start, s->n_strings,
+                             st.str_start + s->n_strings));
+  KSH_HIP(hipMemsetAsync(st.end_bits, 0, size_t(n_end_words) * 8, ctx->stream));
+  hipLaunchKernelGGL(k_mark_ends, dim3(sb), dim3(256), 0, ctx->stream, st.str_start, s->n_strings,
+                     st.end_bits);
+  hipLaunchKernelGGL((k_decode<KeyT, false>), dim3(unsigned(groups)), dim3(kDecThreads),
+                     size_t(nb) * 4, ctx->stream, s->d_words, n_words, s->n_bases, st.end_bits,
+                     n_end_words, g->k, key_bits(g), int(nb), canonical_flag, wpg, st.hist, nullptr,
+                     static_cast<KeyT*>(nullptr));
+  hipLaunchKernelGGL(k_hist_columns, dim3(unsigned((nb + 255) / 256)), dim3(256), 0, ctx->stream,
+                     st.hist, groups, int(nb), st.totals);
+  KSH_TRY(scan_exclusive_i64(ctx, st.totals, d_offsets, nb, d_offsets + nb));
+  KSH_HIP(hipGetLastError());
+  // consistency: the strings must tile the base stream exactly
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, d_offsets + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned + 1, st.str_start + s->n_strings, 8, hipMemcpyDeviceToHost,
+                         ctx->stream));
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  if (ctx->h_pinned[1] != s->n_bases)
+    return fail(KSH_INVALID_ARGUMENT, "spss: sum of string lengths (%lld) != n_bases (%lld)",
+                (long long)ctx->h_pinned[1], (long long)s->n_bases);
+  *n_keys = ctx->h_pinned[0];
+  ctx->dec_kmers = *n_keys;
+  ctx->dec_words = n_words;
+  ctx->dec_groups = groups;
+  ctx->dec_src = s->d_words;
+  return KSH_OK;
+}
+
+template <typename KeyT>
+int decode_write_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int canonical_flag,
+                   int64_t* d_offsets, void* d_keys, int64_t* n_keys) {
+  const int64_t nb = n_buckets(g);
+  if (ctx->dec_src != s->d_words)
+    return fail(KSH_FAILED_PRECONDITION, "ksh_spss_decode_write without a matching decode_plan");
+  if (ctx->dec_kmers == 0) {
+    *n_keys = 0;
+    return KSH_OK;
+  }
+  int64_t n_words, n_end_words, groups, wpg;
+  decode_geometry(s, &n_words, &n_end_words, &groups, &wpg);
+  DecodeState st;
+  decode_carve(ctx, groups, nb, n_end_words, s->n_strings, &st);
+  KeyT* keys = static_cast<KeyT*>(d_keys);
+  hipLaunchKernelGGL((k_decode<KeyT, true>), dim3(unsigned(groups)), dim3(kDecThreads),
+                     size_t(nb) * 4, ctx->stream, s->d_words, n_words, s->n_bases, st.end_bits,
+                     n_end_words, g->k, key_bits(g), int(nb), canonical_flag, wpg, st.hist, d_offsets,
+                     keys);
+  // per-bucket sort + duplicate removal; uniq counts reuse st.totals
+  hipLaunchKernelGGL((k_bucket_sort<KeyT>), dim3(unsigned(nb)), dim3(256), kSortLdsBytes, ctx->stream,
+                     d_offsets, keys, st.totals);
+  KSH_HIP(hipGetLastError());
+  arena_reset(ctx);
+  KSH_TRY(arena_reserve(ctx, a256(size_t(nb + 1) * 8) + (1u << 16)));
+  int64_t* new_off = static_cast<int64_t*>(arena_alloc(ctx, size_t(nb + 1) * 8));
+  if (!new_off) return fail(KSH_INTERNAL, "scratch arena too small");
+  KSH_TRY(scan_exclusive_i64(ctx, st.totals, new_off, nb, new_off + nb));
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, new_off + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  const int64_t kept = ctx->h_pinned[0];
+  if (kept != ctx->dec_kmers) {
+    // repeated k-mers in the input: close the gaps (rare; through a temporary copy)
+    void* tmp = nullptr;
+    KSH_HIP(hipMalloc(&tmp, size_t(ctx->dec_kmers) * sizeof(KeyT)));
+    KSH_HIP(hipMemcpyAsync(tmp, keys, size_t(ctx->dec_kmers) * sizeof(KeyT), hipMemcpyDeviceToDevice,
+                           ctx->stream));
+    hipLaunchKernelGGL((k_compact_buckets<KeyT>), dim3(unsigned(nb)), dim3(256), 0, ctx->stream,
+                       d_offsets, new_off, static_cast<const KeyT*>(tmp), keys);
+    KSH_HIP(hipMemcpyAsync(d_offsets, new_off, size_t(nb + 1) * 8, hipMemcpyDeviceToDevice,
+                           ctx->stream));
+    KSH_HIP(hipStreamSynchronize(ctx->stream));
+    KSH_HIP(hipFree(tmp));
+  }
+  *n_keys = kept;
+  return KSH_OK;
+}
+
+}  // namespace ksh
+
+using namespace ksh;
+
+extern "C" {
+
+int ksh_spss_size(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int64_t* n_kmers) {
+  if (!ctx || !n_kmers) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  KSH_TRY(check_geom(g));
+  KSH_TRY(check_spss(s));
+  KSH_HIP(hipSetDevice(ctx->device));
+  if (s->n_strings == 0) {
+    *n_kmers = 0;
+    return KSH_OK;
+  }
+  arena_reset(ctx);
+  unsigned long long* d_acc = static_cast<unsigned long long*>(arena_alloc(ctx, 8));
+  KSH_HIP(hipMemsetAsync(d_acc, 0, 8, ctx->stream));
+  const unsigned blocks = unsigned(std::min<int64_t>((s->n_strings + 255) / 256, 1024));
+  hipLaunchKernelGGL(k_sum_lens, dim3(blocks), dim3(256), 0, ctx->stream, s->d_lens, s->n_strings,
+                     d_acc);
+  KSH_HIP(hipGetLastError());
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, d_acc, 8, hipMemcpyDeviceToHost, ctx->stream));
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  *n_kmers = ctx->h_pinned[0] + s->n_strings;  // sum(len - K) + n = sum(len - K + 1)
+  return KSH_OK;
+}
+
+int ksh_spss_decode_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int canonical_flag,
+                         int64_t* d_offsets, int64_t* n_keys) {
+  if (!ctx || !d_offsets || !n_keys) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  KSH_TRY(check_geom(g));
+  KSH_TRY(check_spss(s));
+  if (n_buckets(g) > kMaxLdsBuckets)
+    return fail(KSH_INVALID_ARGUMENT, "decode supports n_bucket_bits <= 14 (got %d)", g->n_bucket_bits);
+  KSH_HIP(hipSetDevice(ctx->device));
+  return g->key_bytes == 4 ? decode_plan_t<uint32_t>(ctx, g, s, canonical_flag, d_offsets, n_keys)
+                           : decode_plan_t<uint64_t>(ctx, g, s, canonical_flag, d_offsets, n_keys);
+}
+
+int ksh_spss_decode_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int canonical_flag,
+                          int64_t* d_offsets, void* d_keys, int64_t* n_keys) {
+  if (!ctx || !d_offsets || !n_keys) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  KSH_TRY(check_geom(g));
+  KSH_TRY(check_spss(s));
+  if (ctx->dec_kmers > 0 && !d_keys) return fail(KSH_INVALID_ARGUMENT, "d_keys is NULL");
+  KSH_HIP(hipSetDevice(ctx->device));
+  return g->key_bytes == 4
+             ? decode_write_t<uint32_t>(ctx, g, s, canonical_flag, d_offsets, d_keys, n_keys)
+             : decode_write_t<uint64_t>(ctx, g, s, canonical_flag, d_offsets, d_keys, n_keys);
+}
+
+}  // extern "C"

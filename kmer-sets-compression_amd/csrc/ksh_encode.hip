@@ -1,0 +1,832 @@
+// SPSS encode on device: bucketed sorted key set -> unitigs -> path cover -> packed strings.
+//
+// Replaces KmerSetCompact::FromKmerSet = GetSPSSCanonical(kmer_set, fast = true) +
+// the 2-bit packing constructor (lib/core/kmer_set_compact.h:36-47,206-266;
+// lib/core/spss.h:230-615, :619-695, :1039-1206, :1358-1858), with the
+// reference's n_workers == 1 results and the oracle's ordering rules:
+// the output strings are equal to the oracle's, string for string and in order.
+// tests/model_encode.py is the array-level model of exactly this file.
+//
+// Vocabulary.  A k-mer is its index t in the set's ascending order.  A *state*
+// s = 2t + d walks k-mer t forward (d = 0: enters through its left side, leaves
+// through its right side, spelled as is) or reversed (d = 1).  side index: 0 = left,
+// 1 = right, so state s enters through side (s & 1) and leaves through side (s & 1) ^ 1,
+// i.e. through link[s ^ 1].  A side has a link when it has exactly one neighbour
+// whose facing side also has exactly one (spss.h:276-313).
+//
+//   k_adjacency   8 membership probes per k-mer (4 Next, 4 Prev, forward or reverse
+//                 complement) -> per side: none / the single neighbour / many
+//   k_links       mutual singles
+//   k_walk        one thread per chain start follows links, stamping (start, position)
+//   k_choose      per k-mer: the chain that starts at the larger end (spss.h:511,555)
+//   k_loops       non-branching loops, spelled from their smallest k-mer (spss.h:585-610)
+//   k_head_counts / scans / k_unitig_fill   unitig ids in the reference's push order
+//   k_edges       <= 4 edges per unitig side, in the reference's enumeration order
+//   k_match_*     lexicographically-first maximal matching by rounds of mutual minima
+//                 == the sequential greedy sweep of spss.h:1445-1499
+//   k_cover_mark / k_loop_cut    loops of the path cover, cut where the reference's
+//                 union-by-rank root says (spss.h:1541-1647)
+//   k_string_*    stitch order and orientation (spss.h:1649-1829)
+//   k_emit / k_pack   bases -> 2-bit words, len - K per string
+//
+// All of it is integer gather/scatter work bounded by HBM random-access rate; no MFMA.
+#include "ksh_internal.h"
+#include "ksh_kmer.h"
+
+#include <algorithm>
+
+namespace ksh {
+
+constexpr uint32_t kNone = 0xFFFFFFFFu;
+constexpr uint32_t kMulti = 0xFFFFFFFEu;
+constexpr uint64_t kUnset = ~uint64_t(0);
+
+// ---------------------------------------------------------------------------------- E1
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_adjacency(DevSet<KeyT> set, uint32_t* __restrict__ nbr) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= set.n) return;
+  const int k = set.k;
+  const uint64_t x = set.kmer(t);
+#pragma unroll
+  for (int side = 0; side < 2; side++) {
+    int cnt = 0;
+    uint32_t single = kNone;
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const uint64_t y = side ? kmer_next(x, k, c) : kmer_prev(x, k, c);
+      const uint64_t r = revcomp(y, k);
+      const uint64_t z = y < r ? y : r;
+      if (z == x) continue;  // kmer != next / next_complement (spss.h:242,248)
+      const int64_t idx = set.find(z);
+      if (idx < 0) continue;
+      cnt++;
+      single = (uint32_t(idx) << 1) | uint32_t(z != y);
+    }
+    nbr[2 * t + side] = cnt == 0 ? kNone : (cnt == 1 ? single : kMulti);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_links(const uint32_t* __restrict__ nbr, int64_t n_states,
+                                                uint32_t* __restrict__ link) {
+  const int64_t s = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (s >= n_states) return;
+  const uint32_t v = nbr[s];
+  uint32_t out = kNone;
+  if (v < kMulti) {
+    const uint32_t y = v >> 1, same = v & 1, side = uint32_t(s & 1);
+    const uint32_t facing = same ? side : side ^ 1;
+    if (nbr[2 * int64_t(y) + facing] < kMulti) out = v;
+  }
+  link[s] = out;
+}
+
+// ---------------------------------------------------------------------------------- E2
+__global__ __launch_bounds__(256) void k_walk(const uint32_t* __restrict__ link, int64_t n_states,
+                                               unsigned long long* __restrict__ info) {
+  const int64_t s0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (s0 >= n_states) return;
+  if (link[s0] != kNone) return;  // has a predecessor: not a chain start
+  uint32_t s = uint32_t(s0);
+  uint32_t p = 0;
+  while (true) {
+    info[s] = (uint64_t(s0) << 32) | p;
+    const uint32_t lk = link[s ^ 1];
+    if (lk == kNone || p >= n_states) break;
+    s = ((lk >> 1) << 1) | ((s & 1) ^ (lk & 1));
+    p++;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_choose(const unsigned long long* __restrict__ info,
+                                                 int64_t n, uint32_t* __restrict__ head,
+                                                 uint32_t* __restrict__ pos,
+                                                 uint8_t* __restrict__ ori,
+                                                 uint8_t* __restrict__ hcls,
+                                                 uint32_t* __restrict__ hlen,
+                                                 uint32_t* __restrict__ hlast) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const uint64_t i0 = info[2 * t], i1 = info[2 * t + 1];
+  hcls[t] = 0xFF;
+  if (i0 == kUnset) {  // on a loop: k_loops fills it in
+    head[t] = kNone;
+    return;
+  }
+  const uint32_t st0 = uint32_t(i0 >> 32) >> 1, st1 = uint32_t(i1 >> 32) >> 1;
+  const uint32_t d = st0 >= st1 ? 0u : 1u;
+  const uint64_t sel = d ? i1 : i0, oth = d ? i0 : i1;
+  head[t] = uint32_t(sel >> 32) >> 1;
+  pos[t] = uint32_t(sel);
+  ori[t] = uint8_t(d);
+  if (uint32_t(sel) == 0) {
+    hcls[t] = st0 == st1 ? 0 : ((uint32_t(sel >> 32) & 1) == 0 ? 1 : 2);
+    hlen[t] = uint32_t(oth) + 1;
+    hlast[t] = uint32_t(oth >> 32) ^ 1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_loops(const uint32_t* __restrict__ link,
+                                                const unsigned long long* __restrict__ info,
+                                                int64_t n, uint32_t* __restrict__ head,
+                                                uint32_t* __restrict__ pos,
+                                                uint8_t* __restrict__ ori,
+                                                uint8_t* __restrict__ hcls,
+                                                uint32_t* __restrict__ hlen,
+                                                uint32_t* __restrict__ hlast) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  if (info[2 * t] != kUnset) return;
+  const uint32_t start = uint32_t(2 * t);
+  uint32_t s = start;
+  int64_t steps = 0;
+  do {
+    const uint32_t lk = link[s ^ 1];
+    if (lk == kNone) return;  // cannot happen on a loop; leave the k-mer unassigned
+    s = ((lk >> 1) << 1) | ((s & 1) ^ (lk & 1));
+    if ((s >> 1) < uint32_t(t)) return;  // a smaller k-mer owns this loop
+    steps++;
+  } while (s != start && steps <= 2 * n);
+  if (s != start) return;
+  uint32_t p = 0, last = start;
+  s = start;
+  do {
+    const uint32_t y = s >> 1;
+    head[y] = uint32_t(t);
+    pos[y] = p;
+    ori[y] = uint8_t(s & 1);
+    last = s;
+    const uint32_t lk = link[s ^ 1];
+    s = ((lk >> 1) << 1) | ((s & 1) ^ (lk & 1));
+    p++;
+  } while (s != start);
+  hcls[t] = 3;
+  hlen[t] = p;
+  hlast[t] = last;
+}
+
+// ---------------------------------------------------------------------------------- E3
+__global__ __launch_bounds__(256) void k_head_counts(const uint8_t* __restrict__ hcls, int64_t n,
+                                                      int64_t* __restrict__ c01,
+                                                      int64_t* __restrict__ c23) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const uint8_t c = hcls[t];
+  c01[t] = int64_t(c == 0) | (int64_t(c == 1) << 32);
+  c23[t] = int64_t(c == 2) | (int64_t(c == 3) << 32);
+}
+
+__global__ __launch_bounds__(256) void k_unitig_fill(
+    const uint8_t* __restrict__ hcls, const int64_t* __restrict__ c01,
+    const int64_t* __restrict__ c23, int64_t n, int64_t base1, int64_t base2, int64_t base3,
+    const uint8_t* __restrict__ ori, const uint32_t* __restrict__ hlen,
+    const uint32_t* __restrict__ hlast, uint32_t* __restrict__ uid, uint32_t* __restrict__ u_head,
+    uint32_t* __restrict__ u_first, uint32_t* __restrict__ u_last, uint32_t* __restrict__ u_len) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const uint8_t c = hcls[t];
+  if (c == 0xFF) return;
+  int64_t u;
+  if (c == 0) u = c01[t] & 0xFFFFFFFF;
+  else if (c == 1) u = base1 + (c01[t] >> 32);
+  else if (c == 2) u = base2 + (c23[t] & 0xFFFFFFFF);
+  else u = base3 + (c23[t] >> 32);
+  uid[t] = uint32_t(u);
+  u_head[u] = uint32_t(t);
+  u_first[u] = uint32_t(2 * t) | ori[t];
+  u_last[u] = hlast[t];
+  u_len[u] = hlen[t];
+}
+
+// ---------------------------------------------------------------------------------- E4
+// vertex v = 2u + side (0 = left end, 1 = right end); edges[4v + c] = other vertex or kNone.
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_edges(DevSet<KeyT> set, int64_t n_vertices,
+                                                const uint32_t* __restrict__ u_first,
+                                                const uint32_t* __restrict__ u_last,
+                                                const uint32_t* __restrict__ head,
+                                                const uint32_t* __restrict__ uid,
+                                                uint32_t* __restrict__ edges) {
+  const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (v >= n_vertices) return;
+  const uint32_t u = uint32_t(v >> 1), side = uint32_t(v & 1);
+  const uint32_t st = side ? u_last[u] : u_first[u];
+  const int k = set.k;
+  const uint64_t x = set.kmer(st >> 1);
+  const uint64_t o = (st & 1) ? revcomp(x, k) : x;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const uint64_t y = side ? kmer_next(o, k, c) : kmer_prev(o, k, c);
+    const uint64_t r = revcomp(y, k);
+    const uint64_t z = y < r ? y : r;
+    uint32_t out = kNone;
+    const int64_t i = set.find(z);
+    if (i >= 0) {
+      const uint32_t u2 = uid[head[i]];
+      if (u2 != u) {
+        // side of k-mer z this edge touches
+        const uint32_t f = side ? (y == z ? 0u : 1u) : (y == z ? 1u : 0u);
+        const uint32_t fs = u_first[u2];
+        const uint32_t side2 = ((fs >> 1) == uint32_t(i) && (fs & 1) == f) ? 0u : 1u;
+        out = 2 * u2 + side2;
+      }
+    }
+    edges[4 * v + c] = out;
+  }
+}
+
+// ---------------------------------------------------------------------------------- E5
+__device__ __forceinline__ uint64_t slot_priority(uint32_t v, int c) {
+  return uint64_t(v >> 1) * 8 + ((v & 1) ? 0 : 4) + uint64_t(c);
+}
+
+__global__ __launch_bounds__(256) void k_match_best(const uint32_t* __restrict__ edges,
+                                                     const uint32_t* __restrict__ mate,
+                                                     int64_t n_vertices,
+                                                     unsigned long long* __restrict__ best_prio,
+                                                     uint32_t* __restrict__ best_w,
+                                                     int* __restrict__ any_live) {
+  const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (v >= n_vertices) return;
+  uint32_t bw = kNone;
+  uint64_t bp = ~uint64_t(0);
+  if (mate[v] == kNone) {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const uint32_t w = edges[4 * v + c];
+      if (w == kNone || mate[w] != kNone) continue;
+      uint64_t pr = slot_priority(uint32_t(v), c);
+#pragma unroll
+      for (int c2 = 0; c2 < 4; c2++) {
+        if (edges[4 * int64_t(w) + c2] == uint32_t(v)) {
+          const uint64_t p2 = slot_priority(w, c2);
+          pr = p2 < pr ? p2 : pr;
+        }
+      }
+      if (pr < bp) {
+        bp = pr;
+        bw = w;
+      }
+    }
+  }
+  best_prio[v] = bp;
+  best_w[v] = bw;
+  if (bw != kNone) *any_live = 1;
+}
+
+__global__ __launch_bounds__(256) void k_match_commit(const unsigned long long* __restrict__ best_prio,
+                                                       const uint32_t* __restrict__ best_w,
+                                                       int64_t n_vertices,
+                                                       uint32_t* __restrict__ mate) {
+  const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (v >= n_vertices) return;
+  const uint32_t w = best_w[v];
+  if (w == kNone) return;
+  if (best_w[w] == uint32_t(v) && best_prio[w] == best_prio[v]) mate[v] = w;
+}
+
+// ---------------------------------------------------------------------------------- E6
+__global__ __launch_bounds__(256) void k_cover_mark(const uint32_t* __restrict__ mate, int64_t n_u,
+                                                     uint8_t* __restrict__ visited) {
+  const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (u >= n_u) return;
+  const bool hl = mate[2 * u] != kNone, hr = mate[2 * u + 1] != kNone;
+  if (hl && hr) return;
+  uint32_t cur = uint32_t(u);
+  bool going_right = !hl;
+  int64_t steps = 0;
+  while (true) {
+    visited[cur] = 1;
+    const uint32_t w = mate[2 * int64_t(cur) + (going_right ? 1 : 0)];
+    if (w == kNone || steps++ > n_u) break;
+    cur = w >> 1;
+    going_right = (w & 1) == 0;
+  }
+}
+
+// One thread per loop of the path cover (the loop's smallest unitig).  Replays the
+// reference's sequential union-by-rank over the loop's nodes in ascending order
+// (spss.h:1551-1566, parallel_disjoint_set.h:53-78) to find the root, then drops the
+// root's left edge and its mate entry (spss.h:1626-1643).
+__global__ __launch_bounds__(64) void k_loop_cut(uint32_t* __restrict__ mate, int64_t n_u,
+                                                  const uint8_t* __restrict__ visited,
+                                                  uint32_t* __restrict__ scratch_nodes,
+                                                  uint32_t* __restrict__ scratch_parent,
+                                                  uint32_t* __restrict__ scratch_rank,
+                                                  unsigned long long* __restrict__ scratch_used) {
+  const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (u >= n_u) return;
+  if (visited[u]) return;
+  // first lap: am I the smallest node, and how long is the loop?
+  uint32_t cur = uint32_t(u);
+  bool going_right = true;
+  int64_t len = 0;
+  do {
+    const uint32_t w = mate[2 * int64_t(cur) + (going_right ? 1 : 0)];
+    if (w == kNone) return;
+    cur = w >> 1;
+    going_right = (w & 1) == 0;
+    if (cur < uint32_t(u)) return;
+    len++;
+  } while (cur != uint32_t(u) && len <= n_u);
+  if (cur != uint32_t(u)) return;
+  const uint64_t base = atomicAdd(scratch_used, (unsigned long long)len);
+  uint32_t* nodes = scratch_nodes + base;
+  uint32_t* parent = scratch_parent + base;
+  uint32_t* rank = scratch_rank + base;
+  // second lap: collect
+  cur = uint32_t(u);
+  going_right = true;
+  for (int64_t i = 0; i < len; i++) {
+    nodes[i] = cur;
+    const uint32_t w = mate[2 * int64_t(cur) + (going_right ? 1 : 0)];
+    cur = w >> 1;
+    going_right = (w & 1) == 0;
+  }
+  // heap sort ascending
+  for (int64_t start = len / 2 - 1; start >= 0; start--) {
+    int64_t root = start;
+    while (true) {
+      int64_t child = 2 * root + 1;
+      if (child >= len) break;
+      if (child + 1 < len && nodes[child] < nodes[child + 1]) child++;
+      if (nodes[root] >= nodes[child]) break;
+      const uint32_t tmp = nodes[root];
+      nodes[root] = nodes[child];
+      nodes[child] = tmp;
+      root = child;
+    }
+  }
+  for (int64_t end = len - 1; end > 0; end--) {
+    const uint32_t tmp = nodes[0];
+    nodes[0] = nodes[end];
+    nodes[end] = tmp;
+    int64_t root = 0;
+    while (true) {
+      int64_t child = 2 * root + 1;
+      if (child >= end) break;
+      if (child + 1 < end && nodes[child] < nodes[child + 1]) child++;
+      if (nodes[root] >= nodes[child]) break;
+      const uint32_t t2 = nodes[root];
+      nodes[root] = nodes[child];
+      nodes[child] = t2;
+      root = child;
+    }
+  }
+  for (int64_t i = 0; i < len; i++) {
+    parent[i] = uint32_t(i);
+    rank[i] = 0;
+  }
+  auto index_of = [&](uint32_t node) {
+    int64_t lo = 0, hi = len;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (nodes[mid] < node) lo = mid + 1; else hi = mid;
+    }
+    return uint32_t(lo);
+  };
+  auto find = [&](uint32_t a) {
+    while (parent[a] != a) a = parent[a];
+    return a;
+  };
+  auto unite = [&](uint32_t a, uint32_t b) {
+    a = find(a);
+    b = find(b);
+    if (a == b) return;
+    // lower rank, then lower node index, becomes the child; indices are in node order
+    if (rank[a] > rank[b] || (rank[a] == rank[b] && a > b)) {
+      const uint32_t tmp = a;
+      a = b;
+      b = tmp;
+    }
+    parent[a] = b;
+    if (rank[a] == rank[b]) rank[b]++;
+  };
+  for (int64_t i = 0; i < len; i++) {
+    const uint32_t a = nodes[i];
+    unite(uint32_t(i), index_of(mate[2 * int64_t(a)] >> 1));      // edge_left first
+    unite(uint32_t(i), index_of(mate[2 * int64_t(a) + 1] >> 1));
+  }
+  const uint32_t root_node = nodes[find(0)];
+  const uint32_t w = mate[2 * int64_t(root_node)];
+  mate[2 * int64_t(root_node)] = kNone;
+  mate[w] = kNone;
+}
+
+// ---------------------------------------------------------------------------------- E7
+// scls[u]: 0 = kept walk from a left terminal, 1 = kept walk from a right terminal,
+//          2 = isolated unitig, 0xFF = not the start of an output string.
+__global__ __launch_bounds__(256) void k_string_starts(const uint32_t* __restrict__ mate,
+                                                        const uint32_t* __restrict__ u_len,
+                                                        int64_t n_u, uint8_t* __restrict__ scls,
+                                                        int64_t* __restrict__ s_nk) {
+  const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (u >= n_u) return;
+  const bool hl = mate[2 * u] != kNone, hr = mate[2 * u + 1] != kNone;
+  uint8_t cls = 0xFF;
+  int64_t nk = 0;
+  if (!hl && !hr) {
+    cls = 2;
+    nk = u_len[u];
+  } else if (!hl || !hr) {
+    uint32_t cur = uint32_t(u);
+    bool going_right = !hl;
+    int64_t steps = 0;
+    while (true) {
+      nk += u_len[cur];
+      const uint32_t w = mate[2 * int64_t(cur) + (going_right ? 1 : 0)];
+      if (w == kNone || steps++ > n_u) break;
+      cur = w >> 1;
+      going_right = (w & 1) == 0;
+    }
+    if (uint32_t(u) <= cur) cls = hl ? 1 : 0;  // path.front().first > path.back().first -> skipped
+  }
+  scls[u] = cls;
+  s_nk[u] = nk;
+}
+
+__global__ __launch_bounds__(256) void k_string_counts(const uint8_t* __restrict__ scls, int64_t n_u,
+                                                        int64_t* __restrict__ c01,
+                                                        int64_t* __restrict__ c2) {
+  const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (u >= n_u) return;
+  const uint8_t c = scls[u];
+  c01[u] = int64_t(c == 0) | (int64_t(c == 1) << 32);
+  c2[u] = int64_t(c == 2);
+}
+
+__global__ __launch_bounds__(256) void k_string_assign(
+    const uint32_t* __restrict__ mate, const uint32_t* __restrict__ u_len, int64_t n_u,
+    const uint8_t* __restrict__ scls, const int64_t* __restrict__ c01,
+    const int64_t* __restrict__ c2, const int64_t* __restrict__ s_nk, int64_t base1, int64_t base2,
+    int k, uint32_t* __restrict__ u_sid, uint32_t* __restrict__ u_koff,
+    uint8_t* __restrict__ u_flip, uint32_t* __restrict__ lens, int64_t* __restrict__ str_bases) {
+  const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (u >= n_u) return;
+  const uint8_t c = scls[u];
+  if (c == 0xFF) return;
+  int64_t sid;
+  if (c == 0) sid = c01[u] & 0xFFFFFFFF;
+  else if (c == 1) sid = base1 + (c01[u] >> 32);
+  else sid = base2 + c2[u];
+  lens[sid] = uint32_t(s_nk[u] - 1);
+  str_bases[sid] = s_nk[u] + k - 1;
+  uint32_t cur = uint32_t(u);
+  bool going_right = c != 1;
+  uint32_t koff = 0;
+  int64_t steps = 0;
+  while (true) {
+    u_sid[cur] = uint32_t(sid);
+    u_koff[cur] = koff;
+    u_flip[cur] = going_right ? 0 : 1;
+    koff += u_len[cur];
+    if (c == 2) break;
+    const uint32_t w = mate[2 * int64_t(cur) + (going_right ? 1 : 0)];
+    if (w == kNone || steps++ > n_u) break;
+    cur = w >> 1;
+    going_right = (w & 1) == 0;
+  }
+}
+
+// GetUnitigsCanonical output: every unitig is its own string.
+__global__ __launch_bounds__(256) void k_unitig_strings(const uint32_t* __restrict__ u_len,
+                                                         int64_t n_u, int k,
+                                                         uint32_t* __restrict__ u_sid,
+                                                         uint32_t* __restrict__ u_koff,
+                                                         uint8_t* __restrict__ u_flip,
+                                                         uint32_t* __restrict__ lens,
+                                                         int64_t* __restrict__ str_bases) {
+  const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (u >= n_u) return;
+  u_sid[u] = uint32_t(u);
+  u_koff[u] = 0;
+  u_flip[u] = 0;
+  lens[u] = u_len[u] - 1;
+  str_bases[u] = int64_t(u_len[u]) + k - 1;
+}
+
+// ---------------------------------------------------------------------------------- E8
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_emit(
+    DevSet<KeyT> set, const uint32_t* __restrict__ head, const uint32_t* __restrict__ pos,
+    const uint8_t* __restrict__ ori, const uint32_t* __restrict__ uid,
+    const uint32_t* __restrict__ u_len, const uint32_t* __restrict__ u_sid,
+    const uint32_t* __restrict__ u_koff, const uint8_t* __restrict__ u_flip,
+    const int64_t* __restrict__ str_start, const uint32_t* __restrict__ lens,
+    uint8_t* __restrict__ bytes) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= set.n) return;
+  const uint32_t h = head[t];
+  if (h == kNone) return;
+  const uint32_t u = uid[h];
+  const uint32_t sid = u_sid[u];
+  const uint32_t flip = u_flip[u];
+  const uint32_t q = u_koff[u] + (flip ? (u_len[u] - 1 - pos[t]) : pos[t]);
+  const int k = set.k;
+  const uint64_t x = set.kmer(t);
+  const uint64_t o = (uint32_t(ori[t]) ^ flip) ? revcomp(x, k) : x;
+  const int64_t at = str_start[sid] + q;
+  bytes[at] = uint8_t((o >> (2 * (k - 1))) & 3);
+  if (q == lens[sid]) {  // last k-mer of the string: its remaining K - 1 bases
+    for (int i = 1; i < k; i++) bytes[at + i] = uint8_t((o >> (2 * (k - 1 - i))) & 3);
+  }
+}
+
+__global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ bytes, int64_t n_bases,
+                                               int64_t n_words, uint64_t* __restrict__ words) {
+  const int64_t w = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (w >= n_words) return;
+  const int64_t p0 = w * 32;
+  uint64_t out = 0;
+  if (p0 + 32 <= n_bases) {
+    const uint4 lo = *reinterpret_cast<const uint4*>(bytes + p0);
+    const uint4 hi = *reinterpret_cast<const uint4*>(bytes + p0 + 16);
+    const uint32_t q[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const uint64_t code = (q[i] >> (8 * b)) & 3;
+        out |= code << (62 - 2 * (4 * i + b));
+      }
+    }
+  } else {
+    for (int j = 0; j < 32 && p0 + j < n_bases; j++) out |= uint64_t(bytes[p0 + j] & 3) << (62 - 2 * j);
+  }
+  words[w] = out;
+}
+
+// ---------------------------------------------------------------------------------- host
+struct EncPlan {
+  int64_t n = 0, n_u = 0, n_strings = 0, n_bases = 0;
+  int mode = 0;
+  ksh_geom g{};
+  ksh_set_view set{};
+  // k-mer level (slot kSlotEncode)
+  uint32_t *nbr = nullptr, *link = nullptr, *head = nullptr, *pos = nullptr, *hlen = nullptr,
+           *hlast = nullptr, *uid = nullptr;
+  unsigned long long* info = nullptr;
+  uint8_t *ori = nullptr, *hcls = nullptr;
+  int64_t *c01 = nullptr, *c23 = nullptr;
+  // unitig level (own allocation)
+  char* ublock = nullptr;
+  uint32_t *u_head = nullptr, *u_first = nullptr, *u_last = nullptr, *u_len = nullptr,
+           *edges = nullptr, *mate = nullptr, *best_w = nullptr, *u_sid = nullptr,
+           *u_koff = nullptr, *lens = nullptr, *sc_nodes = nullptr, *sc_parent = nullptr,
+           *sc_rank = nullptr;
+  unsigned long long *best_prio = nullptr, *sc_used = nullptr;
+  uint8_t *visited = nullptr, *scls = nullptr, *u_flip = nullptr;
+  int64_t *s_nk = nullptr, *sc01 = nullptr, *sc2 = nullptr, *str_start = nullptr;
+  int* any_live = nullptr;
+  int rounds = 0;
+};
+
+inline size_t al(size_t x) { return (x + 255) & ~size_t(255); }
+inline unsigned nblk(int64_t n) { return unsigned(std::max<int64_t>(1, (n + 255) / 256)); }
+
+template <typename T>
+T* carve(char*& at, size_t count) {
+  T* p = reinterpret_cast<T*>(at);
+  at += al(count * sizeof(T));
+  return p;
+}
+
+void free_plan(ksh_ctx* ctx) {
+  EncPlan* p = static_cast<EncPlan*>(ctx->enc_state);
+  if (!p) return;
+  if (p->ublock) (void)hipFree(p->ublock);
+  delete p;
+  ctx->enc_state = nullptr;
+}
+
+template <typename KeyT>
+int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, int mode,
+                  int64_t* n_strings, int64_t* n_bases) {
+  free_plan(ctx);
+  EncPlan* p = new EncPlan;
+  ctx->enc_state = p;
+  p->g = *g;
+  p->set = *sv;
+  p->mode = mode;
+  const int64_t n = sv->n_keys;
+  p->n = n;
+  if (n == 0) {
+    *n_strings = 0;
+    *n_bases = 0;
+    return KSH_OK;
+  }
+  if (n >= int64_t(0x7FFFFFF0)) return fail(KSH_INVALID_ARGUMENT, "set too large for 32-bit indices");
+  const int64_t nb = n_buckets(g);
+  const size_t bytes = 2 * al(size_t(2 * n) * 4) + al(size_t(2 * n) * 8) + 5 * al(size_t(n) * 4) +
+                       2 * al(size_t(n)) + 2 * al(size_t(n) * 8) + 4096;
+  KSH_TRY(slot_reserve(ctx, kSlotEncode, bytes));
+  KSH_TRY(arena_reserve(ctx, size_t(n / 256 + 4096) * 8 * 2 + (1u << 16)));
+  arena_reset(ctx);
+  char* at = ctx->slot[kSlotEncode];
+  p->nbr = carve<uint32_t>(at, size_t(2 * n));
+  p->link = carve<uint32_t>(at, size_t(2 * n));
+  p->info = carve<unsigned long long>(at, size_t(2 * n));
+  p->head = carve<uint32_t>(at, size_t(n));
+  p->pos = carve<uint32_t>(at, size_t(n));
+  p->hlen = carve<uint32_t>(at, size_t(n));
+  p->hlast = carve<uint32_t>(at, size_t(n));
+  p->uid = carve<uint32_t>(at, size_t(n));
+  p->ori = carve<uint8_t>(at, size_t(n));
+  p->hcls = carve<uint8_t>(at, size_t(n));
+  p->c01 = carve<int64_t>(at, size_t(n));
+  p->c23 = carve<int64_t>(at, size_t(n));
+
+  DevSet<KeyT> set{sv->d_offsets, static_cast<const KeyT*>(sv->d_keys), nb, n, g->k, key_bits(g)};
+  hipStream_t st = ctx->stream;
+  hipLaunchKernelGGL((k_adjacency<KeyT>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr);
+  hipLaunchKernelGGL(k_links, dim3(nblk(2 * n)), dim3(256), 0, st, p->nbr, 2 * n, p->link);
+  KSH_HIP(hipMemsetAsync(p->info, 0xFF, size_t(2 * n) * 8, st));
+  hipLaunchKernelGGL(k_walk, dim3(nblk(2 * n)), dim3(256), 0, st, p->link, 2 * n, p->info);
+  hipLaunchKernelGGL(k_choose, dim3(nblk(n)), dim3(256), 0, st, p->info, n, p->head, p->pos, p->ori,
+                     p->hcls, p->hlen, p->hlast);
+  hipLaunchKernelGGL(k_loops, dim3(nblk(n)), dim3(256), 0, st, p->link, p->info, n, p->head, p->pos,
+                     p->ori, p->hcls, p->hlen, p->hlast);
+  hipLaunchKernelGGL(k_head_counts, dim3(nblk(n)), dim3(256), 0, st, p->hcls, n, p->c01, p->c23);
+  int64_t* d_tot = static_cast<int64_t*>(arena_alloc(ctx, 16));
+  if (!d_tot) return fail(KSH_INTERNAL, "scratch arena too small");
+  KSH_TRY(scan_exclusive_i64(ctx, p->c01, p->c01, n, d_tot));
+  KSH_TRY(scan_exclusive_i64(ctx, p->c23, p->c23, n, d_tot + 1));
+  KSH_HIP(hipGetLastError());
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, d_tot, 16, hipMemcpyDeviceToHost, st));
+  KSH_HIP(hipStreamSynchronize(st));
+  const int64_t n0 = ctx->h_pinned[0] & 0xFFFFFFFF, n1 = ctx->h_pinned[0] >> 32;
+  const int64_t n2 = ctx->h_pinned[1] & 0xFFFFFFFF, n3 = ctx->h_pinned[1] >> 32;
+  const int64_t n_u = n0 + n1 + n2 + n3;
+  p->n_u = n_u;
+
+  // unitig-level block
+  const size_t ub = 10 * al(size_t(n_u) * 4) + al(size_t(8 * n_u) * 4) + 2 * al(size_t(2 * n_u) * 4) +
+                    al(size_t(2 * n_u) * 8) + 3 * al(size_t(n_u)) + 4 * al(size_t(n_u + 1) * 8) +
+                    3 * al(size_t(n_u) * 4) + 4096;
+  KSH_HIP(hipMalloc(reinterpret_cast<void**>(&p->ublock), ub));
+  at = p->ublock;
+  p->u_head = carve<uint32_t>(at, size_t(n_u));
+  p->u_first = carve<uint32_t>(at, size_t(n_u));
+  p->u_last = carve<uint32_t>(at, size_t(n_u));
+  p->u_len = carve<uint32_t>(at, size_t(n_u));
+  p->u_sid = carve<uint32_t>(at, size_t(n_u));
+  p->u_koff = carve<uint32_t>(at, size_t(n_u));
+  p->lens = carve<uint32_t>(at, size_t(n_u));
+  p->sc_nodes = carve<uint32_t>(at, size_t(n_u));
+  p->sc_parent = carve<uint32_t>(at, size_t(n_u));
+  p->sc_rank = carve<uint32_t>(at, size_t(n_u));
+  p->edges = carve<uint32_t>(at, size_t(8 * n_u));
+  p->mate = carve<uint32_t>(at, size_t(2 * n_u));
+  p->best_w = carve<uint32_t>(at, size_t(2 * n_u));
+  p->best_prio = carve<unsigned long long>(at, size_t(2 * n_u));
+  p->visited = carve<uint8_t>(at, size_t(n_u));
+  p->scls = carve<uint8_t>(at, size_t(n_u));
+  p->u_flip = carve<uint8_t>(at, size_t(n_u));
+  p->s_nk = carve<int64_t>(at, size_t(n_u + 1));
+  p->sc01 = carve<int64_t>(at, size_t(n_u + 1));
+  p->sc2 = carve<int64_t>(at, size_t(n_u + 1));
+  p->str_start = carve<int64_t>(at, size_t(n_u + 1));
+  p->sc_used = carve<unsigned long long>(at, 1);
+  p->any_live = carve<int>(at, 1);
+
+  hipLaunchKernelGGL(k_unitig_fill, dim3(nblk(n)), dim3(256), 0, st, p->hcls, p->c01, p->c23, n, n0,
+                     n0 + n1, n0 + n1 + n2, p->ori, p->hlen, p->hlast, p->uid, p->u_head, p->u_first,
+                     p->u_last, p->u_len);
+
+  int64_t ns = n_u;
+  if (mode == 1) {
+    hipLaunchKernelGGL(k_unitig_strings, dim3(nblk(n_u)), dim3(256), 0, st, p->u_len, n_u, g->k,
+                       p->u_sid, p->u_koff, p->u_flip, p->lens, p->str_start);
+  } else {
+    hipLaunchKernelGGL((k_edges<KeyT>), dim3(nblk(2 * n_u)), dim3(256), 0, st, set, 2 * n_u,
+                       p->u_first, p->u_last, p->head, p->uid, p->edges);
+    KSH_HIP(hipMemsetAsync(p->mate, 0xFF, size_t(2 * n_u) * 4, st));
+    p->rounds = 0;
+    while (true) {
+      KSH_HIP(hipMemsetAsync(p->any_live, 0, sizeof(int), st));
+      hipLaunchKernelGGL(k_match_best, dim3(nblk(2 * n_u)), dim3(256), 0, st, p->edges, p->mate,
+                         2 * n_u, p->best_prio, p->best_w, p->any_live);
+      hipLaunchKernelGGL(k_match_commit, dim3(nblk(2 * n_u)), dim3(256), 0, st, p->best_prio,
+                         p->best_w, 2 * n_u, p->mate);
+      KSH_HIP(hipMemcpyAsync(ctx->h_pinned, p->any_live, sizeof(int), hipMemcpyDeviceToHost, st));
+      KSH_HIP(hipStreamSynchronize(st));
+      p->rounds++;
+      if (*reinterpret_cast<int*>(ctx->h_pinned) == 0) break;
+      if (p->rounds > 100000) return fail(KSH_INTERNAL, "matching did not converge");
+    }
+    KSH_HIP(hipMemsetAsync(p->visited, 0, size_t(n_u), st));
+    KSH_HIP(hipMemsetAsync(p->sc_used, 0, 8, st));
+    hipLaunchKernelGGL(k_cover_mark, dim3(nblk(n_u)), dim3(256), 0, st, p->mate, n_u, p->visited);
+    hipLaunchKernelGGL(k_loop_cut, dim3(unsigned((n_u + 63) / 64)), dim3(64), 0, st, p->mate, n_u,
+                       p->visited, p->sc_nodes, p->sc_parent, p->sc_rank, p->sc_used);
+    hipLaunchKernelGGL(k_string_starts, dim3(nblk(n_u)), dim3(256), 0, st, p->mate, p->u_len, n_u,
+                       p->scls, p->s_nk);
+    hipLaunchKernelGGL(k_string_counts, dim3(nblk(n_u)), dim3(256), 0, st, p->scls, n_u, p->sc01,
+                       p->sc2);
+    arena_reset(ctx);
+    int64_t* d_t2 = static_cast<int64_t*>(arena_alloc(ctx, 16));
+    KSH_TRY(scan_exclusive_i64(ctx, p->sc01, p->sc01, n_u, d_t2));
+    KSH_TRY(scan_exclusive_i64(ctx, p->sc2, p->sc2, n_u, d_t2 + 1));
+    KSH_HIP(hipMemcpyAsync(ctx->h_pinned, d_t2, 16, hipMemcpyDeviceToHost, st));
+    KSH_HIP(hipStreamSynchronize(st));
+    const int64_t s0 = ctx->h_pinned[0] & 0xFFFFFFFF, s1 = ctx->h_pinned[0] >> 32,
+                  s2 = ctx->h_pinned[1];
+    ns = s0 + s1 + s2;
+    hipLaunchKernelGGL(k_string_assign, dim3(nblk(n_u)), dim3(256), 0, st, p->mate, p->u_len, n_u,
+                       p->scls, p->sc01, p->sc2, p->s_nk, s0, s0 + s1, g->k, p->u_sid, p->u_koff,
+                       p->u_flip, p->lens, p->str_start);
+  }
+  // string starts in bases
+  arena_reset(ctx);
+  KSH_TRY(scan_exclusive_i64(ctx, p->str_start, p->str_start, ns, p->str_start + ns));
+  KSH_HIP(hipGetLastError());
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, p->str_start + ns, 8, hipMemcpyDeviceToHost, st));
+  KSH_HIP(hipStreamSynchronize(st));
+  p->n_strings = ns;
+  p->n_bases = ctx->h_pinned[0];
+  *n_strings = p->n_strings;
+  *n_bases = p->n_bases;
+  return KSH_OK;
+}
+
+template <typename KeyT>
+int encode_write_t(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens) {
+  EncPlan* p = static_cast<EncPlan*>(ctx->enc_state);
+  if (p->n == 0) return KSH_OK;
+  const ksh_geom* g = &p->g;
+  const int64_t n = p->n;
+  DevSet<KeyT> set{p->set.d_offsets, static_cast<const KeyT*>(p->set.d_keys), n_buckets(g), n, g->k,
+                   key_bits(g)};
+  hipStream_t st = ctx->stream;
+  // byte staging aliases the neighbour array (2n * 4 bytes >= n_bases needs checking)
+  const size_t need = size_t(p->n_bases) + 64;
+  uint8_t* bytes;
+  void* tmp = nullptr;
+  if (need <= size_t(2 * n) * 4) {
+    bytes = reinterpret_cast<uint8_t*>(p->nbr);
+  } else {
+    KSH_HIP(hipMalloc(&tmp, need));
+    bytes = static_cast<uint8_t*>(tmp);
+  }
+  hipLaunchKernelGGL((k_emit<KeyT>), dim3(nblk(n)), dim3(256), 0, st, set, p->head, p->pos, p->ori,
+                     p->uid, p->u_len, p->u_sid, p->u_koff, p->u_flip, p->str_start, p->lens, bytes);
+  const int64_t n_words = (p->n_bases + 31) / 32;
+  hipLaunchKernelGGL(k_pack, dim3(nblk(n_words)), dim3(256), 0, st, bytes, p->n_bases, n_words,
+                     d_words);
+  KSH_HIP(hipMemcpyAsync(d_lens, p->lens, size_t(p->n_strings) * 4, hipMemcpyDeviceToDevice, st));
+  KSH_HIP(hipGetLastError());
+  if (tmp) {
+    KSH_HIP(hipStreamSynchronize(st));
+    KSH_HIP(hipFree(tmp));
+  }
+  return KSH_OK;
+}
+
+}  // namespace ksh
+
+using namespace ksh;
+
+extern "C" {
+
+int ksh_spss_encode_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* set, int canonical_flag,
+                         int mode, int64_t* n_strings, int64_t* n_bases) {
+  if (!ctx || !set || !n_strings || !n_bases) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  KSH_TRY(check_geom(g));
+  if (!canonical_flag)
+    return fail(KSH_INVALID_ARGUMENT, "only canonical k-mer sets are supported (SURVEY.md: the "
+                                      "non-canonical variant is outside the hot path)");
+  if (mode != 0 && mode != 1) return fail(KSH_INVALID_ARGUMENT, "mode must be 0 (SPSS) or 1 (unitigs)");
+  if (set->n_keys < 0 || !set->d_offsets || (set->n_keys > 0 && !set->d_keys))
+    return fail(KSH_INVALID_ARGUMENT, "bad set view");
+  KSH_HIP(hipSetDevice(ctx->device));
+  return g->key_bytes == 4 ? encode_plan_t<uint32_t>(ctx, g, set, mode, n_strings, n_bases)
+                           : encode_plan_t<uint64_t>(ctx, g, set, mode, n_strings, n_bases);
+}
+
+int ksh_spss_encode_write(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens) {
+  if (!ctx) return fail(KSH_INVALID_ARGUMENT, "ctx is NULL");
+  EncPlan* p = static_cast<EncPlan*>(ctx->enc_state);
+  if (!p) return fail(KSH_FAILED_PRECONDITION, "ksh_spss_encode_write without ksh_spss_encode_plan");
+  if (p->n > 0 && (!d_words || !d_lens)) return fail(KSH_INVALID_ARGUMENT, "NULL output");
+  KSH_HIP(hipSetDevice(ctx->device));
+  return p->g.key_bytes == 4 ? encode_write_t<uint32_t>(ctx, d_words, d_lens)
+                             : encode_write_t<uint64_t>(ctx, d_words, d_lens);
+}
+
+int ksh_spss_encode_stats(ksh_ctx* ctx, int64_t stats[4]) {
+  if (!ctx || !stats) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  EncPlan* p = static_cast<EncPlan*>(ctx->enc_state);
+  if (!p) return fail(KSH_FAILED_PRECONDITION, "no encode plan");
+  stats[0] = p->n_u;
+  stats[1] = p->rounds;
+  stats[2] = p->n_strings;
+  stats[3] = p->n_bases;
+  return KSH_OK;
+}
+
+int ksh_spss_encode_release(ksh_ctx* ctx) {
+  if (ctx) free_plan(ctx);
+  return KSH_OK;
+}
+
+}  // extern "C"

@@ -51,6 +51,18 @@ struct ksh_ctx {
   // pinned host staging for small read-backs
   int64_t* h_pinned = nullptr;  // 64 int64
 
+  // persistent device buffers that must survive between two calls
+  // (decode plan -> write, encode plan -> write)
+  char* slot[2] = {nullptr, nullptr};
+  size_t slot_bytes[2] = {0, 0};
+
+  // decode plan state
+  int64_t dec_words = 0, dec_groups = 0, dec_kmers = 0;
+  const void* dec_src = nullptr;
+
+  // encode plan state (ksh_encode.hip)
+  void* enc_state = nullptr;
+
   // pair plan (ksh_pair_plan -> ksh_pair_write)
   char* plan = nullptr;
   size_t plan_bytes = 0;
@@ -74,12 +86,15 @@ inline void arena_reset(ksh_ctx* ctx) { ctx->arena_used = 0; }
 // Returns nullptr when the arena is too small (callers reserve first).
 void* arena_alloc(ksh_ctx* ctx, size_t bytes);
 int plan_reserve(ksh_ctx* ctx, size_t bytes);
+enum { kSlotDecode = 0, kSlotEncode = 1 };
+int slot_reserve(ksh_ctx* ctx, int which, size_t bytes);
 
 int check_geom(const ksh_geom* g);
 inline int64_t n_buckets(const ksh_geom* g) { return int64_t(1) << g->n_bucket_bits; }
 inline int key_bits(const ksh_geom* g) { return 2 * g->k - g->n_bucket_bits; }
 
 hipEvent_t timer_event(ksh_ctx* ctx, size_t* index);
+void free_plan(ksh_ctx* ctx);  // ksh_encode.hip
 
 struct Timer {
   ksh_ctx* ctx;

@@ -1,0 +1,81 @@
+// Device-side k-mer primitives (lib/core/kmer.h:103-186, lib/core/kmer_set.h:22-43)
+// and membership in a bucketed sorted set (KmerSet::Contains, kmer_set.h:99-105).
+// gfx950 only.
+#ifndef KSH_KMER_H_
+#define KSH_KMER_H_
+
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+namespace ksh {
+
+// Reverse complement of a 2-bit packed k-mer, bit-parallel (the reference loops K
+// times, kmer.h:103-129; same function).
+__device__ __forceinline__ uint64_t revcomp(uint64_t x, int k) {
+  x = ~x;
+  x = ((x >> 2) & 0x3333333333333333ull) | ((x & 0x3333333333333333ull) << 2);
+  x = ((x >> 4) & 0x0F0F0F0F0F0F0F0Full) | ((x & 0x0F0F0F0F0F0F0F0Full) << 4);
+  x = __builtin_bswap64(x);
+  return x >> (64 - 2 * k);
+}
+
+__device__ __forceinline__ uint64_t canonical(uint64_t x, int k) {
+  const uint64_t r = revcomp(x, k);
+  return x < r ? x : r;
+}
+
+__device__ __forceinline__ uint64_t kmer_mask(int k) { return ~uint64_t(0) >> (64 - 2 * k); }
+
+// Kmer::Next / Kmer::Prev (kmer.h:136-186), c in 0..3.
+__device__ __forceinline__ uint64_t kmer_next(uint64_t x, int k, int c) {
+  return ((x << 2) & kmer_mask(k)) | uint64_t(c);
+}
+__device__ __forceinline__ uint64_t kmer_prev(uint64_t x, int k, int c) {
+  return (x >> 2) | (uint64_t(c) << (2 * (k - 1)));
+}
+
+// A resident set seen from a kernel.
+template <typename KeyT>
+struct DevSet {
+  const int64_t* off;  // [n_buckets + 1]
+  const KeyT* keys;
+  int64_t n_buckets;
+  int64_t n;
+  int k;
+  int key_bits;
+
+  __device__ __forceinline__ uint64_t key_mask() const {
+    return key_bits == 64 ? ~uint64_t(0) : ((uint64_t(1) << key_bits) - 1);
+  }
+
+  // Index of k-mer z in the set's ascending order, or -1.
+  __device__ int64_t find(uint64_t z) const {
+    const int64_t b = int64_t(z >> key_bits);
+    const KeyT key = KeyT(z & key_mask());
+    int64_t lo = off[b], hi = off[b + 1];
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (keys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    return (lo < off[b + 1] && keys[lo] == key) ? lo : int64_t(-1);
+  }
+
+  // Bucket holding index t (largest b with off[b] <= t).
+  __device__ int64_t bucket_of(int64_t t) const {
+    int64_t lo = 0, hi = n_buckets;
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (off[mid + 1] <= t) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  }
+
+  __device__ __forceinline__ uint64_t kmer(int64_t t) const {
+    return (uint64_t(bucket_of(t)) << key_bits) | uint64_t(keys[t]);
+  }
+};
+
+}  // namespace ksh
+
+#endif

@@ -34,6 +34,11 @@ class SetView(C.Structure):
     _fields_ = [("d_offsets", C.c_void_p), ("d_keys", C.c_void_p), ("n_keys", C.c_int64)]
 
 
+class SpssView(C.Structure):
+    _fields_ = [("d_words", C.c_void_p), ("d_lens", C.c_void_p), ("n_strings", C.c_int64),
+                ("n_bases", C.c_int64)]
+
+
 def build(force=False):
     """Compiles the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith((".hip", ".h"))]
@@ -83,6 +88,14 @@ def lib():
         "ksh_set_diff": (C.c_int, [vp, GP, SP, SP, C.POINTER(i64)]),
         "ksh_pair_weights": (C.c_int, [vp, GP, SP, i32, C.POINTER(i32), i32, C.POINTER(i32), i32,
                                        C.POINTER(i64)]),
+        "ksh_spss_size": (C.c_int, [vp, GP, C.POINTER(SpssView), C.POINTER(i64)]),
+        "ksh_spss_decode_plan": (C.c_int, [vp, GP, C.POINTER(SpssView), C.c_int, vp, C.POINTER(i64)]),
+        "ksh_spss_decode_write": (C.c_int, [vp, GP, C.POINTER(SpssView), C.c_int, vp, vp,
+                                            C.POINTER(i64)]),
+        "ksh_spss_encode_plan": (C.c_int, [vp, GP, SP, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]),
+        "ksh_spss_encode_write": (C.c_int, [vp, vp, vp]),
+        "ksh_spss_encode_stats": (C.c_int, [vp, C.POINTER(i64)]),
+        "ksh_spss_encode_release": (C.c_int, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -160,6 +173,42 @@ class DeviceSet:
         return synth.from_bucketed(off, keys, self.g.k, self.g.n_bucket_bits)
 
 
+class DeviceSpss:
+    """KmerSetCompact on device: 2-bit bases in 64-bit words + (len - K) per string."""
+
+    def __init__(self, g, words, lens, n_strings, n_bases):
+        self.g, self.words, self.lens = g, words, lens
+        self.n_strings, self.n_bases = int(n_strings), int(n_bases)
+
+    @classmethod
+    def from_strings(cls, g, strings, device):
+        import torch
+        from . import synth
+
+        words, lens = synth.pack_strings(strings, g.k)
+        w = torch.from_numpy(words.view(np.int64).copy()).to(device)
+        ln = torch.from_numpy(lens.view(np.int32).copy()).to(device)
+        if w.numel() == 0:
+            w = torch.zeros(1, dtype=torch.int64, device=device)
+        if ln.numel() == 0:
+            ln = torch.zeros(1, dtype=torch.int32, device=device)
+        return cls(g, w, ln, len(strings), int(sum(len(x) for x in strings)))
+
+    def view(self):
+        return SpssView(self.words.data_ptr(), self.lens.data_ptr(), self.n_strings, self.n_bases)
+
+    def to_strings(self):
+        from . import synth
+
+        n_words = (self.n_bases + 31) // 32
+        words = self.words[:n_words].cpu().numpy().view(np.uint64)
+        lens = self.lens[: self.n_strings].cpu().numpy().view(np.uint32)
+        return synth.unpack_strings(words, lens, self.g.k)
+
+    def weight(self):
+        return self.n_bases
+
+
 class Context:
     """ksh_ctx on one GPU, bound to torch's current stream on that device."""
 
@@ -232,6 +281,48 @@ class Context:
             o.keys = torch.empty(max(n * g.key_bytes, 16), dtype=torch.uint8, device=self.device)
         self.pair_write(a, b, *outs)
         return outs
+
+    # KmerSetCompact::Size / ToKmerSet ---------------------------------------------------
+    def spss_size(self, sp):
+        out = C.c_int64()
+        v = sp.view()
+        check(lib().ksh_spss_size(self.h, C.byref(sp.g), C.byref(v), C.byref(out)))
+        return out.value
+
+    def spss_decode(self, sp, canonical=True):
+        import torch
+
+        g = sp.g
+        out = DeviceSet.empty_like_offsets(g, 0, self.device)
+        n = C.c_int64()
+        v = sp.view()
+        check(lib().ksh_spss_decode_plan(self.h, C.byref(g), C.byref(v), int(canonical),
+                                         out.offsets.data_ptr(), C.byref(n)))
+        out.keys = torch.empty(max(n.value * g.key_bytes, 16), dtype=torch.uint8, device=self.device)
+        check(lib().ksh_spss_decode_write(self.h, C.byref(g), C.byref(v), int(canonical),
+                                          out.offsets.data_ptr(), out.keys.data_ptr(), C.byref(n)))
+        out.n_keys = n.value
+        return out
+
+    # KmerSetCompact::FromKmerSet / GetUnitigsCanonical ---------------------------------------
+    def spss_encode(self, s, mode=0, canonical=True):
+        """mode 0: SPSS (GetSPSSCanonical, fast); mode 1: unitigs.  Returns a DeviceSpss."""
+        import torch
+
+        ns, nbases = C.c_int64(), C.c_int64()
+        v = s.view()
+        check(lib().ksh_spss_encode_plan(self.h, C.byref(s.g), C.byref(v), int(canonical), mode,
+                                         C.byref(ns), C.byref(nbases)))
+        n_words = (nbases.value + 31) // 32
+        words = torch.empty(max(n_words, 1), dtype=torch.int64, device=self.device)
+        lens = torch.empty(max(ns.value, 1), dtype=torch.int32, device=self.device)
+        check(lib().ksh_spss_encode_write(self.h, words.data_ptr(), lens.data_ptr()))
+        return DeviceSpss(s.g, words, lens, ns.value, nbases.value)
+
+    def spss_encode_stats(self):
+        st = (C.c_int64 * 4)()
+        check(lib().ksh_spss_encode_stats(self.h, st))
+        return {"unitigs": st[0], "rounds": st[1], "strings": st[2], "bases": st[3]}
 
     def set_diff(self, a, b):
         out = C.c_int64()

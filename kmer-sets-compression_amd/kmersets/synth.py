@@ -193,3 +193,36 @@ def circular_with_tails(k, length, n_tails, tail_len, seed):
         seq = np.concatenate([anchor, tail]) if out_going else np.concatenate([tail, anchor])
         parts.append(kmers_of_bases(seq, k))
     return np.unique(canonical(np.concatenate(parts), k))
+
+
+def pack_strings(strings, k):
+    """ACGT strings -> (uint64 words, uint32 len - K): the device SPSS container
+    (kmer_set_compact.h:206-266 layout, see include/kmersets_hip.h)."""
+    lens = np.array([len(x) - k for x in strings], dtype=np.int64)
+    assert np.all(lens >= 0), "every SPSS string holds at least one k-mer"
+    total = int(sum(len(x) for x in strings))
+    if total == 0:
+        return np.zeros(0, dtype=U), lens.astype(np.uint32)
+    codes = bases_of_string("".join(strings)).astype(U)
+    n_words = (total + 31) // 32
+    padded = np.zeros(n_words * 32, dtype=U)
+    padded[:total] = codes
+    shifts = (U(62) - U(2) * (np.arange(32, dtype=U)))
+    words = np.bitwise_or.reduce(padded.reshape(n_words, 32) << shifts[None, :], axis=1)
+    return words.astype(U), lens.astype(np.uint32)
+
+
+def unpack_strings(words, lens, k):
+    words = np.asarray(words, dtype=U)
+    lens = np.asarray(lens, dtype=np.int64) + k
+    total = int(lens.sum())
+    if total == 0:
+        return ["" for _ in lens]
+    shifts = (U(62) - U(2) * (np.arange(32, dtype=U)))
+    codes = ((words[:, None] >> shifts[None, :]) & U(3)).reshape(-1)[:total].astype(np.uint8)
+    text = string_of_bases(codes)
+    out, at = [], 0
+    for ln in lens:
+        out.append(text[at:at + int(ln)])
+        at += int(ln)
+    return out

@@ -1,0 +1,167 @@
+"""GPU parity tests for the SPSS container: decode (KmerSetCompact::ToKmerSet), encode
+(KmerSetCompact::FromKmerSet = GetSPSSCanonical fast, and GetUnitigsCanonical) and
+Size/Weight, through the C ABI, against the oracle on the same seeded inputs.
+Bit-exact: the strings must equal the oracle's, in order."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from kmersets import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(gpu):
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def dev_set(ctx, k, n, kmers):
+    return capi.DeviceSet.from_kmers(capi.geom(k, n), np.asarray(kmers, dtype=np.uint64), ctx.device)
+
+
+def kmers_of(seq, k):
+    return synth.canonical_set_of_bases(synth.bases_of_string(seq), k)
+
+
+# ------------------------------------------------------------------------------ decode
+@pytest.mark.parametrize("geom", [(5, 3, 1), (9, 10, 1), (15, 14, 2), (19, 10, 4), (23, 14, 4), (31, 14, 8)])
+def test_decode_oracle_spss(ctx, geom):
+    """ToKmerSet(FromKmerSet(S)) == S  (test/kmer_set_compact.cc:71-90), decode side."""
+    k, n, kb = geom
+    kmers = synth.random_read_kmers(k, 150 if k == 5 else 6000, seed=k + 1, canonical=True)
+    oset = ol.Set.from_kmers(k, n, kb, kmers)
+    strings = oset.spss()
+    sp = capi.DeviceSpss.from_strings(capi.geom(k, n), strings, ctx.device)
+    assert ctx.spss_size(sp) == oset.size() == oset.compact().size()
+    assert sp.weight() == oset.compact().weight()
+    got = ctx.spss_decode(sp)
+    assert got.n_keys == oset.size()
+    assert np.array_equal(got.kmers(), oset.kmers())
+    off, keys = got.to_numpy()
+    w_off, w_keys = synth.to_bucketed(oset.kmers(), k, n, got.g.key_bytes)
+    assert np.array_equal(off, w_off) and np.array_equal(keys, w_keys)
+
+
+def test_decode_arbitrary_lines(ctx):
+    """GetKmerSetFromSPSS on lines that are not an SPSS: repeated k-mers collapse, strings
+    of exactly K bases, string boundaries at every offset of the 32-base words."""
+    k, n, kb = 9, 10, 1
+    g = synth.random_genome(3000, 77)
+    text = synth.string_of_bases(g)
+    lines = []
+    at = 0
+    for i in range(120):
+        ln = k + (i * 7) % 40
+        lines.append(text[at:at + ln])
+        at += ln - (i % 5)            # overlaps -> repeated k-mers across lines
+    lines += [text[:k], text[:k], text[5:5 + k], "ACGTACGTACGTACGTACGT", "A" * 40]
+    want = ol.Set.from_spss(lines, k, n, kb)
+    sp = capi.DeviceSpss.from_strings(capi.geom(k, n), lines, ctx.device)
+    got = ctx.spss_decode(sp)
+    assert got.n_keys == want.size()
+    assert np.array_equal(got.kmers(), want.kmers())
+    assert ctx.spss_size(sp) == sum(len(x) - k + 1 for x in lines)
+    # non-canonical decode keeps the forward k-mers
+    want_fw = ol.Set.from_spss(lines, k, n, kb, canonical=False)
+    got_fw = ctx.spss_decode(sp, canonical=False)
+    assert np.array_equal(got_fw.kmers(), want_fw.kmers())
+
+
+def test_decode_empty_and_tiny(ctx):
+    k, n = 23, 14
+    g = capi.geom(k, n)
+    sp = capi.DeviceSpss.from_strings(g, [], ctx.device)
+    got = ctx.spss_decode(sp)
+    assert got.n_keys == 0 and int(got.offsets[-1]) == 0
+    one = "ACGTTGCATGCATGACTGACTGA"
+    sp = capi.DeviceSpss.from_strings(g, [one], ctx.device)
+    got = ctx.spss_decode(sp)
+    assert got.n_keys == 1
+    assert int(got.kmers()[0]) == int(ol.lib().ko_canonical(ol.kmer(one), k))
+
+
+# ------------------------------------------------------------------------------ encode
+def check_encode(ctx, k, n, kb, kmers):
+    oset = ol.Set.from_kmers(k, n, kb, kmers)
+    d = dev_set(ctx, k, n, oset.kmers())
+    unitigs = ctx.spss_encode(d, mode=1)
+    assert unitigs.to_strings() == oset.unitigs()
+    spss = ctx.spss_encode(d, mode=0)
+    stats = ctx.spss_encode_stats()
+    want = oset.spss()
+    assert spss.to_strings() == want
+    assert spss.n_strings == len(want) and spss.n_bases == sum(len(x) for x in want)
+    assert spss.weight() == oset.compact().weight()
+    # and back: ToKmerSet(FromKmerSet(S)) == S on device
+    back = ctx.spss_decode(spss)
+    assert back.n_keys == d.n_keys and ctx.set_diff(back, d) == 0
+    return stats
+
+
+def test_encode_known_answers(ctx):
+    """SURVEY.md 3.2 known answers of the reference, and the small special shapes."""
+    k, n, kb = 5, 3, 1
+    d = dev_set(ctx, k, n, kmers_of("AACCGTTAGCAT", k))
+    assert ctx.spss_encode(d, mode=0).to_strings() == ["ATGCTAACGGTT"]
+    d = dev_set(ctx, k, n, kmers_of("ACGTACGTACG", k))
+    assert ctx.spss_encode(d, mode=0).to_strings() == ["GTACGT"]
+    for seq in ["AAAAAAAAA", "AACCGGTT", "ACGTTGCAACGT", "ATATATATAT", "GATTACAGATTACAGATTACA",
+                "CCCCCCGGGGGG"]:
+        check_encode(ctx, k, n, kb, kmers_of(seq, k))
+    e = dev_set(ctx, k, n, np.zeros(0, dtype=np.uint64))
+    sp = ctx.spss_encode(e, mode=0)
+    assert sp.n_strings == 0 and sp.n_bases == 0 and sp.to_strings() == []
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_encode_random_reads(ctx, seed):
+    """test/spss.cc:43-66,127-153 shapes (K=9, N=10), exact strings instead of invariants."""
+    k = [5, 7, 9, 9, 11, 15, 9, 9][seed]
+    size = [50, 300, 2000, 20000, 3000, 3000, 65536, 1][seed]
+    km = synth.random_read_kmers(k, min(size, 4 ** k // 3), seed=seed, canonical=True)
+    check_encode(ctx, k, min(10, 2 * k - 4), 4, km)
+
+
+def test_encode_loops_and_loop_cuts(ctx):
+    """Non-branching loops (spss.h:585-610) and loops of the path cover (spss.h:1578-1644)."""
+    n_loops = 0
+    for seed in range(60):
+        k = [5, 7, 9, 11][seed % 4]
+        km = synth.circular_with_tails(k, 20 + (seed * 7) % 150, seed % 5, 1 + seed % 4, seed)
+        check_encode(ctx, k, min(10, 2 * k - 4), 4, km)
+        n_loops += 1
+    assert n_loops == 60
+
+
+@pytest.mark.parametrize("geom", [(15, 14, 2), (19, 10, 4), (23, 14, 4), (31, 14, 8)])
+def test_encode_families(ctx, geom):
+    """The CLI geometries on a correlated family and on its algebra results (what one
+    KmerSetSet iteration encodes: A&B, A\\B, B\\A)."""
+    k, n, kb = geom
+    sets = synth.phylogeny_sets(k, 3, 30000, seed=k)
+    stats = check_encode(ctx, k, n, kb, sets[0])
+    assert stats["unitigs"] >= 1
+    check_encode(ctx, k, n, kb, np.intersect1d(sets[0], sets[1]))
+    check_encode(ctx, k, n, kb, np.setdiff1d(sets[0], sets[1]))
+    check_encode(ctx, k, n, kb, np.setdiff1d(sets[2], sets[0]))
+
+
+def test_encode_roundtrip_large(ctx):
+    """Size-independent properties at 2 x 10^6 k-mers (k = 23): every k-mer exactly once,
+    decode(encode(S)) == S, weight = |S| + (K-1) * strings."""
+    k, n = 23, 14
+    sets = synth.phylogeny_sets(k, 2, 2_000_000, seed=5)
+    a, b = dev_set(ctx, k, n, sets[0]), dev_set(ctx, k, n, sets[1])
+    inter, amb, _ = ctx.pair_algebra(a, b)
+    for s in (a, inter, amb):
+        sp = ctx.spss_encode(s, mode=0)
+        assert ctx.spss_size(sp) == s.n_keys               # sum(len - K + 1) == |S|: no k-mer twice
+        assert sp.n_bases == s.n_keys + (k - 1) * sp.n_strings
+        back = ctx.spss_decode(sp)
+        assert back.n_keys == s.n_keys and ctx.set_diff(back, s) == 0
+        un = ctx.spss_encode(s, mode=1)
+        assert un.n_strings >= sp.n_strings
+        assert ctx.set_diff(ctx.spss_decode(un), s) == 0

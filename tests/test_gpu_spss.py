@@ -49,7 +49,7 @@ def test_decode_arbitrary_lines(ctx):
     """GetKmerSetFromSPSS on lines that are not an SPSS: repeated k-mers collapse, strings
     of exactly K bases, string boundaries at every offset of the 32-base words."""
     k, n, kb = 9, 10, 1
-    g = synth.random_genome(3000, 77)
+    g = synth.random_genome(8000, 77)
     text = synth.string_of_bases(g)
     lines = []
     at = 0

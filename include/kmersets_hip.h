@@ -106,6 +106,13 @@ int ksh_pair_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const 
 int ksh_pair_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
                    void* d_keys_i, void* d_keys_amb, void* d_keys_bma);
 
+/* KmerSet::Add(other) / free Add (lib/core/kmer_set.h:164-174,286-290): A | B, same
+ * two-call shape.  d_off_u is int64[2^N + 1]; d_keys_u holds `total` keys. */
+int ksh_set_union_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a,
+                       const ksh_set_view* b, int64_t* d_off_u, int64_t* total);
+int ksh_set_union_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a,
+                        const ksh_set_view* b, void* d_keys_u);
+
 /* ---- KmerSet::Diff / Equals  (lib/core/kmer_set.h:191-219) ----------------------------- */
 /* |A \ B| + |B \ A|. */
 int ksh_set_diff(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
@@ -165,6 +172,41 @@ int ksh_spss_encode_write(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens);
 int ksh_spss_encode_stats(ksh_ctx* ctx, int64_t stats[4]);
 /* Frees the current plan's device memory (also done by the next plan / ctx_destroy). */
 int ksh_spss_encode_release(ksh_ctx* ctx);
+
+/* ---- KmerSetSet: the loop kmerset-multiple-compress runs -------------------------------
+ * ksh_kss_build = KmerSetSet(vector<KmerSetCompact>, canonical, n_workers)
+ * (lib/core/kmer_set_set.h:109-427) on device-resident sets.  inputs are the
+ * KmerSetCompact containers (device); bucket_ids replaces the unseeded
+ * GetRandomInts((1 << N) / 50, ...) of :123-124 (HOST array, ascending);
+ * max_iterations < 0 runs to the reference's stopping rule.  The input containers
+ * must stay alive while they are nodes of the result. */
+typedef struct ksh_kss ksh_kss;
+int ksh_kss_build(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* inputs, int32_t n_inputs,
+                  const int32_t* bucket_ids, int32_t n_ids, int canonical, int32_t max_iterations,
+                  ksh_kss** out);
+int ksh_kss_destroy(ksh_kss* k);
+/* KmerSetSet::Size (:430): number of nodes. */
+int ksh_kss_size(const ksh_kss* k, int32_t* n_nodes);
+/* Node i: its SPSS container, its resident set and its k-mer count (any may be NULL). */
+int ksh_kss_node(const ksh_kss* k, int32_t i, ksh_spss_view* compact, ksh_set_view* set,
+                 int64_t* size);
+/* children_[i] (:365-366); the pointer stays valid until ksh_kss_destroy. */
+int ksh_kss_children(const ksh_kss* k, int32_t i, const int32_t** children, int32_t* n_children);
+/* Line 0 of meta.<ext> (SerializeAdjacencyList, :45-56), keys ascending. */
+const char* ksh_kss_meta(const ksh_kss* k);
+/* Per-iteration rows {j, k, weight, |S_j| + |S_k|, size_diff} (the values the reference
+ * logs at :324,:380) and per-checkpoint rows {iteration, previous, updated, stopped}
+ * with the float improvement of :289-295. */
+int ksh_kss_trace(const ksh_kss* k, int64_t* n_iterations, const int64_t** rows,
+                  int64_t* n_checkpoints, const int64_t** checkpoint_rows,
+                  const float** improvements);
+int ksh_kss_initial_weights(const ksh_kss* k, const int64_t** weights, int64_t* n);
+/* stats = { initial total_size, final total_size, initial total_spss_weight, N_proc
+ * (SURVEY.md 8d), final total_spss_weight, sum ceil(2 Weight / 8) bytes, strings, nodes }. */
+int ksh_kss_stats(const ksh_kss* k, int64_t stats[8]);
+/* KmerSetSet::Get(i) (:433-454): union over the nodes reachable from i.  Returns new
+ * device buffers (release with ksh_free). */
+int ksh_kss_get(const ksh_kss* k, int32_t i, int64_t** d_offsets, void** d_keys, int64_t* n_keys);
 
 #ifdef __cplusplus
 }

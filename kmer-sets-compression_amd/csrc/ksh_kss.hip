@@ -1,0 +1,413 @@
+// KmerSetSet on device: the greedy pair-merge loop that kmerset-multiple-compress runs
+// (lib/core/kmer_set_set.h:109-427), Get (:433-454) and the node accessors.
+//
+// Host control flow is the reference's, statement for statement (same float
+// arithmetic for the stopping rule, same pair lists), with the oracle's two
+// ordering rules: bucket_ids are an input and the arg-max takes the first maximal
+// (j, k) in lexicographic order.  What changes is where the data lives:
+//
+//   * every node's k-mer set stays resident in HBM as bucketed sorted keys, so the
+//     reference's two ToKmerSet decodes per iteration (:333-336) disappear -- inputs
+//     are decoded once -- and GetSampledKmerSet (:349-363) is a slice, not a pass;
+//   * Intersection + Sub + Sub (:339-343) is one ksh_pair_plan/ksh_pair_write;
+//   * the three FromKmerSet re-encodes (:345-360) are ksh_spss_encode_*;
+//   * the weight table (:191-219,:385-425) is ksh_pair_weights.
+#include "ksh_internal.h"
+
+#include <cstring>
+#include <map>
+#include <queue>
+#include <utility>
+#include <vector>
+
+struct KssSet {
+  int64_t* off = nullptr;
+  void* keys = nullptr;
+  int64_t n = 0;
+};
+
+struct KssCompact {
+  uint64_t* words = nullptr;
+  uint32_t* lens = nullptr;
+  int64_t n_strings = 0, n_bases = 0, size = 0;
+  bool owned = false;
+};
+
+struct ksh_kss {
+  ksh_ctx* ctx = nullptr;
+  ksh_geom g{};
+  int canonical = 1;
+  std::vector<KssSet> sets;
+  std::vector<KssCompact> compacts;
+  std::map<int, std::vector<int>> children;
+  std::vector<int64_t> trace;        // 5 per iteration: j, k, weight, original_size, size_diff
+  std::vector<int64_t> checkpoints;  // 4 per checkpoint: iteration, previous, updated, stopped
+  std::vector<float> improvements;
+  std::vector<int64_t> initial_weights;
+  int64_t initial_total_size = 0, final_total_size = 0, initial_spss_weight = 0, n_processed = 0;
+  int64_t final_spss_weight = 0;
+  std::string meta;
+};
+
+namespace ksh {
+
+static void free_set(KssSet* s) {
+  if (s->off) (void)hipFree(s->off);
+  if (s->keys) (void)hipFree(s->keys);
+  *s = KssSet{};
+}
+
+static void free_compact(KssCompact* c) {
+  if (c->owned) {
+    if (c->words) (void)hipFree(c->words);
+    if (c->lens) (void)hipFree(c->lens);
+  }
+  *c = KssCompact{};
+}
+
+static ksh_set_view view_of(const KssSet& s) { return ksh_set_view{s.off, s.keys, s.n}; }
+static ksh_spss_view view_of(const KssCompact& c) {
+  return ksh_spss_view{c.words, c.lens, c.n_strings, c.n_bases};
+}
+
+static int alloc_set(const ksh_geom* g, int64_t n_keys, KssSet* out) {
+  const int64_t nb = n_buckets(g);
+  KSH_HIP(hipMalloc(reinterpret_cast<void**>(&out->off), size_t(nb + 1) * 8));
+  KSH_HIP(hipMalloc(&out->keys, std::max<size_t>(size_t(n_keys) * g->key_bytes, 16)));
+  out->n = n_keys;
+  return KSH_OK;
+}
+
+static int decode_to_set(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* sp, int canonical_flag,
+                         KssSet* out) {
+  const int64_t nb = n_buckets(g);
+  KSH_HIP(hipMalloc(reinterpret_cast<void**>(&out->off), size_t(nb + 1) * 8));
+  int64_t n = 0;
+  KSH_TRY(ksh_spss_decode_plan(ctx, g, sp, canonical_flag, out->off, &n));
+  KSH_HIP(hipMalloc(&out->keys, std::max<size_t>(size_t(n) * g->key_bytes, 16)));
+  KSH_TRY(ksh_spss_decode_write(ctx, g, sp, canonical_flag, out->off, out->keys, &n));
+  out->n = n;
+  return KSH_OK;
+}
+
+static int encode_set(ksh_ctx* ctx, const ksh_geom* g, const KssSet& s, KssCompact* out) {
+  const ksh_set_view v = view_of(s);
+  int64_t ns = 0, nbases = 0;
+  KSH_TRY(ksh_spss_encode_plan(ctx, g, &v, 1, 0, &ns, &nbases));
+  out->owned = true;
+  KSH_HIP(hipMalloc(reinterpret_cast<void**>(&out->words), std::max<size_t>(size_t((nbases + 31) / 32) * 8, 16)));
+  KSH_HIP(hipMalloc(reinterpret_cast<void**>(&out->lens), std::max<size_t>(size_t(ns) * 4, 16)));
+  KSH_TRY(ksh_spss_encode_write(ctx, out->words, out->lens));
+  out->n_strings = ns;
+  out->n_bases = nbases;
+  out->size = s.n;
+  return KSH_OK;
+}
+
+static int pair_weights(ksh_kss* k, const std::vector<int32_t>& ids,
+                        const std::vector<std::pair<int, int>>& pairs, std::vector<int64_t>* out) {
+  std::vector<ksh_set_view> views;
+  for (const KssSet& s : k->sets) views.push_back(view_of(s));
+  std::vector<int32_t> flat;
+  for (const auto& p : pairs) {
+    flat.push_back(p.first);
+    flat.push_back(p.second);
+  }
+  out->assign(pairs.size(), 0);
+  return ksh_pair_weights(k->ctx, &k->g, views.data(), int32_t(views.size()), ids.data(),
+                          int32_t(ids.size()), flat.data(), int32_t(pairs.size()), out->data());
+}
+
+// SerializeAdjacencyList (kmer_set_set.h:45-56), keys ascending.
+static std::string serialize_children(const std::map<int, std::vector<int>>& a) {
+  std::string s = std::to_string(a.size());
+  for (const auto& p : a) {
+    s += ' ' + std::to_string(p.first);
+    s += ' ' + std::to_string(p.second.size());
+    for (int i : p.second) s += ' ' + std::to_string(i);
+  }
+  return s;
+}
+
+static int build(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs,
+                 const std::vector<int32_t>& ids, int32_t max_iterations) {
+  ksh_ctx* ctx = k->ctx;
+  const ksh_geom* g = &k->g;
+  // inputs: keep the caller's containers as the nodes' compacts, decode each once
+  for (int32_t i = 0; i < n_inputs; i++) {
+    KssCompact c;
+    c.words = const_cast<uint64_t*>(inputs[i].d_words);
+    c.lens = const_cast<uint32_t*>(inputs[i].d_lens);
+    c.n_strings = inputs[i].n_strings;
+    c.n_bases = inputs[i].n_bases;
+    c.owned = false;
+    KSH_TRY(ksh_spss_size(ctx, g, &inputs[i], &c.size));
+    k->compacts.push_back(c);
+    k->sets.emplace_back();
+    KSH_TRY(decode_to_set(ctx, g, &inputs[i], k->canonical, &k->sets.back()));
+  }
+
+  std::map<std::pair<int, int>, int64_t> weights;
+  {
+    std::vector<std::pair<int, int>> pairs;
+    for (int i = 0; i < n_inputs; i++)
+      for (int j = i + 1; j < n_inputs; j++) pairs.emplace_back(i, j);
+    std::vector<int64_t> w;
+    KSH_TRY(pair_weights(k, ids, pairs, &w));
+    for (size_t i = 0; i < pairs.size(); i++) weights[pairs[i]] = w[i];
+    k->initial_weights = w;
+  }
+
+  int64_t total_size = 0;
+  for (const KssCompact& c : k->compacts) total_size += c.size;
+  k->initial_total_size = total_size;
+  k->n_processed = total_size;
+
+  const auto total_spss_weight_now = [&] {
+    int64_t total = 0;
+    for (const KssCompact& c : k->compacts) total += c.n_bases;
+    return total;
+  };
+  int64_t total_spss_weight = total_spss_weight_now();
+  k->initial_spss_weight = total_spss_weight;
+
+  const int interval = int(k->compacts.size() / 8 + 1);
+  const float improvement_threshold = 0.1 * interval / k->compacts.size();
+
+  for (int i = 0;; i++) {
+    if (max_iterations >= 0 && i >= max_iterations) break;
+    if (i > 0 && i % interval == 0) {
+      const int64_t updated = total_spss_weight_now();
+      const float improvement = static_cast<float>(total_spss_weight - updated) / total_spss_weight;
+      const bool stop = improvement <= improvement_threshold;
+      k->checkpoints.insert(k->checkpoints.end(), {int64_t(i), total_spss_weight, updated, int64_t(stop)});
+      k->improvements.push_back(improvement);
+      if (stop) break;
+      total_spss_weight = updated;
+    }
+    const int n = int(k->compacts.size());
+    int64_t weight = 0;
+    int j = -1, kk = -1;
+    for (const auto& p : weights) {
+      if (p.second > weight) {
+        j = p.first.first;
+        kk = p.first.second;
+        weight = p.second;
+      }
+    }
+    if (weight == 0) break;
+
+    const int64_t original_size = k->compacts[j].size + k->compacts[kk].size;
+    {
+      const ksh_set_view vj = view_of(k->sets[j]), vk = view_of(k->sets[kk]);
+      KssSet sn, sj, sk;
+      const int64_t nb = n_buckets(g);
+      KSH_HIP(hipMalloc(reinterpret_cast<void**>(&sn.off), size_t(nb + 1) * 8));
+      KSH_HIP(hipMalloc(reinterpret_cast<void**>(&sj.off), size_t(nb + 1) * 8));
+      KSH_HIP(hipMalloc(reinterpret_cast<void**>(&sk.off), size_t(nb + 1) * 8));
+      int64_t totals[3];
+      KSH_TRY(ksh_pair_plan(ctx, g, &vj, &vk, sn.off, sj.off, sk.off, totals));
+      sn.n = totals[0];
+      sj.n = totals[1];
+      sk.n = totals[2];
+      KSH_HIP(hipMalloc(&sn.keys, std::max<size_t>(size_t(sn.n) * g->key_bytes, 16)));
+      KSH_HIP(hipMalloc(&sj.keys, std::max<size_t>(size_t(sj.n) * g->key_bytes, 16)));
+      KSH_HIP(hipMalloc(&sk.keys, std::max<size_t>(size_t(sk.n) * g->key_bytes, 16)));
+      KSH_TRY(ksh_pair_write(ctx, g, &vj, &vk, sn.keys, sj.keys, sk.keys));
+      KSH_HIP(hipStreamSynchronize(ctx->stream));
+
+      KssCompact cn, cj, ck;
+      KSH_TRY(encode_set(ctx, g, sn, &cn));
+      KSH_TRY(encode_set(ctx, g, sj, &cj));
+      KSH_TRY(encode_set(ctx, g, sk, &ck));
+      KSH_HIP(hipStreamSynchronize(ctx->stream));
+
+      k->sets.push_back(sn);
+      k->compacts.push_back(cn);
+      free_set(&k->sets[j]);
+      free_compact(&k->compacts[j]);
+      k->sets[j] = sj;
+      k->compacts[j] = cj;
+      free_set(&k->sets[kk]);
+      free_compact(&k->compacts[kk]);
+      k->sets[kk] = sk;
+      k->compacts[kk] = ck;
+      k->children[j].push_back(n);
+      k->children[kk].push_back(n);
+    }
+    const int64_t size_diff =
+        k->compacts[n].size + k->compacts[j].size + k->compacts[kk].size - original_size;
+    total_size += size_diff;
+    k->n_processed += original_size;
+    k->trace.insert(k->trace.end(), {int64_t(j), int64_t(kk), weight, original_size, size_diff});
+
+    {
+      std::vector<std::pair<int, int>> pairs;
+      for (int l = 0; l < n; l++) {
+        if (j == l) continue;
+        pairs.emplace_back(std::min(j, l), std::max(j, l));
+      }
+      for (int l = 0; l < n; l++) {
+        if (kk == l) continue;
+        pairs.emplace_back(std::min(kk, l), std::max(kk, l));
+      }
+      for (int l = 0; l < n; l++) pairs.emplace_back(l, n);
+      std::vector<int64_t> w;
+      KSH_TRY(pair_weights(k, ids, pairs, &w));
+      for (size_t q = 0; q < pairs.size(); q++) weights[pairs[q]] = w[q];
+    }
+  }
+  k->final_total_size = total_size;
+  k->final_spss_weight = total_spss_weight_now();
+  k->meta = serialize_children(k->children);
+  return KSH_OK;
+}
+
+}  // namespace ksh
+
+using namespace ksh;
+
+extern "C" {
+
+int ksh_kss_build(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* inputs, int32_t n_inputs,
+                  const int32_t* bucket_ids, int32_t n_ids, int canonical_flag,
+                  int32_t max_iterations, ksh_kss** out) {
+  if (!ctx || !out || (n_inputs > 0 && !inputs)) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  *out = nullptr;
+  KSH_TRY(check_geom(g));
+  if (n_inputs < 0 || n_ids < 0) return fail(KSH_INVALID_ARGUMENT, "negative count");
+  if (!canonical_flag) return fail(KSH_INVALID_ARGUMENT, "only canonical k-mer sets are supported");
+  KSH_HIP(hipSetDevice(ctx->device));
+  ksh_kss* k = new ksh_kss;
+  k->ctx = ctx;
+  k->g = *g;
+  k->canonical = canonical_flag;
+  std::vector<int32_t> ids(bucket_ids, bucket_ids + n_ids);
+  int rc = KSH_OK;
+  if (n_inputs > 0) rc = build(k, inputs, n_inputs, ids, max_iterations);
+  if (rc != KSH_OK) {
+    ksh_kss_destroy(k);
+    return rc;
+  }
+  *out = k;
+  return KSH_OK;
+}
+
+int ksh_kss_destroy(ksh_kss* k) {
+  if (!k) return KSH_OK;
+  (void)hipSetDevice(k->ctx->device);
+  (void)hipStreamSynchronize(k->ctx->stream);
+  for (KssSet& s : k->sets) free_set(&s);
+  for (KssCompact& c : k->compacts) free_compact(&c);
+  delete k;
+  return KSH_OK;
+}
+
+int ksh_kss_size(const ksh_kss* k, int32_t* n_nodes) {
+  if (!k || !n_nodes) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  *n_nodes = int32_t(k->compacts.size());
+  return KSH_OK;
+}
+
+int ksh_kss_node(const ksh_kss* k, int32_t i, ksh_spss_view* compact, ksh_set_view* set,
+                 int64_t* size) {
+  if (!k) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  if (i < 0 || size_t(i) >= k->compacts.size()) return fail(KSH_INVALID_ARGUMENT, "no node %d", i);
+  if (compact) *compact = view_of(k->compacts[i]);
+  if (set) *set = view_of(k->sets[i]);
+  if (size) *size = k->compacts[i].size;
+  return KSH_OK;
+}
+
+int ksh_kss_children(const ksh_kss* k, int32_t i, const int32_t** children, int32_t* n_children) {
+  if (!k || !children || !n_children) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  auto it = k->children.find(i);
+  if (it == k->children.end()) {
+    *children = nullptr;
+    *n_children = 0;
+  } else {
+    static_assert(sizeof(int) == sizeof(int32_t), "int is 32 bits");
+    *children = reinterpret_cast<const int32_t*>(it->second.data());
+    *n_children = int32_t(it->second.size());
+  }
+  return KSH_OK;
+}
+
+const char* ksh_kss_meta(const ksh_kss* k) { return k ? k->meta.c_str() : ""; }
+
+int ksh_kss_trace(const ksh_kss* k, int64_t* n_iterations, const int64_t** rows,
+                  int64_t* n_checkpoints, const int64_t** checkpoint_rows,
+                  const float** improvements) {
+  if (!k) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  if (n_iterations) *n_iterations = int64_t(k->trace.size() / 5);
+  if (rows) *rows = k->trace.data();
+  if (n_checkpoints) *n_checkpoints = int64_t(k->checkpoints.size() / 4);
+  if (checkpoint_rows) *checkpoint_rows = k->checkpoints.data();
+  if (improvements) *improvements = k->improvements.data();
+  return KSH_OK;
+}
+
+int ksh_kss_initial_weights(const ksh_kss* k, const int64_t** weights, int64_t* n) {
+  if (!k || !weights || !n) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  *weights = k->initial_weights.data();
+  *n = int64_t(k->initial_weights.size());
+  return KSH_OK;
+}
+
+int ksh_kss_stats(const ksh_kss* k, int64_t stats[8]) {
+  if (!k || !stats) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  stats[0] = k->initial_total_size;
+  stats[1] = k->final_total_size;
+  stats[2] = k->initial_spss_weight;
+  stats[3] = k->n_processed;
+  stats[4] = k->final_spss_weight;
+  int64_t bytes = 0, strings = 0;
+  for (const KssCompact& c : k->compacts) {
+    bytes += (2 * c.n_bases + 7) / 8;
+    strings += c.n_strings;
+  }
+  stats[5] = bytes;    // sum over nodes of ceil(2 * Weight / 8)
+  stats[6] = strings;  // sum over nodes of the string count (the lengths' side)
+  stats[7] = int64_t(k->compacts.size());
+  return KSH_OK;
+}
+
+// KmerSetSet::Get (kmer_set_set.h:433-454): BFS over children_, union of the reached nodes.
+// Returns freshly allocated device buffers (ksh_free them).
+int ksh_kss_get(const ksh_kss* k, int32_t i, int64_t** d_offsets, void** d_keys, int64_t* n_keys) {
+  if (!k || !d_offsets || !d_keys || !n_keys) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  if (i < 0 || size_t(i) >= k->sets.size()) return fail(KSH_INVALID_ARGUMENT, "no node %d", i);
+  ksh_ctx* ctx = k->ctx;
+  const ksh_geom* g = &k->g;
+  KSH_HIP(hipSetDevice(ctx->device));
+  const int64_t nb = n_buckets(g);
+  KssSet acc;
+  KSH_TRY(alloc_set(g, 0, &acc));
+  KSH_HIP(hipMemsetAsync(acc.off, 0, size_t(nb + 1) * 8, ctx->stream));
+  std::queue<int> queue;
+  queue.push(i);
+  while (!queue.empty()) {
+    const int current = queue.front();
+    queue.pop();
+    const ksh_set_view va = view_of(acc), vb = view_of(k->sets[current]);
+    KssSet next;
+    KSH_HIP(hipMalloc(reinterpret_cast<void**>(&next.off), size_t(nb + 1) * 8));
+    int64_t total = 0;
+    KSH_TRY(ksh_set_union_plan(ctx, g, &va, &vb, next.off, &total));
+    KSH_HIP(hipMalloc(&next.keys, std::max<size_t>(size_t(total) * g->key_bytes, 16)));
+    next.n = total;
+    KSH_TRY(ksh_set_union_write(ctx, g, &va, &vb, next.keys));
+    KSH_HIP(hipStreamSynchronize(ctx->stream));
+    free_set(&acc);
+    acc = next;
+    auto it = k->children.find(current);
+    if (it != k->children.end())
+      for (int child : it->second) queue.push(child);
+  }
+  *d_offsets = acc.off;
+  *d_keys = acc.keys;
+  *n_keys = acc.n;
+  return KSH_OK;
+}
+
+}  // extern "C"

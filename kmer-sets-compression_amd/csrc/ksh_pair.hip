@@ -148,10 +148,12 @@ __device__ inline uint64_t block_exclusive_scan_u64(uint64_t v, uint64_t* total,
 }
 
 // ---- the merge kernel ------------------------------------------------------------------------
-// kWrite == false: tile_m[t] = number of common keys in tile t.
-// kWrite == true : compacts the tile's A&B / A\B / B\A keys and writes them at
-//                  tile_ioff[t], tile_a[t] - tile_ioff[t], tile_b[t] - tile_ioff[t].
-template <typename KeyT, typename Segs, bool kWrite>
+// kMode == 0: tile_m[t] = number of common keys in tile t.
+// kMode == 1: compacts the tile's A&B / A\B / B\A keys and writes them at
+//             tile_ioff[t], tile_a[t] - tile_ioff[t], tile_b[t] - tile_ioff[t].
+// kMode == 2: writes the tile's A|B keys (merged order, common keys once) to out_i at
+//             tile_a[t] + tile_b[t] - tile_ioff[t]  (KmerSet::Add, kmer_set.h:164-174).
+template <typename KeyT, typename Segs, int kMode>
 __global__ __launch_bounds__(kThreads) void k_tile_merge(
     Segs segs, int64_t n_segs, const int64_t* __restrict__ tile_base,
     const int32_t* __restrict__ tile_seg, const int64_t* __restrict__ tile_a,
@@ -163,6 +165,7 @@ __global__ __launch_bounds__(kThreads) void k_tile_merge(
 
   const int64_t t = blockIdx.x;
   const int64_t total = tile_base[n_segs];
+  constexpr bool kWrite = kMode != 0;
   if (t >= total) {
     if (!kWrite && threadIdx.x == 0) tile_m[t] = 0;
     return;
@@ -234,6 +237,18 @@ __global__ __launch_bounds__(kThreads) void k_tile_merge(
   }
 
   // every thread has finished reading sa/sb (the scan's barrier): reuse the LDS
+  if (kMode == 2) {
+    int p_u = int(excl & 0xFFFFF) + int((excl >> 20) & 0xFFFFF) + int(excl >> 40);
+    __syncthreads();
+#pragma unroll
+    for (int step = 0; step < kVT; step++)
+      if (cls[step] != 3) lds[p_u++] = vals[step];
+    __syncthreads();
+    const int tot_u = tot_i + tot_a + tot_b;
+    KeyT* o = out_i + (a0 + b0 - tile_ioff[t]);
+    for (int x = threadIdx.x; x < tot_u; x += kThreads) o[x] = lds[x];
+    return;
+  }
   int p_i = int(excl & 0xFFFFF);
   int p_a = tot_i + int((excl >> 20) & 0xFFFFF);
   int p_b = tot_i + tot_a + int(excl >> 40);
@@ -350,7 +365,7 @@ int plan_count(ksh_ctx* ctx, const Segs& segs, const Plan& p, int timer_kind) {
                      ctx->stream, segs, p.n_segs, p.tile_base, p.tile_seg, p.tile_a, p.tile_b);
   {
     Timer timer(ctx, timer_kind);
-    hipLaunchKernelGGL((k_tile_merge<KeyT, Segs, false>), dim3(unsigned(p.max_tiles)),
+    hipLaunchKernelGGL((k_tile_merge<KeyT, Segs, 0>), dim3(unsigned(p.max_tiles)),
                        dim3(kThreads), 0, ctx->stream, segs, p.n_segs, p.tile_base, p.tile_seg,
                        p.tile_a, p.tile_b, p.tile_ioff, nullptr, nullptr, nullptr, nullptr);
   }
@@ -416,11 +431,75 @@ int pair_write_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const k
                         static_cast<const KeyT*>(b->d_keys), b->d_offsets};
   {
     Timer timer(ctx, 0);
-    hipLaunchKernelGGL((k_tile_merge<KeyT, BucketSegs<KeyT>, true>), dim3(unsigned(p.max_tiles)),
+    hipLaunchKernelGGL((k_tile_merge<KeyT, BucketSegs<KeyT>, 1>), dim3(unsigned(p.max_tiles)),
                        dim3(kThreads), 0, ctx->stream, segs, p.n_segs, p.tile_base, p.tile_seg,
                        p.tile_a, p.tile_b, nullptr, p.tile_ioff, static_cast<KeyT*>(d_keys_i),
                        static_cast<KeyT*>(d_keys_amb), static_cast<KeyT*>(d_keys_bma));
   }
+  KSH_HIP(hipGetLastError());
+  return KSH_OK;
+}
+
+// A | B in two calls like the pair plan: offsets + total first, keys second.
+__global__ __launch_bounds__(256) void k_union_offsets(
+    const int64_t* __restrict__ a_off, const int64_t* __restrict__ b_off,
+    const int64_t* __restrict__ tile_base, const int64_t* __restrict__ tile_ioff,
+    const int64_t* __restrict__ total_m, int64_t n_buckets, int64_t* __restrict__ off_u,
+    int64_t* __restrict__ total_u) {
+  const int64_t s = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (s > n_buckets) return;
+  const int64_t total_tiles = tile_base[n_buckets];
+  const int64_t first = tile_base[s];
+  const int64_t m = first < total_tiles ? tile_ioff[first] : *total_m;
+  off_u[s] = a_off[s] + b_off[s] - m;
+  if (s == n_buckets) *total_u = a_off[s] + b_off[s] - m;
+}
+
+template <typename KeyT>
+int union_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
+                 int64_t* d_off_u, int64_t* total) {
+  const int64_t nb = n_buckets(g);
+  const int64_t max_tiles = nb + (a->n_keys + b->n_keys) / kTile + 1;
+  if (max_tiles > int64_t(0x7FFFFFF0)) return fail(KSH_INVALID_ARGUMENT, "pair too large for one launch");
+  KSH_TRY(plan_reserve(ctx, plan_bytes(nb, max_tiles)));
+  KSH_TRY(arena_reserve(ctx, size_t(max_tiles / 256 + 4096) * 8 + (1u << 16)));
+  arena_reset(ctx);
+  Plan p;
+  plan_carve(ctx->plan, nb, max_tiles, &p);
+  BucketSegs<KeyT> segs{static_cast<const KeyT*>(a->d_keys), a->d_offsets,
+                        static_cast<const KeyT*>(b->d_keys), b->d_offsets};
+  KSH_TRY((plan_tile_base<KeyT>(ctx, segs, nb, p.tile_base)));
+  KSH_TRY((plan_count<KeyT>(ctx, segs, p, 1)));
+  int64_t* d_total = static_cast<int64_t*>(arena_alloc(ctx, sizeof(int64_t)));
+  if (!d_total) return fail(KSH_INTERNAL, "scratch arena too small");
+  hipLaunchKernelGGL(k_union_offsets, dim3(blocks_for(nb + 1, 256)), dim3(256), 0, ctx->stream,
+                     a->d_offsets, b->d_offsets, p.tile_base, p.tile_ioff, p.total_m, nb, d_off_u,
+                     d_total);
+  KSH_HIP(hipGetLastError());
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, d_total, sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  *total = ctx->h_pinned[0];
+  ctx->plan_tiles = max_tiles;
+  ctx->plan_buckets = nb;
+  ctx->plan_a_keys = a->d_keys;
+  ctx->plan_b_keys = b->d_keys;
+  return KSH_OK;
+}
+
+template <typename KeyT>
+int union_write_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
+                  void* d_keys_u) {
+  const int64_t nb = n_buckets(g);
+  if (!ctx->plan || ctx->plan_buckets != nb || ctx->plan_a_keys != a->d_keys ||
+      ctx->plan_b_keys != b->d_keys)
+    return fail(KSH_FAILED_PRECONDITION, "ksh_set_union_write without a matching ksh_set_union_plan");
+  Plan p;
+  plan_carve(ctx->plan, nb, ctx->plan_tiles, &p);
+  BucketSegs<KeyT> segs{static_cast<const KeyT*>(a->d_keys), a->d_offsets,
+                        static_cast<const KeyT*>(b->d_keys), b->d_offsets};
+  hipLaunchKernelGGL((k_tile_merge<KeyT, BucketSegs<KeyT>, 2>), dim3(unsigned(p.max_tiles)),
+                     dim3(kThreads), 0, ctx->stream, segs, p.n_segs, p.tile_base, p.tile_seg, p.tile_a,
+                     p.tile_b, nullptr, p.tile_ioff, static_cast<KeyT*>(d_keys_u), nullptr, nullptr);
   KSH_HIP(hipGetLastError());
   return KSH_OK;
 }
@@ -532,6 +611,28 @@ int ksh_pair_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const
   KSH_HIP(hipSetDevice(ctx->device));
   return g->key_bytes == 4 ? pair_write_t<uint32_t>(ctx, g, a, b, d_keys_i, d_keys_amb, d_keys_bma)
                            : pair_write_t<uint64_t>(ctx, g, a, b, d_keys_i, d_keys_amb, d_keys_bma);
+}
+
+int ksh_set_union_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a,
+                       const ksh_set_view* b, int64_t* d_off_u, int64_t* total) {
+  if (!ctx || !d_off_u || !total) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  KSH_TRY(check_geom(g));
+  KSH_TRY(check_view(a, "a"));
+  KSH_TRY(check_view(b, "b"));
+  KSH_HIP(hipSetDevice(ctx->device));
+  return g->key_bytes == 4 ? union_plan_t<uint32_t>(ctx, g, a, b, d_off_u, total)
+                           : union_plan_t<uint64_t>(ctx, g, a, b, d_off_u, total);
+}
+
+int ksh_set_union_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a,
+                        const ksh_set_view* b, void* d_keys_u) {
+  if (!ctx) return fail(KSH_INVALID_ARGUMENT, "ctx is NULL");
+  KSH_TRY(check_geom(g));
+  KSH_TRY(check_view(a, "a"));
+  KSH_TRY(check_view(b, "b"));
+  KSH_HIP(hipSetDevice(ctx->device));
+  return g->key_bytes == 4 ? union_write_t<uint32_t>(ctx, g, a, b, d_keys_u)
+                           : union_write_t<uint64_t>(ctx, g, a, b, d_keys_u);
 }
 
 int ksh_set_diff(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,

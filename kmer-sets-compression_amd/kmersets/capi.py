@@ -96,6 +96,20 @@ def lib():
         "ksh_spss_encode_write": (C.c_int, [vp, vp, vp]),
         "ksh_spss_encode_stats": (C.c_int, [vp, C.POINTER(i64)]),
         "ksh_spss_encode_release": (C.c_int, [vp]),
+        "ksh_set_union_plan": (C.c_int, [vp, GP, SP, SP, vp, C.POINTER(i64)]),
+        "ksh_set_union_write": (C.c_int, [vp, GP, SP, SP, vp]),
+        "ksh_kss_build": (C.c_int, [vp, GP, C.POINTER(SpssView), i32, C.POINTER(i32), i32, C.c_int,
+                                    i32, C.POINTER(vp)]),
+        "ksh_kss_destroy": (C.c_int, [vp]),
+        "ksh_kss_size": (C.c_int, [vp, C.POINTER(i32)]),
+        "ksh_kss_node": (C.c_int, [vp, i32, C.POINTER(SpssView), SP, C.POINTER(i64)]),
+        "ksh_kss_children": (C.c_int, [vp, i32, C.POINTER(C.POINTER(i32)), C.POINTER(i32)]),
+        "ksh_kss_meta": (C.c_char_p, [vp]),
+        "ksh_kss_trace": (C.c_int, [vp, C.POINTER(i64), C.POINTER(C.POINTER(i64)), C.POINTER(i64),
+                                    C.POINTER(C.POINTER(i64)), C.POINTER(C.POINTER(C.c_float))]),
+        "ksh_kss_initial_weights": (C.c_int, [vp, C.POINTER(C.POINTER(i64)), C.POINTER(i64)]),
+        "ksh_kss_stats": (C.c_int, [vp, C.POINTER(i64)]),
+        "ksh_kss_get": (C.c_int, [vp, i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(i64)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -210,18 +224,22 @@ class DeviceSpss:
 
 
 class Context:
-    """ksh_ctx on one GPU, bound to torch's current stream on that device."""
+    """ksh_ctx on one GPU; its stream becomes torch's current stream on that device."""
 
-    def __init__(self, device_index=0, use_torch_stream=True):
+    def __init__(self, device_index=0):
         import torch
 
         if not torch.cuda.is_available():
             raise RuntimeError("no GPU visible: the k-mer set hot path has no CPU fallback")
         self.device = torch.device("cuda", device_index)
         torch.cuda.set_device(self.device)
-        stream = torch.cuda.current_stream(self.device).cuda_stream if use_torch_stream else 0
+        # One stream for everything: the library's kernels and torch's copies/allocations
+        # are ordered against each other only if they share a stream (torch's default
+        # stream has handle 0, which the C ABI reads as "make me a stream").
+        self.stream = torch.cuda.Stream(device=self.device)
+        torch.cuda.set_stream(self.stream)
         h = C.c_void_p()
-        check(lib().ksh_ctx_create(device_index, C.c_void_p(stream), C.byref(h)))
+        check(lib().ksh_ctx_create(device_index, C.c_void_p(self.stream.cuda_stream), C.byref(h)))
         self.h = h
 
     def close(self):
@@ -324,6 +342,22 @@ class Context:
         check(lib().ksh_spss_encode_stats(self.h, st))
         return {"unitigs": st[0], "rounds": st[1], "strings": st[2], "bases": st[3]}
 
+    def set_union(self, a, b):
+        """KmerSet::Add: A | B as a new DeviceSet."""
+        import torch
+
+        g = a.g
+        out = DeviceSet.empty_like_offsets(g, 0, self.device)
+        total = C.c_int64()
+        va, vb = a.view(), b.view()
+        check(lib().ksh_set_union_plan(self.h, C.byref(g), C.byref(va), C.byref(vb),
+                                       out.offsets.data_ptr(), C.byref(total)))
+        out.n_keys = total.value
+        out.keys = torch.empty(max(total.value * g.key_bytes, 16), dtype=torch.uint8, device=self.device)
+        check(lib().ksh_set_union_write(self.h, C.byref(g), C.byref(va), C.byref(vb),
+                                        out.keys.data_ptr()))
+        return out
+
     def set_diff(self, a, b):
         out = C.c_int64()
         va, vb = a.view(), b.view()
@@ -343,3 +377,112 @@ class Context:
             prs.ctypes.data_as(C.POINTER(C.c_int32)), n_pairs,
             out.ctypes.data_as(C.POINTER(C.c_int64))))
         return out[:n_pairs]
+
+
+class DeviceKmerSetSet:
+    """ksh_kss: KmerSetSet built on device (lib/core/kmer_set_set.h:109-427)."""
+
+    def __init__(self, ctx, compacts, bucket_ids, canonical=True, max_iterations=-1):
+        self.ctx, self.g, self.inputs = ctx, compacts[0].g, list(compacts)
+        views = (SpssView * len(compacts))(*[c.view() for c in compacts])
+        ids = np.ascontiguousarray(bucket_ids, dtype=np.int32)
+        h = C.c_void_p()
+        check(lib().ksh_kss_build(ctx.h, C.byref(self.g), views, len(compacts),
+                                  ids.ctypes.data_as(C.POINTER(C.c_int32)), ids.size, int(canonical),
+                                  max_iterations, C.byref(h)))
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ksh_kss_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def size(self):
+        n = C.c_int32()
+        check(lib().ksh_kss_size(self.h, C.byref(n)))
+        return n.value
+
+    def node_strings(self, i):
+        """SPSS strings of node i (downloaded)."""
+        from . import synth
+
+        sv = SpssView()
+        check(lib().ksh_kss_node(self.h, i, C.byref(sv), None, None))
+        n_words = (sv.n_bases + 31) // 32
+        words = np.zeros(max(n_words, 1), dtype=np.uint64)
+        lens = np.zeros(max(sv.n_strings, 1), dtype=np.uint32)
+        dev = self.ctx.device.index
+        if n_words:
+            check(lib().ksh_memcpy_d2h(dev, words.ctypes.data_as(C.c_void_p), sv.d_words, n_words * 8))
+        if sv.n_strings:
+            check(lib().ksh_memcpy_d2h(dev, lens.ctypes.data_as(C.c_void_p), sv.d_lens, sv.n_strings * 4))
+        return synth.unpack_strings(words[:n_words], lens[: sv.n_strings], self.g.k)
+
+    def node_size(self, i):
+        n = C.c_int64()
+        check(lib().ksh_kss_node(self.h, i, None, None, C.byref(n)))
+        return n.value
+
+    def node_kmers(self, i):
+        from . import synth
+
+        v = SetView()
+        check(lib().ksh_kss_node(self.h, i, None, C.byref(v), None))
+        return self._download_set(v.d_offsets, v.d_keys, v.n_keys)
+
+    def _download_set(self, d_off, d_keys, n_keys):
+        from . import synth
+
+        g = self.g
+        nb = 1 << g.n_bucket_bits
+        off = np.zeros(nb + 1, dtype=np.int64)
+        kdt = np.uint32 if g.key_bytes == 4 else np.uint64
+        keys = np.zeros(max(n_keys, 1), dtype=kdt)
+        dev = self.ctx.device.index
+        check(lib().ksh_memcpy_d2h(dev, off.ctypes.data_as(C.c_void_p), d_off, (nb + 1) * 8))
+        if n_keys:
+            check(lib().ksh_memcpy_d2h(dev, keys.ctypes.data_as(C.c_void_p), d_keys, n_keys * g.key_bytes))
+        return synth.from_bucketed(off, keys[:n_keys], g.k, g.n_bucket_bits)
+
+    def children(self, i):
+        p, n = C.POINTER(C.c_int32)(), C.c_int32()
+        check(lib().ksh_kss_children(self.h, i, C.byref(p), C.byref(n)))
+        return [p[j] for j in range(n.value)]
+
+    def meta(self):
+        return lib().ksh_kss_meta(self.h).decode()
+
+    def trace(self):
+        ni, nc = C.c_int64(), C.c_int64()
+        rows, crows, imp = C.POINTER(C.c_int64)(), C.POINTER(C.c_int64)(), C.POINTER(C.c_float)()
+        check(lib().ksh_kss_trace(self.h, C.byref(ni), C.byref(rows), C.byref(nc), C.byref(crows),
+                                  C.byref(imp)))
+        it = np.array([rows[i] for i in range(5 * ni.value)], dtype=np.int64).reshape(-1, 5)
+        cp = np.array([crows[i] for i in range(4 * nc.value)], dtype=np.int64).reshape(-1, 4)
+        im = np.array([imp[i] for i in range(nc.value)], dtype=np.float32)
+        return it, cp, im
+
+    def initial_weights(self):
+        p, n = C.POINTER(C.c_int64)(), C.c_int64()
+        check(lib().ksh_kss_initial_weights(self.h, C.byref(p), C.byref(n)))
+        return np.array([p[i] for i in range(n.value)], dtype=np.int64)
+
+    def stats(self):
+        st = (C.c_int64 * 8)()
+        check(lib().ksh_kss_stats(self.h, st))
+        keys = ["initial_total_size", "final_total_size", "initial_spss_weight", "n_processed",
+                "final_spss_weight", "packed_bytes", "strings", "nodes"]
+        return dict(zip(keys, [int(x) for x in st]))
+
+    def get_kmers(self, i):
+        """KmerSetSet::Get(i) as a sorted uint64 array (downloaded)."""
+        d_off, d_keys, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(lib().ksh_kss_get(self.h, i, C.byref(d_off), C.byref(d_keys), C.byref(n)))
+        try:
+            return self._download_set(d_off, d_keys, n.value)
+        finally:
+            dev = self.ctx.device.index
+            lib().ksh_free(dev, d_off)
+            lib().ksh_free(dev, d_keys)

@@ -1,0 +1,96 @@
+"""GPU parity tests for the set-of-sets loop (lib/core/kmer_set_set.h:109-454) through
+the C ABI: merge trace, convergence checkpoints, DAG, every node's SPSS strings and
+Get(i) must equal the oracle's on the same seeded family."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from kmersets import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(gpu):
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def build_both(ctx, k, n, kb, n_sets, size, seed, max_iterations=-1):
+    sets = synth.phylogeny_sets(k, n_sets, size, seed=seed)
+    osets = [ol.Set.from_kmers(k, n, kb, s) for s in sets]
+    ocompacts = [s.compact() for s in osets]
+    ids = synth.sample_bucket_ids(n, seed=seed + 1)
+    okss = ol.KmerSetSet(ocompacts, ids, max_iterations=max_iterations)
+    g = capi.geom(k, n)
+    dcompacts = [capi.DeviceSpss.from_strings(g, c.strings(), ctx.device) for c in ocompacts]
+    dkss = capi.DeviceKmerSetSet(ctx, dcompacts, ids, max_iterations=max_iterations)
+    return sets, osets, okss, dkss
+
+
+def compare(sets, osets, okss, dkss):
+    n0 = len(sets)
+    assert np.array_equal(dkss.initial_weights(), okss.initial_weights(n0))
+    it, cp, imp = dkss.trace()
+    assert np.array_equal(it, okss.iterations())
+    ocp, oimp = okss.checkpoints()
+    assert np.array_equal(cp, ocp)
+    assert np.array_equal(imp, oimp)            # same float arithmetic, bit for bit
+    assert dkss.size() == okss.size()
+    assert dkss.meta() == okss.meta()
+    st = dkss.stats()
+    assert st["initial_total_size"] == okss.stat(0) and st["final_total_size"] == okss.stat(1)
+    assert st["initial_spss_weight"] == okss.stat(2) and st["n_processed"] == okss.stat(3)
+    for i in range(okss.size()):
+        node = okss.node(i)
+        assert dkss.node_strings(i) == node.strings(), "node %d" % i
+        assert dkss.node_size(i) == node.size()
+    for i in range(n0):
+        got = dkss.get_kmers(i)
+        assert np.array_equal(got, sets[i])      # test/kmer_set_set.cc:30-34
+        assert np.array_equal(got, okss.get(i).kmers())
+    return len(it)
+
+
+@pytest.mark.parametrize("case", [(9, 10, 1, 6, 3000, 11), (15, 14, 2, 8, 20000, 3),
+                                  (23, 14, 4, 8, 30000, 5), (31, 14, 8, 4, 20000, 7)])
+def test_loop_vs_oracle(ctx, case):
+    k, n, kb, n_sets, size, seed = case
+    sets, osets, okss, dkss = build_both(ctx, k, n, kb, n_sets, size, seed)
+    merges = compare(sets, osets, okss, dkss)
+    if k >= 15:
+        assert merges > 0, "a correlated family must merge"
+    dkss.close()
+
+
+def test_loop_truncated_and_no_merge(ctx):
+    k, n, kb = 23, 14, 4
+    sets, osets, okss, dkss = build_both(ctx, k, n, kb, 6, 20000, 9, max_iterations=2)
+    assert compare(sets, osets, okss, dkss) == 2
+    dkss.close()
+    # independent random sets share nothing: the loop stops at weight == 0 (kmer_set_set.h:319-322)
+    g = capi.geom(k, n)
+    ids = synth.sample_bucket_ids(n, seed=3)
+    a, b = synth.uniform_pair(k, 20000, 0.0, seed=5)
+    comp = [capi.DeviceSpss.from_strings(g, ol.Set.from_kmers(k, n, kb, s).spss(), ctx.device) for s in (a, b)]
+    d = capi.DeviceKmerSetSet(ctx, comp, ids)
+    assert d.size() == 2 and d.trace()[0].shape[0] == 0
+    d.close()
+
+
+def test_set_union(ctx):
+    k, n = 23, 14
+    sets = synth.phylogeny_sets(k, 2, 50000, seed=4)
+    g = capi.geom(k, n)
+    a = capi.DeviceSet.from_kmers(g, sets[0], ctx.device)
+    b = capi.DeviceSet.from_kmers(g, sets[1], ctx.device)
+    u = ctx.set_union(a, b)
+    want = np.union1d(sets[0], sets[1])
+    assert u.n_keys == want.size and np.array_equal(u.kmers(), want)
+    off, keys = u.to_numpy()
+    w_off, w_keys = synth.to_bucketed(want, k, n, 4)
+    assert np.array_equal(off, w_off) and np.array_equal(keys, w_keys)
+    e = capi.DeviceSet.from_kmers(g, np.zeros(0, dtype=np.uint64), ctx.device)
+    assert np.array_equal(ctx.set_union(e, a).kmers(), sets[0])
+    assert np.array_equal(ctx.set_union(a, a).kmers(), sets[0])

@@ -184,3 +184,18 @@ def test_config2_properties(ctx):
                 assert bool(torch.all(km[1:] > km[:-1]))
             # exact membership against numpy on this pair
             assert np.array_equal(inter.kmers(), np.intersect1d(sets[i], sets[j]))
+
+
+def test_device_generator_matches_host(ctx):
+    """bench.py builds its large inputs on the GPU; same sets as the numpy generator."""
+    from kmersets import synth_torch
+
+    for k, n in ((23, 14), (31, 14), (15, 14)):
+        host = synth.phylogeny_sets(k, 4, 20000, seed=6)
+        dev = synth_torch.phylogeny_sets(k, 4, 20000, seed=6, device=ctx.device)
+        g = capi.geom(k, n)
+        for h, d in zip(host, dev):
+            assert np.array_equal(d.cpu().numpy().astype(np.uint64), h)
+            ds = synth_torch.device_set(g, d)
+            assert ds.n_keys == h.size and np.array_equal(ds.kmers(), h)
+            assert ctx.set_hash(ds) == int(np.bitwise_xor.reduce(h))

@@ -106,6 +106,14 @@ int ksh_pair_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const 
 int ksh_pair_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
                    void* d_keys_i, void* d_keys_amb, void* d_keys_bma);
 
+/* Both passes in ONE call, enqueued back to back (one stream synchronisation, for the
+ * totals, and no allocation between the passes).  The key buffers are allocated by the
+ * caller before the sizes are known: d_keys_i >= min(|A|, |B|) keys, d_keys_amb >= |A|,
+ * d_keys_bma >= |B|. */
+int ksh_pair_algebra(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
+                     int64_t* d_off_i, int64_t* d_off_amb, int64_t* d_off_bma, void* d_keys_i,
+                     void* d_keys_amb, void* d_keys_bma, int64_t totals[3]);
+
 /* KmerSet::Add(other) / free Add (lib/core/kmer_set.h:164-174,286-290): A | B, same
  * two-call shape.  d_off_u is int64[2^N + 1]; d_keys_u holds `total` keys. */
 int ksh_set_union_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a,

@@ -170,10 +170,45 @@ __global__ void k_store_total(const int64_t* __restrict__ block_prefix_last,
   *total = *block_prefix_last + *block_sums_last;
 }
 
+// Small inputs (bucket counts, tile counts): one 1024-thread workgroup, one launch.
+constexpr int64_t kScanSmallMax = 1 << 17;
+
+__global__ __launch_bounds__(1024) void k_scan_small(const int64_t* __restrict__ in,
+                                                      int64_t* __restrict__ out, int64_t n,
+                                                      int64_t* __restrict__ total_out) {
+  __shared__ int64_t wave_sums[16];
+  const int tid = threadIdx.x;
+  const int64_t per = (n + 1023) / 1024;
+  const int64_t lo = min(int64_t(tid) * per, n), hi = min(lo + per, n);
+  int64_t mine = 0;
+  for (int64_t i = lo; i < hi; i++) mine += in[i];
+  int64_t inc = wave_inclusive_scan(mine);
+  const int lane = tid & 63, wave = tid >> 6;
+  if (lane == 63) wave_sums[wave] = inc;
+  __syncthreads();
+  int64_t base = 0, total = 0;
+  for (int w = 0; w < 16; w++) {
+    if (w < wave) base += wave_sums[w];
+    total += wave_sums[w];
+  }
+  int64_t run = base + inc - mine;
+  for (int64_t i = lo; i < hi; i++) {
+    const int64_t v = in[i];
+    out[i] = run;
+    run += v;
+  }
+  if (tid == 0 && total_out) *total_out = total;
+}
+
 int scan_exclusive_i64(ksh_ctx* ctx, const int64_t* d_in, int64_t* d_out, int64_t n,
                        int64_t* d_total) {
   if (n <= 0) {
     if (d_total) KSH_HIP(hipMemsetAsync(d_total, 0, sizeof(int64_t), ctx->stream));
+    return KSH_OK;
+  }
+  if (n <= kScanSmallMax) {
+    hipLaunchKernelGGL(k_scan_small, dim3(1), dim3(1024), 0, ctx->stream, d_in, d_out, n, d_total);
+    KSH_HIP(hipGetLastError());
     return KSH_OK;
   }
   const int64_t blocks = (n + kScanTile - 1) / kScanTile;

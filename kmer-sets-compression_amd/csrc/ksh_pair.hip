@@ -6,9 +6,9 @@
 // A set is one ascending array of k-mers with a bucket index, so every one of
 // these is a merge of two sorted ranges per bucket.  The work is cut into
 // *segments* (one per bucket of a pair, or one per (pair, sampled bucket)) and each
-// segment into *tiles* of at most kTileCap merged keys by merge-path; a workgroup
-// of 256 threads stages one tile's two key ranges in LDS with coalesced loads,
-// every thread merges kVT keys from LDS, and the three result streams are
+// segment into *tiles* of at most kTileCap (1024) merged keys by merge-path; one
+// wavefront per tile stages the tile's two key ranges in LDS with 16-byte coalesced
+// loads, every lane merges kVT (16) keys from LDS, and the three result streams are
 // compacted in LDS and written back coalesced.  HBM-bound integer work; no MFMA.
 //
 // Tie rule: on equal keys the A key is merged first, so a common key shows up as
@@ -22,8 +22,12 @@
 
 namespace ksh {
 
-constexpr int kThreads = 256;
-constexpr int kVT = 8;                     // merged keys per thread
+// One wavefront per tile: 64 lanes x 16 keys.  Tiles are bounded by buckets (about 1.2 k
+// merged keys per bucket at 10^7 keys per set), so the kernel is latency-bound per tile;
+// single-wave workgroups put 4x more tiles in flight per CU than 256-thread ones and need
+// no cross-wave scan.
+constexpr int kThreads = 64;
+constexpr int kVT = 16;                    // merged keys per lane
 constexpr int kTile = kThreads * kVT - 1;  // diagonal spacing (the +1 is the tie fix-up)
 constexpr int kTileCap = kThreads * kVT;   // LDS capacity in keys
 
@@ -73,6 +77,15 @@ struct PairSegs {
   }
 };
 
+// Everything a tile needs, in one 40-byte record (one dependent load in the merge kernel).
+struct TileDesc {
+  const void* pa;  // first A key of the tile
+  const void* pb;  // first B key of the tile
+  int64_t a0;      // its index in A's key array
+  int64_t b0;
+  int32_t ca, cb;  // keys of A / B in the tile
+};
+
 // ---- tile plan --------------------------------------------------------------------------
 template <typename KeyT, typename Segs>
 __global__ __launch_bounds__(256) void k_seg_tiles(Segs segs, int64_t n_segs,
@@ -86,13 +99,29 @@ __global__ __launch_bounds__(256) void k_seg_tiles(Segs segs, int64_t n_segs,
   tiles_per_seg[s] = (len + kTile - 1) / kTile;
 }
 
-// One thread per tile: which segment, and where the tile starts in A and in B.
+// Merge-path split of (a[0, na), b[0, nb)) at `diag` (A first on ties); a common key's
+// "a, b" pair is never separated: the B side moves by one when the split falls inside it.
+template <typename KeyT>
+__device__ __forceinline__ void merge_path_split(const KeyT* __restrict__ a, int64_t na,
+                                                 const KeyT* __restrict__ b, int64_t nb,
+                                                 int64_t diag, int64_t* i_out, int64_t* j_out) {
+  int64_t lo = diag > nb ? diag - nb : 0;
+  int64_t hi = diag < na ? diag : na;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (a[mid] <= b[diag - 1 - mid]) lo = mid + 1; else hi = mid;
+  }
+  int64_t i = lo, j = diag - lo;
+  if (i > 0 && j < nb && a[i - 1] == b[j]) j += 1;
+  *i_out = i;
+  *j_out = j;
+}
+
+// One thread per tile: which segment, where the tile starts and ends in A and in B.
 template <typename KeyT, typename Segs>
 __global__ __launch_bounds__(256) void k_tile_split(Segs segs, int64_t n_segs,
                                                      const int64_t* __restrict__ tile_base,
-                                                     int32_t* __restrict__ tile_seg,
-                                                     int64_t* __restrict__ tile_a,
-                                                     int64_t* __restrict__ tile_b) {
+                                                     TileDesc* __restrict__ desc) {
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const int64_t total = tile_base[n_segs];
   if (t >= total) return;
@@ -108,89 +137,79 @@ __global__ __launch_bounds__(256) void k_tile_split(Segs segs, int64_t n_segs,
   segs.get(s, a, a_lo, a_hi, b, b_lo, b_hi);
   const int64_t na = a_hi - a_lo, nb = b_hi - b_lo;
   const int64_t diag = (t - tile_base[s]) * kTile;
-  int64_t i_lo = diag > nb ? diag - nb : 0;
-  int64_t i_hi = diag < na ? diag : na;
-  while (i_lo < i_hi) {
-    const int64_t mid = (i_lo + i_hi) >> 1;
-    if (a[a_lo + mid] <= b[b_lo + diag - 1 - mid]) i_lo = mid + 1; else i_hi = mid;
-  }
-  int64_t i = i_lo, j = diag - i_lo;
-  if (i > 0 && j < nb && a[a_lo + i - 1] == b[b_lo + j]) j += 1;  // keep a common key's pair together
-  tile_seg[t] = int32_t(s);
-  tile_a[t] = a_lo + i;
-  tile_b[t] = b_lo + j;
+  int64_t i0, j0, i1 = na, j1 = nb;
+  merge_path_split(a + a_lo, na, b + b_lo, nb, diag, &i0, &j0);
+  if (diag + kTile < na + nb) merge_path_split(a + a_lo, na, b + b_lo, nb, diag + kTile, &i1, &j1);
+  TileDesc d;
+  d.pa = a + a_lo + i0;
+  d.pb = b + b_lo + j0;
+  d.a0 = a_lo + i0;
+  d.b0 = b_lo + j0;
+  d.ca = int32_t(i1 - i0);
+  d.cb = int32_t(j1 - j0);
+  desc[t] = d;
 }
 
-// ---- block helpers ----------------------------------------------------------------------------
-__device__ inline uint64_t wave_inclusive_scan_u64(uint64_t v) {
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    uint64_t o = __shfl_up(v, d, 64);
-    if (lane >= d) v += o;
+// Coalesced staging of src[0, cnt) into LDS by one wave: 16-byte global loads on the
+// aligned interior, scalar loads on the ragged ends.
+template <typename KeyT>
+__device__ __forceinline__ void stage(const KeyT* __restrict__ src, int cnt, KeyT* __restrict__ dst) {
+  constexpr int kPer = 16 / int(sizeof(KeyT));
+  const int mis = int((reinterpret_cast<uintptr_t>(src) / sizeof(KeyT)) & (kPer - 1));
+  const int head = (kPer - mis) & (kPer - 1);
+  const int h = head < cnt ? head : cnt;
+  if (int(threadIdx.x) < h) dst[threadIdx.x] = src[threadIdx.x];
+  const int n_vec = (cnt - h) / kPer;
+  using Vec = typename std::conditional<sizeof(KeyT) == 4, uint4, ulonglong2>::type;
+  const Vec* vp = reinterpret_cast<const Vec*>(src + h);
+  for (int v = threadIdx.x; v < n_vec; v += kThreads) {
+    const Vec x = vp[v];
+    KeyT* d = dst + h + v * kPer;
+    if constexpr (sizeof(KeyT) == 4) {
+      d[0] = x.x;
+      d[1] = x.y;
+      d[2] = x.z;
+      d[3] = x.w;
+    } else {
+      d[0] = x.x;
+      d[1] = x.y;
+    }
   }
-  return v;
-}
-
-// Exclusive scan of one packed value per thread; returns the exclusive prefix and
-// the block total.  lds4 = 4 uint64 of scratch.
-__device__ inline uint64_t block_exclusive_scan_u64(uint64_t v, uint64_t* total, uint64_t* lds4) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const uint64_t inc = wave_inclusive_scan_u64(v);
-  if (lane == 63) lds4[wave] = inc;
-  __syncthreads();
-  uint64_t base = 0;
-#pragma unroll
-  for (int w = 0; w < kThreads / 64; w++)
-    if (w < wave) base += lds4[w];
-  *total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
-  return base + inc - v;
+  const int done = h + n_vec * kPer;
+  if (int(threadIdx.x) < cnt - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
 }
 
 // ---- the merge kernel ------------------------------------------------------------------------
 // kMode == 0: tile_m[t] = number of common keys in tile t.
 // kMode == 1: compacts the tile's A&B / A\B / B\A keys and writes them at
-//             tile_ioff[t], tile_a[t] - tile_ioff[t], tile_b[t] - tile_ioff[t].
+//             tile_ioff[t], a0 - tile_ioff[t], b0 - tile_ioff[t].
 // kMode == 2: writes the tile's A|B keys (merged order, common keys once) to out_i at
-//             tile_a[t] + tile_b[t] - tile_ioff[t]  (KmerSet::Add, kmer_set.h:164-174).
-template <typename KeyT, typename Segs, int kMode>
+//             a0 + b0 - tile_ioff[t]  (KmerSet::Add, kmer_set.h:164-174).
+template <typename KeyT, int kMode>
 __global__ __launch_bounds__(kThreads) void k_tile_merge(
-    Segs segs, int64_t n_segs, const int64_t* __restrict__ tile_base,
-    const int32_t* __restrict__ tile_seg, const int64_t* __restrict__ tile_a,
-    const int64_t* __restrict__ tile_b, int64_t* __restrict__ tile_m,
-    const int64_t* __restrict__ tile_ioff, KeyT* __restrict__ out_i, KeyT* __restrict__ out_amb,
-    KeyT* __restrict__ out_bma) {
+    const TileDesc* __restrict__ desc, const int64_t* __restrict__ total_tiles,
+    int64_t* __restrict__ tile_m, const int64_t* __restrict__ tile_ioff, KeyT* __restrict__ out_i,
+    KeyT* __restrict__ out_amb, KeyT* __restrict__ out_bma) {
   __shared__ KeyT lds[kTileCap];
-  __shared__ uint64_t lds4[4];
 
   const int64_t t = blockIdx.x;
-  const int64_t total = tile_base[n_segs];
   constexpr bool kWrite = kMode != 0;
-  if (t >= total) {
+  if (t >= *total_tiles) {
     if (!kWrite && threadIdx.x == 0) tile_m[t] = 0;
     return;
   }
-  const int64_t s = tile_seg[t];
-  const KeyT *a, *b;
-  int64_t a_lo, a_hi, b_lo, b_hi;
-  segs.get(s, a, a_lo, a_hi, b, b_lo, b_hi);
-  const int64_t a0 = tile_a[t], b0 = tile_b[t];
-  int64_t a1 = a_hi, b1 = b_hi;
-  if (t + 1 < total && tile_seg[t + 1] == s) {
-    a1 = tile_a[t + 1];
-    b1 = tile_b[t + 1];
-  }
-  const int ca = int(a1 - a0), cb = int(b1 - b0);
+  const TileDesc d = desc[t];
+  const int ca = d.ca, cb = d.cb;
   KeyT* sa = lds;
   KeyT* sb = lds + ca;
-  for (int x = threadIdx.x; x < ca; x += kThreads) sa[x] = a[a0 + x];
-  for (int x = threadIdx.x; x < cb; x += kThreads) sb[x] = b[b0 + x];
+  stage(static_cast<const KeyT*>(d.pa), ca, sa);
+  stage(static_cast<const KeyT*>(d.pb), cb, sb);
   __syncthreads();
 
   const int n = ca + cb;
   const int d0 = min(int(threadIdx.x) * kVT, n);
   const int d1 = min(d0 + kVT, n);
-  // merge-path split of this thread's diagonal (A first on ties)
+  // merge-path split of this lane's diagonal (A first on ties)
   int lo = max(0, d0 - cb), hi = min(d0, ca);
   while (lo < hi) {
     const int mid = (lo + hi) >> 1;
@@ -199,11 +218,11 @@ __global__ __launch_bounds__(kThreads) void k_tile_merge(
   int i = lo, j = d0 - lo;
 
   KeyT vals[kVT];
-  int cls[kVT];  // 0 = A&B, 1 = A\B, 2 = B\A, 3 = nothing
+  uint32_t cls_bits = 0;  // 2 bits per step: 0 = A&B, 1 = A\B, 2 = B\A, 3 = nothing
   int n_i = 0, n_a = 0, n_b = 0;
 #pragma unroll
   for (int step = 0; step < kVT; step++) {
-    int c = 3;
+    uint32_t c = 3;
     KeyT v = KeyT(0);
     if (d0 + step < d1) {
       const bool has_a = i < ca, has_b = j < cb;
@@ -211,67 +230,74 @@ __global__ __launch_bounds__(kThreads) void k_tile_merge(
       const KeyT bv = has_b ? sb[j] : KeyT(0);
       if (has_a && (!has_b || av <= bv)) {
         v = av;
-        c = (has_b && av == bv) ? 0 : 1;
+        c = (has_b && av == bv) ? 0u : 1u;
         i++;
       } else {
         v = bv;
-        c = (i > 0 && sa[i - 1] == bv) ? 3 : 2;
+        c = (i > 0 && sa[i - 1] == bv) ? 3u : 2u;
         j++;
       }
     }
     vals[step] = v;
-    cls[step] = c;
+    cls_bits |= c << (2 * step);
     n_i += c == 0;
     n_a += c == 1;
     n_b += c == 2;
   }
 
+  // wave scan of the three counts, packed into one word
   const uint64_t packed = uint64_t(n_i) | (uint64_t(n_a) << 20) | (uint64_t(n_b) << 40);
-  uint64_t tot;
-  const uint64_t excl = block_exclusive_scan_u64(packed, &tot, lds4);
+  uint64_t inc = packed;
+  const int lane = threadIdx.x;
+#pragma unroll
+  for (int dd = 1; dd < 64; dd <<= 1) {
+    const uint64_t o = __shfl_up(inc, dd, 64);
+    if (lane >= dd) inc += o;
+  }
+  const uint64_t tot = __shfl(inc, 63, 64);
+  const uint64_t excl = inc - packed;
   const int tot_i = int(tot & 0xFFFFF), tot_a = int((tot >> 20) & 0xFFFFF), tot_b = int(tot >> 40);
 
   if (!kWrite) {
-    if (threadIdx.x == 0) tile_m[t] = tot_i;
+    if (lane == 0) tile_m[t] = tot_i;
     return;
   }
 
-  // every thread has finished reading sa/sb (the scan's barrier): reuse the LDS
+  __syncthreads();  // every lane is done reading sa / sb: reuse the LDS for compaction
+  const int64_t ioff = tile_ioff[t];
   if (kMode == 2) {
     int p_u = int(excl & 0xFFFFF) + int((excl >> 20) & 0xFFFFF) + int(excl >> 40);
-    __syncthreads();
 #pragma unroll
     for (int step = 0; step < kVT; step++)
-      if (cls[step] != 3) lds[p_u++] = vals[step];
+      if (((cls_bits >> (2 * step)) & 3) != 3) lds[p_u++] = vals[step];
     __syncthreads();
     const int tot_u = tot_i + tot_a + tot_b;
-    KeyT* o = out_i + (a0 + b0 - tile_ioff[t]);
-    for (int x = threadIdx.x; x < tot_u; x += kThreads) o[x] = lds[x];
+    KeyT* o = out_i + (d.a0 + d.b0 - ioff);
+    for (int x = lane; x < tot_u; x += kThreads) o[x] = lds[x];
     return;
   }
   int p_i = int(excl & 0xFFFFF);
   int p_a = tot_i + int((excl >> 20) & 0xFFFFF);
   int p_b = tot_i + tot_a + int(excl >> 40);
-  __syncthreads();
 #pragma unroll
   for (int step = 0; step < kVT; step++) {
-    if (cls[step] == 0) lds[p_i++] = vals[step];
-    else if (cls[step] == 1) lds[p_a++] = vals[step];
-    else if (cls[step] == 2) lds[p_b++] = vals[step];
+    const uint32_t c = (cls_bits >> (2 * step)) & 3;
+    if (c == 0) lds[p_i++] = vals[step];
+    else if (c == 1) lds[p_a++] = vals[step];
+    else if (c == 2) lds[p_b++] = vals[step];
   }
   __syncthreads();
-  const int64_t ioff = tile_ioff[t];
   if (out_i) {
     KeyT* o = out_i + ioff;
-    for (int x = threadIdx.x; x < tot_i; x += kThreads) o[x] = lds[x];
+    for (int x = lane; x < tot_i; x += kThreads) o[x] = lds[x];
   }
   if (out_amb) {
-    KeyT* o = out_amb + (a0 - ioff);
-    for (int x = threadIdx.x; x < tot_a; x += kThreads) o[x] = lds[tot_i + x];
+    KeyT* o = out_amb + (d.a0 - ioff);
+    for (int x = lane; x < tot_a; x += kThreads) o[x] = lds[tot_i + x];
   }
   if (out_bma) {
-    KeyT* o = out_bma + (b0 - ioff);
-    for (int x = threadIdx.x; x < tot_b; x += kThreads) o[x] = lds[tot_i + tot_a + x];
+    KeyT* o = out_bma + (d.b0 - ioff);
+    for (int x = lane; x < tot_b; x += kThreads) o[x] = lds[tot_i + tot_a + x];
   }
 }
 
@@ -316,9 +342,7 @@ struct Plan {
   int64_t n_segs = 0;
   int64_t max_tiles = 0;
   int64_t* tile_base = nullptr;  // n_segs + 1
-  int32_t* tile_seg = nullptr;   // max_tiles
-  int64_t* tile_a = nullptr;     // max_tiles
-  int64_t* tile_b = nullptr;     // max_tiles
+  TileDesc* desc = nullptr;      // max_tiles
   int64_t* tile_ioff = nullptr;  // max_tiles (count, then exclusive prefix in place)
   int64_t* total_m = nullptr;    // 1
 };
@@ -326,8 +350,8 @@ struct Plan {
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
 inline size_t plan_bytes(int64_t n_segs, int64_t max_tiles) {
-  return align256(size_t(n_segs + 1) * 8) + align256(size_t(max_tiles) * 4) +
-         3 * align256(size_t(max_tiles) * 8) + 256;
+  return align256(size_t(n_segs + 1) * 8) + align256(size_t(max_tiles) * sizeof(TileDesc)) +
+         align256(size_t(max_tiles) * 8) + 256;
 }
 
 inline void plan_carve(char* base, int64_t n_segs, int64_t max_tiles, Plan* p) {
@@ -336,12 +360,8 @@ inline void plan_carve(char* base, int64_t n_segs, int64_t max_tiles, Plan* p) {
   char* at = base;
   p->tile_base = reinterpret_cast<int64_t*>(at);
   at += align256(size_t(n_segs + 1) * 8);
-  p->tile_seg = reinterpret_cast<int32_t*>(at);
-  at += align256(size_t(max_tiles) * 4);
-  p->tile_a = reinterpret_cast<int64_t*>(at);
-  at += align256(size_t(max_tiles) * 8);
-  p->tile_b = reinterpret_cast<int64_t*>(at);
-  at += align256(size_t(max_tiles) * 8);
+  p->desc = reinterpret_cast<TileDesc*>(at);
+  at += align256(size_t(max_tiles) * sizeof(TileDesc));
   p->tile_ioff = reinterpret_cast<int64_t*>(at);
   at += align256(size_t(max_tiles) * 8);
   p->total_m = reinterpret_cast<int64_t*>(at);
@@ -362,12 +382,13 @@ int plan_tile_base(ksh_ctx* ctx, const Segs& segs, int64_t n_segs, int64_t* tile
 template <typename KeyT, typename Segs>
 int plan_count(ksh_ctx* ctx, const Segs& segs, const Plan& p, int timer_kind) {
   hipLaunchKernelGGL((k_tile_split<KeyT, Segs>), dim3(blocks_for(p.max_tiles, 256)), dim3(256), 0,
-                     ctx->stream, segs, p.n_segs, p.tile_base, p.tile_seg, p.tile_a, p.tile_b);
+                     ctx->stream, segs, p.n_segs, p.tile_base, p.desc);
   {
     Timer timer(ctx, timer_kind);
-    hipLaunchKernelGGL((k_tile_merge<KeyT, Segs, 0>), dim3(unsigned(p.max_tiles)),
-                       dim3(kThreads), 0, ctx->stream, segs, p.n_segs, p.tile_base, p.tile_seg,
-                       p.tile_a, p.tile_b, p.tile_ioff, nullptr, nullptr, nullptr, nullptr);
+    hipLaunchKernelGGL((k_tile_merge<KeyT, 0>), dim3(unsigned(p.max_tiles)), dim3(kThreads), 0,
+                       ctx->stream, p.desc, p.tile_base + p.n_segs, p.tile_ioff, nullptr,
+                       static_cast<KeyT*>(nullptr), static_cast<KeyT*>(nullptr),
+                       static_cast<KeyT*>(nullptr));
   }
   KSH_TRY(scan_exclusive_i64(ctx, p.tile_ioff, p.tile_ioff, p.max_tiles, p.total_m));
   KSH_HIP(hipGetLastError());
@@ -427,16 +448,54 @@ int pair_write_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const k
     return fail(KSH_FAILED_PRECONDITION, "ksh_pair_write without a matching ksh_pair_plan");
   Plan p;
   plan_carve(ctx->plan, nb, ctx->plan_tiles, &p);
-  BucketSegs<KeyT> segs{static_cast<const KeyT*>(a->d_keys), a->d_offsets,
-                        static_cast<const KeyT*>(b->d_keys), b->d_offsets};
   {
     Timer timer(ctx, 0);
-    hipLaunchKernelGGL((k_tile_merge<KeyT, BucketSegs<KeyT>, 1>), dim3(unsigned(p.max_tiles)),
-                       dim3(kThreads), 0, ctx->stream, segs, p.n_segs, p.tile_base, p.tile_seg,
-                       p.tile_a, p.tile_b, nullptr, p.tile_ioff, static_cast<KeyT*>(d_keys_i),
-                       static_cast<KeyT*>(d_keys_amb), static_cast<KeyT*>(d_keys_bma));
+    hipLaunchKernelGGL((k_tile_merge<KeyT, 1>), dim3(unsigned(p.max_tiles)), dim3(kThreads), 0,
+                       ctx->stream, p.desc, p.tile_base + p.n_segs, nullptr, p.tile_ioff,
+                       static_cast<KeyT*>(d_keys_i), static_cast<KeyT*>(d_keys_amb),
+                       static_cast<KeyT*>(d_keys_bma));
   }
   KSH_HIP(hipGetLastError());
+  return KSH_OK;
+}
+
+// Plan + write back to back with caller-provided upper-bound buffers: one stream sync
+// (for the totals) instead of two and no allocation between the passes.
+template <typename KeyT>
+int pair_algebra_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
+                   int64_t* d_off_i, int64_t* d_off_amb, int64_t* d_off_bma, void* d_keys_i,
+                   void* d_keys_amb, void* d_keys_bma, int64_t totals[3]) {
+  const int64_t nb = n_buckets(g);
+  const int64_t max_tiles = nb + (a->n_keys + b->n_keys) / kTile + 1;
+  if (max_tiles > int64_t(0x7FFFFFF0)) return fail(KSH_INVALID_ARGUMENT, "pair too large for one launch");
+  KSH_TRY(arena_reserve(ctx, plan_bytes(nb, max_tiles) + size_t(max_tiles / 256 + 4096) * 8 + (1u << 16)));
+  arena_reset(ctx);
+  char* base = static_cast<char*>(arena_alloc(ctx, plan_bytes(nb, max_tiles)));
+  Plan p;
+  plan_carve(base, nb, max_tiles, &p);
+  BucketSegs<KeyT> segs{static_cast<const KeyT*>(a->d_keys), a->d_offsets,
+                        static_cast<const KeyT*>(b->d_keys), b->d_offsets};
+  KSH_TRY((plan_tile_base<KeyT>(ctx, segs, nb, p.tile_base)));
+  KSH_TRY((plan_count<KeyT>(ctx, segs, p, 1)));
+  int64_t* d_totals = static_cast<int64_t*>(arena_alloc(ctx, 3 * sizeof(int64_t)));
+  if (!d_totals) return fail(KSH_INTERNAL, "scratch arena too small");
+  hipLaunchKernelGGL(k_result_offsets, dim3(blocks_for(nb + 1, 256)), dim3(256), 0, ctx->stream,
+                     a->d_offsets, b->d_offsets, p.tile_base, p.tile_ioff, p.total_m, nb, d_off_i,
+                     d_off_amb, d_off_bma, d_totals);
+  {
+    Timer timer(ctx, 0);
+    hipLaunchKernelGGL((k_tile_merge<KeyT, 1>), dim3(unsigned(p.max_tiles)), dim3(kThreads), 0,
+                       ctx->stream, p.desc, p.tile_base + p.n_segs, nullptr, p.tile_ioff,
+                       static_cast<KeyT*>(d_keys_i), static_cast<KeyT*>(d_keys_amb),
+                       static_cast<KeyT*>(d_keys_bma));
+  }
+  KSH_HIP(hipGetLastError());
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, d_totals, 3 * sizeof(int64_t), hipMemcpyDeviceToHost,
+                         ctx->stream));
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  totals[0] = ctx->h_pinned[0];
+  totals[1] = ctx->h_pinned[1];
+  totals[2] = ctx->h_pinned[2];
   return KSH_OK;
 }
 
@@ -495,11 +554,10 @@ int union_write_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const 
     return fail(KSH_FAILED_PRECONDITION, "ksh_set_union_write without a matching ksh_set_union_plan");
   Plan p;
   plan_carve(ctx->plan, nb, ctx->plan_tiles, &p);
-  BucketSegs<KeyT> segs{static_cast<const KeyT*>(a->d_keys), a->d_offsets,
-                        static_cast<const KeyT*>(b->d_keys), b->d_offsets};
-  hipLaunchKernelGGL((k_tile_merge<KeyT, BucketSegs<KeyT>, 2>), dim3(unsigned(p.max_tiles)),
-                     dim3(kThreads), 0, ctx->stream, segs, p.n_segs, p.tile_base, p.tile_seg, p.tile_a,
-                     p.tile_b, nullptr, p.tile_ioff, static_cast<KeyT*>(d_keys_u), nullptr, nullptr);
+  hipLaunchKernelGGL((k_tile_merge<KeyT, 2>), dim3(unsigned(p.max_tiles)), dim3(kThreads), 0,
+                     ctx->stream, p.desc, p.tile_base + p.n_segs, nullptr, p.tile_ioff,
+                     static_cast<KeyT*>(d_keys_u), static_cast<KeyT*>(nullptr),
+                     static_cast<KeyT*>(nullptr));
   KSH_HIP(hipGetLastError());
   return KSH_OK;
 }
@@ -611,6 +669,22 @@ int ksh_pair_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const
   KSH_HIP(hipSetDevice(ctx->device));
   return g->key_bytes == 4 ? pair_write_t<uint32_t>(ctx, g, a, b, d_keys_i, d_keys_amb, d_keys_bma)
                            : pair_write_t<uint64_t>(ctx, g, a, b, d_keys_i, d_keys_amb, d_keys_bma);
+}
+
+int ksh_pair_algebra(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
+                     int64_t* d_off_i, int64_t* d_off_amb, int64_t* d_off_bma, void* d_keys_i,
+                     void* d_keys_amb, void* d_keys_bma, int64_t totals[3]) {
+  if (!ctx || !d_off_i || !d_off_amb || !d_off_bma || !totals || !d_keys_i || !d_keys_amb ||
+      !d_keys_bma)
+    return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  KSH_TRY(check_geom(g));
+  KSH_TRY(check_view(a, "a"));
+  KSH_TRY(check_view(b, "b"));
+  KSH_HIP(hipSetDevice(ctx->device));
+  return g->key_bytes == 4 ? pair_algebra_t<uint32_t>(ctx, g, a, b, d_off_i, d_off_amb, d_off_bma,
+                                                      d_keys_i, d_keys_amb, d_keys_bma, totals)
+                           : pair_algebra_t<uint64_t>(ctx, g, a, b, d_off_i, d_off_amb, d_off_bma,
+                                                      d_keys_i, d_keys_amb, d_keys_bma, totals);
 }
 
 int ksh_set_union_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a,

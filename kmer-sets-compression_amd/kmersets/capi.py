@@ -86,6 +86,7 @@ def lib():
         "ksh_pair_plan": (C.c_int, [vp, GP, SP, SP, vp, vp, vp, C.POINTER(i64)]),
         "ksh_pair_write": (C.c_int, [vp, GP, SP, SP, vp, vp, vp]),
         "ksh_set_diff": (C.c_int, [vp, GP, SP, SP, C.POINTER(i64)]),
+        "ksh_pair_algebra": (C.c_int, [vp, GP, SP, SP, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]),
         "ksh_pair_weights": (C.c_int, [vp, GP, SP, i32, C.POINTER(i32), i32, C.POINTER(i32), i32,
                                        C.POINTER(i64)]),
         "ksh_spss_size": (C.c_int, [vp, GP, C.POINTER(SpssView), C.POINTER(i64)]),
@@ -341,6 +342,28 @@ class Context:
         st = (C.c_int64 * 4)()
         check(lib().ksh_spss_encode_stats(self.h, st))
         return {"unitigs": st[0], "rounds": st[1], "strings": st[2], "bases": st[3]}
+
+    def pair_algebra_onepass(self, a, b):
+        """(A & B, A \\ B, B \\ A) by ksh_pair_algebra (count + write passes enqueued back to
+        back); key buffers are allocated at their upper bounds before the sizes are known."""
+        import torch
+
+        g = a.g
+        caps = (min(a.n_keys, b.n_keys), a.n_keys, b.n_keys)
+        outs = []
+        for cap in caps:
+            o = DeviceSet.empty_like_offsets(g, 0, self.device)
+            o.keys = torch.empty(max(cap * g.key_bytes, 16), dtype=torch.uint8, device=self.device)
+            outs.append(o)
+        totals = (C.c_int64 * 3)()
+        va, vb = a.view(), b.view()
+        check(lib().ksh_pair_algebra(self.h, C.byref(g), C.byref(va), C.byref(vb),
+                                     outs[0].offsets.data_ptr(), outs[1].offsets.data_ptr(),
+                                     outs[2].offsets.data_ptr(), outs[0].keys.data_ptr(),
+                                     outs[1].keys.data_ptr(), outs[2].keys.data_ptr(), totals))
+        for o, n in zip(outs, totals):
+            o.n_keys = int(n)
+        return outs
 
     def set_union(self, a, b):
         """KmerSet::Add: A | B as a new DeviceSet."""

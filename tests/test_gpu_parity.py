@@ -44,6 +44,13 @@ def check_algebra(ctx, k, n, kb, ka, kbm, use_oracle=True):
         w_off, w_keys = synth.to_bucketed(want, k, n, got.g.key_bytes)
         assert np.array_equal(off, w_off)
         assert np.array_equal(keys, w_keys)
+    # the one-call form (upper-bound buffers) must give the same three sets
+    for got, want in zip(ctx.pair_algebra_onepass(a, b), (want_i, want_amb, want_bma)):
+        assert got.n_keys == want.size
+        off, keys = got.to_numpy()
+        w_off, w_keys = synth.to_bucketed(want, k, n, got.g.key_bytes)
+        assert np.array_equal(off, w_off)
+        assert np.array_equal(keys, w_keys)
     assert ctx.set_diff(a, b) == want_amb.size + want_bma.size
     for d, want in ((a, ka), (b, kbm), (i_d, want_i)):
         h = 0
@@ -162,6 +169,9 @@ def test_config2_properties(ctx):
         for j in range(i + 1, 4):
             a, b = d[i], d[j]
             inter, amb, bma = ctx.pair_algebra(a, b)
+            i1, a1, b1 = ctx.pair_algebra_onepass(a, b)
+            assert ctx.set_diff(i1, inter) == 0 and ctx.set_diff(a1, amb) == 0 and ctx.set_diff(b1, bma) == 0
+            assert bool(torch.equal(i1.offsets, inter.offsets)) and bool(torch.equal(b1.offsets, bma.offsets))
             assert inter.n_keys + amb.n_keys == a.n_keys
             assert inter.n_keys + bma.n_keys == b.n_keys
             assert ctx.set_hash(inter) ^ ctx.set_hash(amb) == hashes[i]

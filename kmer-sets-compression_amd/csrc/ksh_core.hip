@@ -171,7 +171,7 @@ __global__ void k_store_total(const int64_t* __restrict__ block_prefix_last,
 }
 
 // Small inputs (bucket counts, tile counts): one 1024-thread workgroup, one launch.
-constexpr int64_t kScanSmallMax = 1 << 17;
+constexpr int64_t kScanSmallMax = 20000;  // beyond this one CU's bandwidth is the limit
 
 __global__ __launch_bounds__(1024) void k_scan_small(const int64_t* __restrict__ in,
                                                       int64_t* __restrict__ out, int64_t n,

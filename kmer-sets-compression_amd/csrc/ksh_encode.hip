@@ -17,7 +17,7 @@
 //   k_adjacency   8 membership probes per k-mer (4 Next, 4 Prev, forward or reverse
 //                 complement) -> per side: none / the single neighbour / many
 //   k_links       mutual singles
-//   k_walk        one thread per chain start follows links, stamping (start, position)
+//   k_ruler_*     chains of states ranked through a sparse ruler set: (end, distance to end)
 //   k_choose      per k-mer: the chain that starts at the larger end (spss.h:511,555)
 //   k_loops       non-branching loops, spelled from their smallest k-mer (spss.h:585-610)
 //   k_head_counts / scans / k_unitig_fill   unitig ids in the reference's push order
@@ -67,37 +67,142 @@ __global__ __launch_bounds__(256) void k_adjacency(DevSet<KeyT> set, uint32_t* _
   }
 }
 
-__global__ __launch_bounds__(256) void k_links(const uint32_t* __restrict__ nbr, int64_t n_states,
-                                                uint32_t* __restrict__ link) {
-  const int64_t s = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (s >= n_states) return;
-  const uint32_t v = nbr[s];
-  uint32_t out = kNone;
-  if (v < kMulti) {
-    const uint32_t y = v >> 1, same = v & 1, side = uint32_t(s & 1);
-    const uint32_t facing = same ? side : side ^ 1;
-    if (nbr[2 * int64_t(y) + facing] < kMulti) out = v;
+// One thread per k-mer: both links, and the initial chain-rank record of its two states
+// ((itself, 0) for a state that ends its chain, unset otherwise).
+__global__ __launch_bounds__(256) void k_links(const uint32_t* __restrict__ nbr, int64_t n,
+                                                uint32_t* __restrict__ link,
+                                                unsigned long long* __restrict__ info) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const uint2 nb2 = reinterpret_cast<const uint2*>(nbr)[t];
+  const uint32_t v[2] = {nb2.x, nb2.y};
+  uint32_t out[2];
+#pragma unroll
+  for (uint32_t side = 0; side < 2; side++) {
+    out[side] = kNone;
+    if (v[side] < kMulti) {
+      const uint32_t y = v[side] >> 1, same = v[side] & 1;
+      const uint32_t facing = same ? side : side ^ 1;
+      if (nbr[2 * int64_t(y) + facing] < kMulti) out[side] = v[side];
+    }
   }
-  link[s] = out;
+  reinterpret_cast<uint2*>(link)[t] = make_uint2(out[0], out[1]);
+  // state 2t leaves through side 1, state 2t+1 through side 0
+  info[2 * t] = out[1] == kNone ? (uint64_t(2 * t) << 32) : kUnset;
+  info[2 * t + 1] = out[0] == kNone ? (uint64_t(2 * t + 1) << 32) : kUnset;
 }
 
 // ---------------------------------------------------------------------------------- E2
-__global__ __launch_bounds__(256) void k_walk(const uint32_t* __restrict__ link, int64_t n_states,
-                                               unsigned long long* __restrict__ info) {
-  const int64_t s0 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (s0 >= n_states) return;
-  if (link[s0] != kNone) return;  // has a predecessor: not a chain start
-  uint32_t s = uint32_t(s0);
-  uint32_t p = 0;
+// Chains of states are ranked with a sparse ruler set instead of one serial walk per
+// chain (a 10^7-k-mer unitig would otherwise be a 10^7-step dependent walk):
+//   rulers = chain starts, chain ends and a hashed 1-in-32 sample of the states;
+//   k_ruler_walk  every ruler walks to the next ruler (about 16 steps): info[r] = (next, steps);
+//   k_ruler_jump  pointer jumping over the sampled rulers only, until each points at its
+//                 chain's end with the full distance (log2(rulers per chain) rounds);
+//   k_ruler_fill  every ruler walks its segment again: info[s] = (end state, distance to end).
+// Rulers on a non-branching loop never reach an end; they and their segments stay unset
+// and k_loops handles the loop.
+// Both links of the k-mer of state s in one 8-byte load: .x = link[2t], .y = link[2t+1].
+__device__ __forceinline__ uint2 link_pair(const uint32_t* __restrict__ link, uint32_t s) {
+  return reinterpret_cast<const uint2*>(link)[s >> 1];
+}
+__device__ __forceinline__ uint32_t leave_link(uint2 pr, uint32_t s) { return (s & 1) ? pr.x : pr.y; }
+__device__ __forceinline__ uint32_t enter_link(uint2 pr, uint32_t s) { return (s & 1) ? pr.y : pr.x; }
+__device__ __forceinline__ uint32_t step_to(uint32_t s, uint32_t lk) {
+  return ((lk >> 1) << 1) | ((s & 1) ^ (lk & 1));
+}
+
+// Sampled rulers are both states of every 16th k-mer (index order is unrelated to chain
+// order, so this is as good as a hash), which makes them enumerable without compaction:
+// dense thread i <-> state 32 * (i >> 1) + (i & 1).  The other rulers are chain starts and
+// chain ends; "is a ruler" needs only the state's own link pair, which the walk loads anyway.
+__device__ __forceinline__ bool sampled_ruler(uint32_t s) { return (s & 30u) == 0; }
+
+// kDense: thread i is the i-th sampled ruler.  !kDense: thread i is state i and acts only
+// if it starts a chain and is not sampled.  Chain ends never act (they are (itself, 0)).
+template <bool kDense>
+__device__ __forceinline__ bool ruler_of_thread(const uint32_t* __restrict__ link, int64_t n_states,
+                                                uint32_t* r, uint32_t* leave) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t s = kDense ? (32 * (i >> 1) + (i & 1)) : i;
+  if (s >= n_states) return false;
+  const uint2 pr = link_pair(link, uint32_t(s));
+  const uint32_t lv = leave_link(pr, uint32_t(s));
+  if (lv == kNone) return false;  // a chain end
+  if (!kDense && (sampled_ruler(uint32_t(s)) || enter_link(pr, uint32_t(s)) != kNone)) return false;
+  *r = uint32_t(s);
+  *leave = lv;
+  return true;
+}
+
+template <bool kDense>
+__global__ __launch_bounds__(256) void k_ruler_walk(const uint32_t* __restrict__ link,
+                                                     int64_t n_states,
+                                                     unsigned long long* __restrict__ info) {
+  uint32_t r, lk;
+  if (!ruler_of_thread<kDense>(link, n_states, &r, &lk)) return;
+  uint32_t cur = r, steps = 0;
   while (true) {
-    info[s] = (uint64_t(s0) << 32) | p;
-    const uint32_t lk = link[s ^ 1];
-    if (lk == kNone || p >= n_states) break;
-    s = ((lk >> 1) << 1) | ((s & 1) ^ (lk & 1));
-    p++;
+    cur = step_to(cur, lk);
+    steps++;
+    lk = leave_link(link_pair(link, cur), cur);
+    if (lk == kNone || sampled_ruler(cur) || steps == 0xFFFFFFFFu) break;  // next ruler
+  }
+  info[r] = (uint64_t(cur) << 32) | steps;
+}
+
+// Pointer jumping over the sampled rulers (dense) until they all point at a chain end.
+__global__ __launch_bounds__(256) void k_ruler_jump(const uint32_t* __restrict__ link,
+                                                     int64_t n_states,
+                                                     unsigned long long* __restrict__ info,
+                                                     int* __restrict__ changed) {
+  uint32_t r, lk;
+  if (!ruler_of_thread<true>(link, n_states, &r, &lk)) return;
+  const uint64_t mine = info[r];
+  const uint32_t nx = uint32_t(mine >> 32);
+  if (nx == r) return;
+  const uint64_t theirs = info[nx];
+  const uint32_t nx2 = uint32_t(theirs >> 32);
+  if (nx2 == nx) return;  // nx is a chain end (or the only ruler of a loop)
+  info[r] = (uint64_t(nx2) << 32) | uint32_t(uint32_t(mine) + uint32_t(theirs));
+  *changed = 1;
+}
+
+// Final hop of the unsampled chain starts, then every ruler stamps its segment.
+template <bool kDense>
+__global__ __launch_bounds__(256) void k_ruler_fill(const uint32_t* __restrict__ link,
+                                                     int64_t n_states,
+                                                     unsigned long long* __restrict__ info) {
+  uint32_t r, lk;
+  if (!ruler_of_thread<kDense>(link, n_states, &r, &lk)) return;
+  uint64_t mine = info[r];
+  uint32_t e = uint32_t(mine >> 32);
+  if (!kDense) {
+    // its next ruler is sampled (and converged) or a chain end
+    const uint64_t theirs = info[e];
+    mine = (theirs & 0xFFFFFFFF00000000ull) | uint32_t(uint32_t(mine) + uint32_t(theirs));
+    e = uint32_t(mine >> 32);
+  }
+  const bool ends = leave_link(link_pair(link, e), e) == kNone;
+  if (!ends) {  // never reached an end: a ruler on a non-branching loop
+    info[r] = kUnset;
+    return;
+  }
+  if (!kDense) info[r] = mine;
+  uint32_t d = uint32_t(mine);
+  uint32_t cur = r;
+  while (true) {
+    cur = step_to(cur, lk);
+    d--;
+    lk = leave_link(link_pair(link, cur), cur);
+    if (lk == kNone || sampled_ruler(cur)) break;
+    info[cur] = (uint64_t(e) << 32) | d;
   }
 }
 
+// info[s] = (end state of s's chain, distance from s to it).  For k-mer t the chain of
+// (t, 0) ends at E0 and the chain of (t, 1) ends at E1, i.e. the forward chain runs from
+// k-mer E1 >> 1 to k-mer E0 >> 1; the spelling starts at the larger end (spss.h:511,555).
 __global__ __launch_bounds__(256) void k_choose(const unsigned long long* __restrict__ info,
                                                  int64_t n, uint32_t* __restrict__ head,
                                                  uint32_t* __restrict__ pos,
@@ -109,20 +214,23 @@ __global__ __launch_bounds__(256) void k_choose(const unsigned long long* __rest
   if (t >= n) return;
   const uint64_t i0 = info[2 * t], i1 = info[2 * t + 1];
   hcls[t] = 0xFF;
-  if (i0 == kUnset) {  // on a loop: k_loops fills it in
+  if (i0 == kUnset || i1 == kUnset) {  // on a loop: k_loops fills it in
     head[t] = kNone;
     return;
   }
-  const uint32_t st0 = uint32_t(i0 >> 32) >> 1, st1 = uint32_t(i1 >> 32) >> 1;
-  const uint32_t d = st0 >= st1 ? 0u : 1u;
-  const uint64_t sel = d ? i1 : i0, oth = d ? i0 : i1;
-  head[t] = uint32_t(sel >> 32) >> 1;
-  pos[t] = uint32_t(sel);
+  const uint32_t e0 = uint32_t(i0 >> 32), e1 = uint32_t(i1 >> 32);
+  const uint32_t d0 = uint32_t(i0), d1 = uint32_t(i1);
+  const uint32_t fwd_start = e1 >> 1, fwd_end = e0 >> 1;
+  const uint32_t d = fwd_start >= fwd_end ? 0u : 1u;
+  const uint32_t start_state = (d ? e0 : e1) ^ 1;
+  const uint32_t p = d ? d0 : d1;
+  head[t] = start_state >> 1;
+  pos[t] = p;
   ori[t] = uint8_t(d);
-  if (uint32_t(sel) == 0) {
-    hcls[t] = st0 == st1 ? 0 : ((uint32_t(sel >> 32) & 1) == 0 ? 1 : 2);
-    hlen[t] = uint32_t(oth) + 1;
-    hlast[t] = uint32_t(oth >> 32) ^ 1;
+  if (p == 0) {
+    hcls[t] = fwd_start == fwd_end ? 0 : ((start_state & 1) == 0 ? 1 : 2);
+    hlen[t] = d0 + d1 + 1;
+    hlast[t] = d ? e1 : e0;
   }
 }
 
@@ -639,9 +747,31 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, int m
   DevSet<KeyT> set{sv->d_offsets, static_cast<const KeyT*>(sv->d_keys), nb, n, g->k, key_bits(g)};
   hipStream_t st = ctx->stream;
   hipLaunchKernelGGL((k_adjacency<KeyT>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr);
-  hipLaunchKernelGGL(k_links, dim3(nblk(2 * n)), dim3(256), 0, st, p->nbr, 2 * n, p->link);
-  KSH_HIP(hipMemsetAsync(p->info, 0xFF, size_t(2 * n) * 8, st));
-  hipLaunchKernelGGL(k_walk, dim3(nblk(2 * n)), dim3(256), 0, st, p->link, 2 * n, p->info);
+  hipLaunchKernelGGL(k_links, dim3(nblk(n)), dim3(256), 0, st, p->nbr, n, p->link, p->info);
+  {
+    int* changed = static_cast<int*>(arena_alloc(ctx, 16));
+    if (!changed) return fail(KSH_INTERNAL, "scratch arena too small");
+    const int64_t ns2 = 2 * n;
+    const int64_t n_dense = 2 * ((n + 15) / 16);
+    hipLaunchKernelGGL(k_ruler_walk<true>, dim3(nblk(n_dense)), dim3(256), 0, st, p->link, ns2,
+                       p->info);
+    hipLaunchKernelGGL(k_ruler_walk<false>, dim3(nblk(ns2)), dim3(256), 0, st, p->link, ns2, p->info);
+    int max_rounds = 2;
+    for (int64_t x = n_dense; x > 1; x >>= 1) max_rounds++;
+    for (int round = 0; round < max_rounds;) {
+      KSH_HIP(hipMemsetAsync(changed, 0, sizeof(int), st));
+      for (int b = 0; b < 4 && round < max_rounds; b++, round++)
+        hipLaunchKernelGGL(k_ruler_jump, dim3(nblk(n_dense)), dim3(256), 0, st, p->link, ns2, p->info,
+                           changed);
+      KSH_HIP(hipMemcpyAsync(ctx->h_pinned, changed, sizeof(int), hipMemcpyDeviceToHost, st));
+      KSH_HIP(hipStreamSynchronize(st));
+      if (*reinterpret_cast<int*>(ctx->h_pinned) == 0) break;
+    }
+    // sparse first: it reads the converged records of the sampled rulers it points at
+    hipLaunchKernelGGL(k_ruler_fill<false>, dim3(nblk(ns2)), dim3(256), 0, st, p->link, ns2, p->info);
+    hipLaunchKernelGGL(k_ruler_fill<true>, dim3(nblk(n_dense)), dim3(256), 0, st, p->link, ns2,
+                       p->info);
+  }
   hipLaunchKernelGGL(k_choose, dim3(nblk(n)), dim3(256), 0, st, p->info, n, p->head, p->pos, p->ori,
                      p->hcls, p->hlen, p->hlast);
   hipLaunchKernelGGL(k_loops, dim3(nblk(n)), dim3(256), 0, st, p->link, p->info, n, p->head, p->pos,

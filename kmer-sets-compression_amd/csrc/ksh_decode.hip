@@ -13,7 +13,8 @@
 //                    per-workgroup histograms go to a [groups][2^N] matrix
 //   k_hist_columns   column sums -> bucket offsets, and per-(group, bucket) bases
 //   k_decode<true>   same walk again, scatters the key into its bucket slot
-//   k_bucket_sort    one workgroup per bucket: bitonic sort in LDS, duplicates dropped
+//   k_bucket_sort    one workgroup per bucket: distribution + insertion sort in LDS (bitonic
+//                    network for skewed or oversize buckets), duplicates dropped
 //                    (GetKmerSetFromSPSS inserts into sets, so repeated k-mers of a
 //                    hand-written input collapse; a real SPSS has none)
 //
@@ -28,7 +29,8 @@ namespace ksh {
 
 constexpr int kDecThreads = 256;
 constexpr int kMaxLdsBuckets = 16384;   // 64 KiB of u32 counters
-constexpr int kSortLdsBytes = 61440;   // + a few static bytes stays under 64 KiB
+constexpr int kSortLdsBytes = 49152;   // + 8 KiB of sub-bin counters stays under 64 KiB
+constexpr int kMaxSubBits = 11;
 
 __global__ __launch_bounds__(256) void k_str_bases(const uint32_t* __restrict__ lens, int64_t n,
                                                     int k, int64_t* __restrict__ bases) {
@@ -138,9 +140,11 @@ __global__ __launch_bounds__(256) void k_hist_columns(uint32_t* __restrict__ his
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_bucket_sort(const int64_t* __restrict__ offsets,
                                                       KeyT* __restrict__ keys,
-                                                      int64_t* __restrict__ uniq) {
+                                                      int64_t* __restrict__ uniq, int key_bits) {
   extern __shared__ unsigned char lds_raw[];
   __shared__ int lds_cnt[4];
+  __shared__ uint32_t sub_cnt[(1 << kMaxSubBits) + 1];
+  __shared__ int s_overflow;
   KeyT* lds = reinterpret_cast<KeyT*>(lds_raw);
   constexpr int kCap = kSortLdsBytes / int(sizeof(KeyT));
   const int64_t b = blockIdx.x;
@@ -155,14 +159,77 @@ __global__ __launch_bounds__(256) void k_bucket_sort(const int64_t* __restrict__
   int64_t padded = 1;
   while (padded < cnt64) padded <<= 1;
   KeyT* buf = in_lds ? lds : g;
+  bool sorted = false;
   if (in_lds) {
-    for (int64_t i = threadIdx.x; i < cnt64; i += 256) lds[i] = g[i];
+    // Distribution sort: keys of one bucket are close to uniform, so one pass on the top
+    // `bits` key bits leaves sub-bins of a few keys each, finished by insertion sort (one
+    // thread per sub-bin).  A skewed bucket (a sub-bin over 64 keys) falls back to the
+    // bitonic network below.
+    const int cnt = int(cnt64);
+    int bits = 0;
+    while ((4 << bits) < cnt && bits < kMaxSubBits) bits++;
+    if (bits > key_bits) bits = key_bits;
+    const int n_sub = 1 << bits;
+    const int sh = key_bits - bits;
+    for (int i = threadIdx.x; i <= n_sub; i += 256) sub_cnt[i] = 0;
+    if (threadIdx.x == 0) s_overflow = 0;
     __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += 256)
+      atomicAdd(&sub_cnt[uint32_t(uint64_t(g[i]) >> sh) & uint32_t(n_sub - 1)], 1u);
+    __syncthreads();
+    {  // exclusive scan of the sub-bin counts
+      const int per = (n_sub + 255) / 256;
+      const int c0 = min(int(threadIdx.x) * per, n_sub), c1 = min(c0 + per, n_sub);
+      int mine = 0;
+      for (int i = c0; i < c1; i++) mine += int(sub_cnt[i]);
+      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+      int inc = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc += o;
+      }
+      if (lane == 63) lds_cnt[wave] = inc;
+      __syncthreads();
+      int run = inc - mine;
+      for (int w = 0; w < wave; w++) run += lds_cnt[w];
+      for (int i = c0; i < c1; i++) {
+        const int c = int(sub_cnt[i]);
+        sub_cnt[i] = uint32_t(run);
+        run += c;
+      }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < cnt; i += 256) {
+      const KeyT key = g[i];
+      const uint32_t pos = atomicAdd(&sub_cnt[uint32_t(uint64_t(key) >> sh) & uint32_t(n_sub - 1)], 1u);
+      lds[pos] = key;
+    }
+    __syncthreads();
+    // sub_cnt[b] is now the end of sub-bin b (= start of b + 1)
+    for (int b2 = threadIdx.x; b2 < n_sub; b2 += 256) {
+      const int s0 = b2 ? int(sub_cnt[b2 - 1]) : 0, s1 = int(sub_cnt[b2]);
+      if (s1 - s0 > 64) {
+        s_overflow = 1;
+      } else {
+        for (int i = s0 + 1; i < s1; i++) {
+          const KeyT x = lds[i];
+          int j = i - 1;
+          while (j >= s0 && lds[j] > x) {
+            lds[j + 1] = lds[j];
+            j--;
+          }
+          lds[j + 1] = x;
+        }
+      }
+    }
+    __syncthreads();
+    sorted = s_overflow == 0;
   }
   // Bitonic network in its all-ascending form (each merge starts with a mirror step), so
   // the slots in [cnt64, padded) can stay virtual: a real key never moves above them.
   const int64_t half = padded >> 1;
-  for (int64_t size = 2; size <= padded; size <<= 1) {
+  for (int64_t size = 2; !sorted && size <= padded; size <<= 1) {
     const int64_t hs = size >> 1;
     for (int64_t p = threadIdx.x; p < half; p += 256) {
       const int64_t block = p / hs, o = p - block * hs;
@@ -354,7 +421,7 @@ int decode_write_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int 
                      keys);
   // per-bucket sort + duplicate removal; uniq counts reuse st.totals
   hipLaunchKernelGGL((k_bucket_sort<KeyT>), dim3(unsigned(nb)), dim3(256), kSortLdsBytes, ctx->stream,
-                     d_offsets, keys, st.totals);
+                     d_offsets, keys, st.totals, key_bits(g));
   KSH_HIP(hipGetLastError());
   arena_reset(ctx);
   KSH_TRY(arena_reserve(ctx, a256(size_t(nb + 1) * 8) + (1u << 16)));

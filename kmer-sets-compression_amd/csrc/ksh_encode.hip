@@ -42,6 +42,31 @@ constexpr uint32_t kMulti = 0xFFFFFFFEu;
 constexpr uint64_t kUnset = ~uint64_t(0);
 
 // ---------------------------------------------------------------------------------- E1
+// Fine index of a set: one workgroup per bucket walks its sorted keys once and records
+// where the top 8 key bits change.
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_fine_index(const int64_t* __restrict__ off,
+                                                     const KeyT* __restrict__ keys, int key_bits,
+                                                     uint32_t* __restrict__ fine,
+                                                     int64_t n_buckets) {
+  const int64_t b = blockIdx.x;
+  const int64_t lo = off[b], hi = off[b + 1];
+  const int sh = key_bits - 8;
+  uint32_t* f = fine + (b << 8);
+  if (lo == hi) {
+    f[threadIdx.x] = uint32_t(lo);
+  } else {
+    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+      const int cur = int(uint64_t(keys[i]) >> sh);
+      const int prev = i > lo ? int(uint64_t(keys[i - 1]) >> sh) : -1;
+      for (int sub = prev + 1; sub <= cur; sub++) f[sub] = uint32_t(i);
+    }
+    const int last = int(uint64_t(keys[hi - 1]) >> sh);
+    for (int sub = last + 1 + int(threadIdx.x); sub < 256; sub += 256) f[sub] = uint32_t(hi);
+  }
+  if (b == n_buckets - 1 && threadIdx.x == 0) fine[n_buckets << 8] = uint32_t(hi);
+}
+
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_adjacency(DevSet<KeyT> set, uint32_t* __restrict__ nbr) {
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -676,6 +701,7 @@ struct EncPlan {
   unsigned long long* info = nullptr;
   uint8_t *ori = nullptr, *hcls = nullptr;
   int64_t *c01 = nullptr, *c23 = nullptr;
+  uint32_t* fine = nullptr;
   // unitig level (own allocation)
   char* ublock = nullptr;
   uint32_t *u_head = nullptr, *u_first = nullptr, *u_last = nullptr, *u_len = nullptr,
@@ -725,8 +751,10 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, int m
   }
   if (n >= int64_t(0x7FFFFFF0)) return fail(KSH_INVALID_ARGUMENT, "set too large for 32-bit indices");
   const int64_t nb = n_buckets(g);
+  const bool use_fine = key_bits(g) >= 8;
+  const size_t fine_entries = use_fine ? size_t(nb) * 256 + 1 : 0;
   const size_t bytes = 2 * al(size_t(2 * n) * 4) + al(size_t(2 * n) * 8) + 5 * al(size_t(n) * 4) +
-                       2 * al(size_t(n)) + 2 * al(size_t(n) * 8) + 4096;
+                       2 * al(size_t(n)) + 2 * al(size_t(n) * 8) + al(fine_entries * 4) + 4096;
   KSH_TRY(slot_reserve(ctx, kSlotEncode, bytes));
   KSH_TRY(arena_reserve(ctx, size_t(n / 256 + 4096) * 8 * 2 + (1u << 16)));
   arena_reset(ctx);
@@ -743,9 +771,15 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, int m
   p->hcls = carve<uint8_t>(at, size_t(n));
   p->c01 = carve<int64_t>(at, size_t(n));
   p->c23 = carve<int64_t>(at, size_t(n));
+  p->fine = use_fine ? carve<uint32_t>(at, fine_entries) : nullptr;
 
   DevSet<KeyT> set{sv->d_offsets, static_cast<const KeyT*>(sv->d_keys), nb, n, g->k, key_bits(g)};
   hipStream_t st = ctx->stream;
+  if (use_fine) {
+    hipLaunchKernelGGL((k_fine_index<KeyT>), dim3(unsigned(nb)), dim3(256), 0, st, sv->d_offsets,
+                       static_cast<const KeyT*>(sv->d_keys), key_bits(g), p->fine, nb);
+    set.fine = p->fine;
+  }
   hipLaunchKernelGGL((k_adjacency<KeyT>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr);
   hipLaunchKernelGGL(k_links, dim3(nblk(n)), dim3(256), 0, st, p->nbr, n, p->link, p->info);
   {
@@ -887,6 +921,7 @@ int encode_write_t(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens) {
   const int64_t n = p->n;
   DevSet<KeyT> set{p->set.d_offsets, static_cast<const KeyT*>(p->set.d_keys), n_buckets(g), n, g->k,
                    key_bits(g)};
+  set.fine = p->fine;
   hipStream_t st = ctx->stream;
   // byte staging aliases the neighbour array (2n * 4 bytes >= n_bases needs checking)
   const size_t need = size_t(p->n_bases) + 64;

@@ -69,6 +69,7 @@ int ksh_malloc(int device, size_t bytes, void** d_ptr);
 int ksh_free(int device, void* d_ptr);
 int ksh_memcpy_h2d(int device, void* d_dst, const void* src, size_t bytes);
 int ksh_memcpy_d2h(int device, void* dst, const void* d_src, size_t bytes);
+int ksh_memcpy_d2d(int device, void* d_dst, const void* d_src, size_t bytes);
 
 /* A context = one GPU + one HIP stream + a scratch arena.  `stream` may be an
  * existing hipStream_t (e.g. torch's current stream) or NULL for a new one.

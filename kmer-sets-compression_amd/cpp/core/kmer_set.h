@@ -1,0 +1,298 @@
+// KmerSet<K, N, KeyType>: the reference's public surface (lib/core/kmer_set.h:57-305)
+// over a set resident in HBM.
+//
+// The reference keeps 2^N absl::flat_hash_set<KeyType>; here the set is
+// offsets[2^N + 1] + keys sorted inside each bucket, on the GPU, and every bulk
+// operation is one or two kernel launches through the C ABI:
+//   Size / Hash / Diff / Equals          ksh_set_view.n_keys / ksh_set_hash / ksh_set_diff
+//   Add(other) / Sub(other)              ksh_set_union_* / ksh_pair_plan + ksh_pair_write
+//   free Add / Sub / Intersection        the same (Intersection is NOT lhs.Sub(Sub(lhs, rhs)):
+//                                        one merge emits it directly)
+// Single-k-mer Add / Remove / Contains and Find(pred) exist for the callers that build
+// or inspect a set on the host (kmerset-build, tests); they go through a pending list /
+// a lazily downloaded sorted copy.  n_workers stays in the signatures and is ignored.
+// KeyType keeps its meaning for the host-side accessors; on the device keys are 4 bytes
+// when 2K - N <= 32, else 8.
+#ifndef KSC_CORE_KMER_SET_H_
+#define KSC_CORE_KMER_SET_H_
+
+#include <algorithm>
+#include <cstdint>
+#include <tuple>
+#include <utility>
+#include <vector>
+
+#include "core/device.h"
+#include "core/kmer.h"
+
+// The first N bits select the bucket, the last 2K - N bits are the key
+// (lib/core/kmer_set.h:22-43).
+template <int K, int N, typename KeyType>
+std::pair<int, KeyType> GetBucketAndKeyFromKmer(const Kmer<K>& kmer) {
+  const int n_key_bits = K * 2 - N;
+  static_assert(n_key_bits <= static_cast<int>(sizeof(KeyType) * 8));
+  const std::uint64_t bits = kmer.Bits();
+  return std::make_pair(static_cast<int>(bits >> n_key_bits),
+                        static_cast<KeyType>(bits % (std::uint64_t(1) << n_key_bits)));
+}
+
+template <int K, int N, typename KeyType>
+Kmer<K> GetKmerFromBucketAndKey(int bucket_id, KeyType key) {
+  const int n_key_bits = K * 2 - N;
+  return Kmer<K>((static_cast<std::uint64_t>(bucket_id) << n_key_bits) +
+                 static_cast<std::uint64_t>(key));
+}
+
+template <int K, int N, typename KeyType>
+class KmerSetCompact;
+
+template <int K, int N, typename KeyType>
+class KmerSet {
+  static_assert(2 * K - N <= static_cast<int>(sizeof(KeyType) * 8));
+
+ public:
+  static constexpr int kBucketsNum = 1 << N;
+  static constexpr int kKeyBits = 2 * K - N;
+  static constexpr int kDeviceKeyBytes = kKeyBits <= 32 ? 4 : 8;
+  static ksh_geom Geom() { return ksh_geom{K, N, kDeviceKeyBytes, 0}; }
+
+  KmerSet() = default;
+
+  // From an ascending list of distinct k-mer bit patterns.
+  static KmerSet FromSortedBits(const std::vector<std::uint64_t>& bits) {
+    KmerSet s;
+    s.Upload(bits);
+    return s;
+  }
+
+  // Takes ownership of device buffers in the C-ABI layout.
+  static KmerSet FromDevice(ksc::DeviceBuffer offsets, ksc::DeviceBuffer keys, std::int64_t n) {
+    KmerSet s;
+    s.offsets_ = std::move(offsets);
+    s.keys_ = std::move(keys);
+    s.n_ = n;
+    s.resident_ = true;
+    return s;
+  }
+
+  std::int64_t Size() const {
+    Flush();
+    return n_;
+  }
+
+  void Clear() { *this = KmerSet(); }
+
+  void Add(const Kmer<K>& kmer) {
+    pending_add_.push_back(kmer.Bits());
+    host_valid_ = false;
+  }
+
+  void Remove(const Kmer<K>& kmer) {
+    Flush();  // keeps Add-then-Remove order
+    pending_remove_.push_back(kmer.Bits());
+    host_valid_ = false;
+  }
+
+  bool Contains(const Kmer<K>& kmer) const {
+    const std::vector<std::uint64_t>& h = HostBits();
+    return std::binary_search(h.begin(), h.end(), kmer.Bits());
+  }
+
+  void Reserve(std::int64_t) {}
+
+  // K-mers matching the predicate, ascending.
+  template <typename PredType>
+  std::vector<Kmer<K>> Find(PredType pred, int /*n_workers*/, std::int64_t estimated_size = 0) const {
+    std::vector<Kmer<K>> kmers;
+    if (estimated_size > 0) kmers.reserve(static_cast<std::size_t>(estimated_size));
+    for (std::uint64_t b : HostBits()) {
+      const Kmer<K> kmer(b);
+      if (pred(kmer)) kmers.push_back(kmer);
+    }
+    return kmers;
+  }
+
+  std::vector<Kmer<K>> Find(int n_workers) const {
+    return Find([](const Kmer<K>&) { return true; }, n_workers, Size());
+  }
+
+  KmerSet& Add(const KmerSet& other, int /*n_workers*/) {
+    Flush();
+    other.Flush();
+    const ksh_geom g = Geom();
+    const ksh_set_view va = View(), vb = other.View();
+    ksc::DeviceBuffer off(std::size_t(kBucketsNum + 1) * 8);
+    std::int64_t total = 0;
+    ksc::Check(ksh_set_union_plan(ksc::Ctx(), &g, &va, &vb, static_cast<std::int64_t*>(off.get()), &total));
+    ksc::DeviceBuffer keys(std::size_t(total) * kDeviceKeyBytes);
+    ksc::Check(ksh_set_union_write(ksc::Ctx(), &g, &va, &vb, keys.get()));
+    ksc::Check(ksh_ctx_sync(ksc::Ctx()));
+    Adopt(std::move(off), std::move(keys), total);
+    return *this;
+  }
+
+  KmerSet& Sub(const KmerSet& other, int /*n_workers*/) {
+    KmerSet amb;
+    Algebra(*this, other, nullptr, &amb, nullptr);
+    *this = std::move(amb);
+    return *this;
+  }
+
+  std::int64_t Diff(const KmerSet& other, int /*n_workers*/) const {
+    Flush();
+    other.Flush();
+    const ksh_geom g = Geom();
+    const ksh_set_view va = View(), vb = other.View();
+    std::int64_t d = 0;
+    ksc::Check(ksh_set_diff(ksc::Ctx(), &g, &va, &vb, &d));
+    return d;
+  }
+
+  bool Equals(const KmerSet& other, int n_workers) const { return Diff(other, n_workers) == 0; }
+
+  std::size_t Hash(int /*n_workers*/) const {
+    Flush();
+    const ksh_geom g = Geom();
+    const ksh_set_view v = View();
+    std::uint64_t h = 0;
+    ksc::Check(ksh_set_hash(ksc::Ctx(), &g, &v, &h));
+    return h;
+  }
+
+  // A&B, A\B, B\A of one pair in one merge (what kmer_set_set.h:339-343 asks for).
+  static void Algebra(const KmerSet& a, const KmerSet& b, KmerSet* inter, KmerSet* a_minus_b,
+                      KmerSet* b_minus_a) {
+    a.Flush();
+    b.Flush();
+    const ksh_geom g = Geom();
+    const ksh_set_view va = a.View(), vb = b.View();
+    ksc::DeviceBuffer oi(std::size_t(kBucketsNum + 1) * 8), oa(std::size_t(kBucketsNum + 1) * 8),
+        ob(std::size_t(kBucketsNum + 1) * 8);
+    std::int64_t totals[3];
+    ksc::Check(ksh_pair_plan(ksc::Ctx(), &g, &va, &vb, static_cast<std::int64_t*>(oi.get()),
+                             static_cast<std::int64_t*>(oa.get()), static_cast<std::int64_t*>(ob.get()),
+                             totals));
+    ksc::DeviceBuffer ki, ka, kb;
+    if (inter) ki = ksc::DeviceBuffer(std::size_t(totals[0]) * kDeviceKeyBytes);
+    if (a_minus_b) ka = ksc::DeviceBuffer(std::size_t(totals[1]) * kDeviceKeyBytes);
+    if (b_minus_a) kb = ksc::DeviceBuffer(std::size_t(totals[2]) * kDeviceKeyBytes);
+    ksc::Check(ksh_pair_write(ksc::Ctx(), &g, &va, &vb, inter ? ki.get() : nullptr,
+                              a_minus_b ? ka.get() : nullptr, b_minus_a ? kb.get() : nullptr));
+    ksc::Check(ksh_ctx_sync(ksc::Ctx()));
+    if (inter) *inter = FromDevice(std::move(oi), std::move(ki), totals[0]);
+    if (a_minus_b) *a_minus_b = FromDevice(std::move(oa), std::move(ka), totals[1]);
+    if (b_minus_a) *b_minus_a = FromDevice(std::move(ob), std::move(kb), totals[2]);
+  }
+
+  // Device view (flushes pending single-k-mer edits first).
+  ksh_set_view View() const {
+    Flush();
+    return ksh_set_view{static_cast<const std::int64_t*>(offsets_.get()), keys_.get(), n_};
+  }
+
+  // Ascending bit patterns of all k-mers (downloaded once, cached).
+  const std::vector<std::uint64_t>& HostBits() const {
+    Flush();
+    if (!host_valid_) {
+      const std::vector<std::int64_t> off = offsets_.ToHost<std::int64_t>(kBucketsNum + 1);
+      host_.assign(static_cast<std::size_t>(n_), 0);
+      if (kDeviceKeyBytes == 4) {
+        const std::vector<std::uint32_t> keys = keys_.ToHost<std::uint32_t>(static_cast<std::size_t>(n_));
+        for (int b = 0; b < kBucketsNum; b++)
+          for (std::int64_t i = off[b]; i < off[b + 1]; i++)
+            host_[i] = (std::uint64_t(b) << kKeyBits) | keys[i];
+      } else {
+        const std::vector<std::uint64_t> keys = keys_.ToHost<std::uint64_t>(static_cast<std::size_t>(n_));
+        for (int b = 0; b < kBucketsNum; b++)
+          for (std::int64_t i = off[b]; i < off[b + 1]; i++)
+            host_[i] = (std::uint64_t(b) << kKeyBits) | keys[i];
+      }
+      host_valid_ = true;
+    }
+    return host_;
+  }
+
+ private:
+  void Adopt(ksc::DeviceBuffer off, ksc::DeviceBuffer keys, std::int64_t n) const {
+    offsets_ = std::move(off);
+    keys_ = std::move(keys);
+    n_ = n;
+    resident_ = true;
+    host_valid_ = false;
+  }
+
+  void Upload(std::vector<std::uint64_t> bits) const {
+    std::vector<std::int64_t> off(kBucketsNum + 1, 0);
+    for (std::uint64_t b : bits) off[(b >> kKeyBits) + 1]++;
+    for (int b = 0; b < kBucketsNum; b++) off[b + 1] += off[b];
+    ksc::DeviceBuffer keys;
+    if (kDeviceKeyBytes == 4) {
+      std::vector<std::uint32_t> k32(bits.size());
+      for (std::size_t i = 0; i < bits.size(); i++)
+        k32[i] = static_cast<std::uint32_t>(bits[i] & ((std::uint64_t(1) << kKeyBits) - 1));
+      keys = ksc::DeviceBuffer::FromHost(k32);
+    } else {
+      std::vector<std::uint64_t> k64(bits.size());
+      for (std::size_t i = 0; i < bits.size(); i++) k64[i] = bits[i] & ((std::uint64_t(1) << kKeyBits) - 1);
+      keys = ksc::DeviceBuffer::FromHost(k64);
+    }
+    Adopt(ksc::DeviceBuffer::FromHost(off), std::move(keys), static_cast<std::int64_t>(bits.size()));
+    host_ = std::move(bits);
+    host_valid_ = true;
+  }
+
+  // Applies pending single-k-mer edits: set = (set | adds) \ removes.
+  void Flush() const {
+    if (!resident_) {
+      resident_ = true;
+      Upload({});
+    }
+    if (pending_add_.empty() && pending_remove_.empty()) return;
+    std::vector<std::uint64_t> adds, removes;
+    adds.swap(pending_add_);
+    removes.swap(pending_remove_);
+    if (!adds.empty()) {
+      std::sort(adds.begin(), adds.end());
+      adds.erase(std::unique(adds.begin(), adds.end()), adds.end());
+      KmerSet tmp = FromSortedBits(adds);
+      const_cast<KmerSet*>(this)->Add(tmp, 1);
+    }
+    if (!removes.empty()) {
+      std::sort(removes.begin(), removes.end());
+      removes.erase(std::unique(removes.begin(), removes.end()), removes.end());
+      KmerSet tmp = FromSortedBits(removes);
+      const_cast<KmerSet*>(this)->Sub(tmp, 1);
+    }
+  }
+
+  mutable ksc::DeviceBuffer offsets_, keys_;
+  mutable std::int64_t n_ = 0;
+  mutable bool resident_ = false;
+  mutable std::vector<std::uint64_t> pending_add_, pending_remove_;
+  mutable std::vector<std::uint64_t> host_;
+  mutable bool host_valid_ = false;
+
+  friend class KmerSetCompact<K, N, KeyType>;
+};
+
+// Union / difference / intersection by value, as the reference has them
+// (lib/core/kmer_set.h:286-305).
+template <int K, int N, typename KeyType>
+KmerSet<K, N, KeyType> Add(KmerSet<K, N, KeyType> lhs, const KmerSet<K, N, KeyType>& rhs, int n_workers) {
+  return lhs.Add(rhs, n_workers);
+}
+
+template <int K, int N, typename KeyType>
+KmerSet<K, N, KeyType> Sub(KmerSet<K, N, KeyType> lhs, const KmerSet<K, N, KeyType>& rhs, int n_workers) {
+  return lhs.Sub(rhs, n_workers);
+}
+
+template <int K, int N, typename KeyType>
+KmerSet<K, N, KeyType> Intersection(KmerSet<K, N, KeyType> lhs, const KmerSet<K, N, KeyType>& rhs,
+                                    int /*n_workers*/) {
+  KmerSet<K, N, KeyType> inter;
+  KmerSet<K, N, KeyType>::Algebra(lhs, rhs, &inter, nullptr, nullptr);
+  return inter;
+}
+
+#endif

@@ -1,0 +1,269 @@
+// Host-side tests of the C++17 mirror of the reference API, written after the
+// reference's own tests (test/kmer.cc, test/kmer_set.cc, test/spss.cc,
+// test/kmer_set_compact.cc, test/kmer_set_set.cc) with seeded inputs.  Needs a GPU:
+// every set operation below runs through libkmersets_hip.so.
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <filesystem>
+#include <functional>
+#include <set>
+#include <string>
+#include <vector>
+
+#include "core/kmer.h"
+#include "core/kmer_set.h"
+#include "core/kmer_set_compact.h"
+#include "core/kmer_set_set.h"
+#include "core/random.h"
+#include "core/spss.h"
+
+static int g_failed = 0, g_checks = 0;
+#define EXPECT_TRUE(x)                                                        \
+  do {                                                                        \
+    g_checks++;                                                               \
+    if (!(x)) {                                                               \
+      g_failed++;                                                             \
+      std::fprintf(stderr, "FAILED %s:%d: %s\n", __FILE__, __LINE__, #x);     \
+    }                                                                         \
+  } while (0)
+#define EXPECT_EQ(a, b) EXPECT_TRUE((a) == (b))
+
+// ---- seeded inputs (shape of lib/random.h:37-110) ------------------------------------
+static std::uint64_t g_ctr = 0;
+static std::uint64_t Rand() { return ksc::Mix64(0xC0FFEE00 + g_ctr++); }
+
+template <int K>
+std::string RandomRead() {
+  std::string s;
+  const int n = 1 + int(Rand() % 100);
+  for (int j = 0; j < n; j++) s += Kmer<K>(Rand() & (~std::uint64_t(0) >> (64 - 2 * K))).String();
+  if (Rand() % 2 == 0) s += s;  // creates a loop
+  return s;
+}
+
+template <int K, int N, typename KeyType>
+KmerSet<K, N, KeyType> RandomKmerSet(int n, bool canonical) {
+  std::set<std::uint64_t> kmers;
+  while (static_cast<int>(kmers.size()) < n) {
+    const std::string s = RandomRead<K>();
+    for (int j = 0; j + K <= static_cast<int>(s.size()) && static_cast<int>(kmers.size()) < n; j++) {
+      Kmer<K> kmer(s.substr(j, K));
+      if (canonical) kmer = kmer.Canonical();
+      kmers.insert(kmer.Bits());
+    }
+  }
+  return KmerSet<K, N, KeyType>::FromSortedBits(std::vector<std::uint64_t>(kmers.begin(), kmers.end()));
+}
+
+// A correlated family: one random genome, point substitutions per member.
+template <int K, int N, typename KeyType>
+std::vector<KmerSet<K, N, KeyType>> Family(int n_sets, int length) {
+  std::string genome;
+  for (int i = 0; i < length; i++) genome += "ACGT"[Rand() % 4];
+  std::vector<KmerSet<K, N, KeyType>> out;
+  for (int s = 0; s < n_sets; s++) {
+    std::string g = genome;
+    for (int i = 0; i < length; i++)
+      if (Rand() % 300 == 0) g[i] = "ACGT"[Rand() % 4];
+    std::set<std::uint64_t> kmers;
+    for (int j = 0; j + K <= length; j++) kmers.insert(Kmer<K>(g.substr(j, K)).Canonical().Bits());
+    out.push_back(KmerSet<K, N, KeyType>::FromSortedBits(std::vector<std::uint64_t>(kmers.begin(), kmers.end())));
+  }
+  return out;
+}
+
+// ---- test/kmer.cc ----------------------------------------------------------------------
+static void TestKmer() {
+  EXPECT_EQ(Kmer<5>("AGCTG").String(), "AGCTG");
+  EXPECT_EQ(Kmer<5>("AAAAT").Canonical().String(), "AAAAT");
+  EXPECT_EQ(Kmer<5>("TTTTA").Canonical().String(), "TAAAA");
+  EXPECT_EQ(Kmer<5>("CCCCG").Canonical().String(), "CCCCG");
+  EXPECT_EQ(Kmer<5>("GGGGC").Canonical().String(), "GCCCC");
+  EXPECT_EQ(Kmer<5>("AGCTA").Complement().String(), "TAGCT");
+  EXPECT_EQ(Kmer<5>("AGCTG").Next('C').String(), "GCTGC");
+  EXPECT_EQ(Kmer<5>("AGCTG").Prev('C').String(), "CAGCT");
+  EXPECT_EQ(internal::Complement("ACGTT"), "AACGT");  // test/spss.cc:13
+}
+
+// ---- test/kmer_set.cc ---------------------------------------------------------------------
+static void TestKmerSet() {
+  const int K = 5, N = 3;
+  using KeyType = std::uint8_t;
+  {
+    Kmer<K> kmer("AGCTG");
+    int bucket;
+    KeyType key;
+    std::tie(bucket, key) = GetBucketAndKeyFromKmer<K, N, KeyType>(kmer);
+    EXPECT_EQ(kmer.String(), (GetKmerFromBucketAndKey<K, N, KeyType>(bucket, key)).String());
+  }
+  {
+    Kmer<K> kmer("AAAAA");
+    KmerSet<K, N, KeyType> s;
+    EXPECT_EQ(s.Size(), 0);
+    EXPECT_TRUE(!s.Contains(kmer));
+    s.Add(kmer);
+    EXPECT_EQ(s.Size(), 1);
+    EXPECT_TRUE(s.Contains(kmer));
+    s.Remove(kmer);
+    EXPECT_EQ(s.Size(), 0);
+    EXPECT_TRUE(!s.Contains(kmer));
+  }
+  {
+    KmerSet<K, N, KeyType> s;
+    s.Add(Kmer<K>("AAAAA"));
+    s.Add(Kmer<K>("CCCCC"));
+    auto a = s.Find([](const Kmer<K>& k) { return k.String()[0] == 'A'; }, 1);
+    EXPECT_EQ(a.size(), 1u);
+    EXPECT_EQ(a[0].String(), "AAAAA");
+    auto c = s.Find([](const Kmer<K>& k) { return k.String()[1] == 'C'; }, 1);
+    EXPECT_EQ(c.size(), 1u);
+    EXPECT_EQ(c[0].String(), "CCCCC");
+  }
+  {
+    KmerSet<K, N, KeyType> s1, s2;
+    for (const char* x : {"AAAAA", "TTTTT", "CCCCC"}) s1.Add(Kmer<K>(x));
+    for (const char* x : {"AAAAA", "TTTTT", "GGGGG"}) s2.Add(Kmer<K>(x));
+    EXPECT_EQ(Add(s1, s2, 1).Size(), 4);
+    EXPECT_EQ(Sub(s1, s2, 1).Size(), 1);
+    EXPECT_EQ(Sub(s2, s1, 1).Size(), 1);
+    EXPECT_EQ(Intersection(s2, s1, 1).Size(), 2);
+    EXPECT_EQ(Intersection(s1, s2, 1).Size(), 2);
+  }
+  {
+    KmerSet<K, N, KeyType> s1, s2, s3;
+    for (const char* x : {"AAAAA", "TTTTT"}) {
+      s1.Add(Kmer<K>(x));
+      s2.Add(Kmer<K>(x));
+    }
+    for (const char* x : {"AAAAA", "CCCCC", "GGGGG"}) s3.Add(Kmer<K>(x));
+    EXPECT_TRUE(s1.Equals(s1, 1) && s2.Equals(s2, 1) && s3.Equals(s3, 1));
+    EXPECT_TRUE(s1.Equals(s2, 1) && s2.Equals(s1, 1));
+    EXPECT_TRUE(!s1.Equals(s3, 1) && !s3.Equals(s1, 1));
+  }
+}
+
+// ---- test/spss.cc ----------------------------------------------------------------------------
+template <int K, int N, typename KeyType>
+static void CheckStrings(const std::vector<std::string>& strings, const KmerSet<K, N, KeyType>& want) {
+  std::set<std::uint64_t> seen;
+  bool ok = true;
+  for (const std::string& s : strings) {
+    if (static_cast<int>(s.length()) < K) ok = false;
+    for (int i = 0; i + K <= static_cast<int>(s.length()); i++)
+      if (!seen.insert(Kmer<K>(s.substr(i, K)).Canonical().Bits()).second) ok = false;  // no k-mer twice
+  }
+  EXPECT_TRUE(ok);
+  auto got = KmerSet<K, N, KeyType>::FromSortedBits(std::vector<std::uint64_t>(seen.begin(), seen.end()));
+  EXPECT_TRUE(want.Equals(got, 1));
+}
+
+static void TestSpss() {
+  const int K = 9, N = 10;
+  using KeyType = std::uint8_t;
+  for (int size : {1, 300, 20000, 65536}) {
+    auto s = RandomKmerSet<K, N, KeyType>(size, true);
+    CheckStrings(GetUnitigsCanonical(s, 4), s);
+    const auto spss = GetSPSSCanonical(s, true, 4);
+    CheckStrings(spss, s);
+    EXPECT_TRUE(s.Equals(GetKmerSetFromSPSS<K, N, KeyType>(spss, true, 4), 4));
+  }
+  {  // outputs of the reference's own headers
+    auto of = [](const std::string& seq) {
+      std::set<std::uint64_t> k;
+      for (int i = 0; i + 5 <= static_cast<int>(seq.size()); i++) k.insert(Kmer<5>(seq.substr(i, 5)).Canonical().Bits());
+      return KmerSet<5, 3, std::uint8_t>::FromSortedBits(std::vector<std::uint64_t>(k.begin(), k.end()));
+    };
+    auto a = of("AACCGTTAGCAT");
+    EXPECT_EQ(a.Size(), 8);
+    EXPECT_EQ(a.Hash(1), 493u);
+    EXPECT_TRUE((GetSPSSCanonical(a, true, 1) == std::vector<std::string>{"ATGCTAACGGTT"}));
+    auto b = of("ACGTACGTACG");
+    EXPECT_EQ(b.Hash(1), 477u);
+    EXPECT_TRUE((GetSPSSCanonical(b, true, 1) == std::vector<std::string>{"GTACGT"}));
+    EXPECT_EQ(of("AAAAAAAAA").Hash(1), 0u);
+  }
+}
+
+// ---- test/kmer_set_compact.cc -----------------------------------------------------------------------
+static void TestCompact() {
+  const int K = 9, N = 10;
+  using KeyType = std::uint8_t;
+  const auto s = RandomKmerSet<K, N, KeyType>(100000, true);
+  const auto c = KmerSetCompact<K, N, KeyType>::FromKmerSet(s, true, true, 4);
+  const std::string file = (std::filesystem::temp_directory_path() / "ksc_test_compact.txt").string();
+  EXPECT_TRUE(c.Dump(file, "", 4).ok());
+  {
+    auto loaded = KmerSetCompact<K, N, KeyType>::Load(file, "");
+    EXPECT_TRUE(loaded.ok());
+    EXPECT_TRUE(s.Equals(loaded.value().ToKmerSet(true, 4), 4));
+  }
+  {
+    auto loaded = KmerSetCompact<K, N, KeyType>::Load(file, "cat");  // through a (de)compressor pipe
+    EXPECT_TRUE(loaded.ok());
+    EXPECT_TRUE(s.Equals(loaded.value().ToKmerSet(true, 4), 4));
+  }
+  EXPECT_TRUE((!KmerSetCompact<K, N, KeyType>::Load(file + ".missing", "").ok()));
+  EXPECT_EQ(s.Size(), c.Size(4));
+  EXPECT_TRUE(s.Equals(c.ToKmerSet(true, 4), 4));
+  std::vector<int> ids;
+  for (int i = (1 << N) - 1; i >= 0; i--) ids.push_back(i);
+  const auto sampled = c.GetSampledKmerSet(ids, true, 4);
+  KmerSet<K, N, KeyType> rebuilt;
+  bool sorted = true;
+  for (std::size_t i = 0; i < ids.size(); i++) {
+    for (std::size_t j = 1; j < sampled[i].size(); j++) sorted = sorted && sampled[i][j - 1] < sampled[i][j];
+    for (KeyType key : sampled[i]) rebuilt.Add(GetKmerFromBucketAndKey<K, N, KeyType>(ids[i], key));
+  }
+  EXPECT_TRUE(sorted);
+  EXPECT_TRUE(s.Equals(rebuilt, 4));
+  std::filesystem::remove(file);
+}
+
+// ---- test/kmer_set_set.cc -------------------------------------------------------------------------------
+template <int K, int N, typename KeyType>
+static void TestSetSet(int n_sets, int length) {
+  auto sets = Family<K, N, KeyType>(n_sets, length);
+  std::vector<KmerSetCompact<K, N, KeyType>> compacts;
+  for (const auto& s : sets) compacts.push_back(KmerSetCompact<K, N, KeyType>::FromKmerSet(s, true, true, 4));
+  KmerSetSet<K, N, KeyType> kss(compacts, true, 4);
+  EXPECT_TRUE(kss.Size() >= n_sets);
+  for (int i = 0; i < n_sets; i++) EXPECT_TRUE(kss.Get(i, true, 4).Equals(sets[i], 4));
+  const std::string dir = (std::filesystem::temp_directory_path() / "ksc_test_kss").string();
+  std::filesystem::remove_all(dir);
+  EXPECT_TRUE(kss.Dump(dir, "", "txt", 4).ok());
+  EXPECT_TRUE(kss.DumpGraph(dir + "/graph.dot").ok());
+  auto loaded = KmerSetSet<K, N, KeyType>::Load(dir, "", "txt", 4);
+  EXPECT_TRUE(loaded.ok());
+  EXPECT_EQ(loaded.value().Size(), kss.Size());
+  for (int i = 0; i < kss.Size(); i++)
+    EXPECT_TRUE(kss.Get(i, true, 4).Equals(loaded.value().Get(i, true, 4), 4));
+  auto reader = KmerSetSetReader<K, N, KeyType>::FromDirectory(dir, "txt", "", true);
+  EXPECT_TRUE(reader.ok());
+  EXPECT_EQ(reader.value().Size(), kss.Size());
+  for (int i = 0; i < n_sets; i++) {
+    auto got = reader.value().Get(i, 4);
+    EXPECT_TRUE(got.ok());
+    EXPECT_TRUE(got.value().Equals(sets[i], 4));
+  }
+  std::printf("  KmerSetSet<%d,%d>: %d -> %d nodes, %zu merges, N_proc = %lld\n", K, N, n_sets, kss.Size(),
+              kss.Iterations().size(), static_cast<long long>(kss.ProcessedKmers()));
+  std::filesystem::remove_all(dir);
+}
+
+int main() {
+  try {
+    TestKmer();
+    TestKmerSet();
+    TestSpss();
+    TestCompact();
+    TestSetSet<15, 14, std::uint16_t>(8, 20000);
+    TestSetSet<23, 14, std::uint32_t>(6, 30000);
+    TestSetSet<31, 14, std::uint64_t>(4, 20000);
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "exception: %s\n", e.what());
+    return 2;
+  }
+  std::printf("%d checks, %d failed\n", g_checks, g_failed);
+  return g_failed ? 1 : 0;
+}

@@ -322,6 +322,12 @@ int ksh_memcpy_d2h(int device, void* dst, const void* d_src, size_t bytes) {
   return KSH_OK;
 }
 
+int ksh_memcpy_d2d(int device, void* d_dst, const void* d_src, size_t bytes) {
+  KSH_HIP(hipSetDevice(device));
+  if (bytes) KSH_HIP(hipMemcpy(d_dst, d_src, bytes, hipMemcpyDeviceToDevice));
+  return KSH_OK;
+}
+
 int ksh_ctx_create(int device, void* stream, ksh_ctx** out) {
   if (!out) return fail(KSH_INVALID_ARGUMENT, "out is NULL");
   *out = nullptr;

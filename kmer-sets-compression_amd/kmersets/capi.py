@@ -75,6 +75,7 @@ def lib():
         "ksh_free": (C.c_int, [C.c_int, vp]),
         "ksh_memcpy_h2d": (C.c_int, [C.c_int, vp, vp, C.c_size_t]),
         "ksh_memcpy_d2h": (C.c_int, [C.c_int, vp, vp, C.c_size_t]),
+        "ksh_memcpy_d2d": (C.c_int, [C.c_int, vp, vp, C.c_size_t]),
         "ksh_ctx_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
         "ksh_ctx_destroy": (C.c_int, [vp]),
         "ksh_ctx_sync": (C.c_int, [vp]),

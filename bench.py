@@ -15,10 +15,14 @@ the same-size batch on its own family (weak scaling), then the per-pair diff
 sizes are all-gathered over RCCL (the exchange step north_star names).
 
 Prints ONE JSON line on rank 0.  `roofline` is the write-pass merge kernel
-(k_tile_merge<.., true>): algorithmic bytes (|A| + |B| + |A u B|) * key_bytes per
-launch over its HIP-event duration, against the 8 TB/s HBM peak.  `cpu_baseline`
-times the oracle's restatement of the reference's hash-set algebra on the host
-(rank 0, N = 1 only, bounded sample).
+(k_tile_merge<KeyT, 1>): algorithmic bytes (|A| + |B| + |A u B|) * key_bytes per
+launch over its HIP-event duration, against the 8 TB/s HBM peak; `traffic` is filled
+from profiles/pmc_traffic.json when that file holds a PMC measurement (rocprofv3
+--pmc FETCH_SIZE / WRITE_SIZE passes) of the same kernel on the same workload.
+`cpu_baseline` times the oracle's restatement of the reference's hash-set algebra on
+the host (rank 0, N = 1 only, bounded sample).  `spss` (outside the timed region) runs
+the whole KmerSetSet loop once on the same sets and reports the second half of the
+metric: bytes/k-mer after SPSS.
 """
 import argparse
 import json
@@ -45,6 +49,7 @@ def main():
     ap.add_argument("--size", type=float, default=1e7, help="k-mers per set")
     ap.add_argument("--seed", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-spss", action="store_true", help="skip the untimed KmerSetSet run")
     ap.add_argument("--two-pass", action="store_true",
                     help="use ksh_pair_plan + allocate + ksh_pair_write (exact-size outputs) "
                          "instead of the one-call ksh_pair_algebra (upper-bound outputs)")
@@ -166,11 +171,40 @@ def main():
                       "workload, full size, set construction excluded, %.1f s of CPU" % (used, spent),
         }
 
+    spss = None
+    if rank == 0 and world == 1 and not args.no_spss:
+        compacts = [ctx.spss_encode(s, mode=0) for s in sets]
+        ids = synth.sample_bucket_ids(nbits, seed=args.seed + 1)
+        torch.cuda.synchronize()
+        l0 = time.perf_counter()
+        kss = capi.DeviceKmerSetSet(ctx, compacts, ids)
+        torch.cuda.synchronize()
+        lwall = time.perf_counter() - l0
+        st = kss.stats()
+        total = sum(s.n_keys for s in sets)
+        spss = {
+            "bytes_per_kmer": (st["packed_bytes"] + st["strings"]) / total,
+            "chars_per_kmer_before": st["initial_spss_weight"] / total,
+            "chars_per_kmer_after": st["final_spss_weight"] / total,
+            "nodes": st["nodes"], "iterations": int(kss.trace()[0].shape[0]),
+            "loop_mkmers_per_s": st["n_processed"] / lwall / 1e6, "loop_wall_ms": lwall * 1e3,
+            "note": "whole KmerSetSet constructor on the same %d sets, one run, outside the timed "
+                    "region; bytes = sum ceil(2 * Weight / 8) + 1 byte per string length" % n_sets,
+        }
+        kss.close()
+
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if rank == 0 and os.path.exists(pmc_file):
+        pmc = json.load(open(pmc_file))
+        if pmc.get("kernel") == "k_tile_merge<KeyT, 1>" and pmc.get("kmers_per_set") == size \
+                and pmc.get("k") == k and pmc.get("sets") == n_sets:
+            traffic, traffic_src = pmc["bytes_per_launch"], "profiles/pmc_traffic.json"
+
     if rank == 0:
         achieved = algo_bytes[0] / (write_ms * 1e-3) / 1e9 if write_ms > 0 else 0.0
         out = {
-            "metric": "Mk-mers/s processed in kmerset-multiple-compress (pair set-algebra stage); "
-                      "bytes/k-mer after SPSS not yet measured",
+            "metric": "Mk-mers/s processed in kmerset-multiple-compress; bytes/k-mer after SPSS",
             "value": value,
             "unit": "Mk-mers/s",
             "n_gpus": world,
@@ -198,13 +232,15 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "launches": int(write_launches),
                 "avg_launch_ms": write_ms / max(write_launches, 1),
                 "algorithmic_bytes_per_launch": algo_bytes[0] / max(write_launches, 1),
                 "count_pass_avg_launch_ms": (count_ms / count_launches) if count_launches else None,
             },
             "cpu_baseline": cpu_baseline,
+            "spss": spss,
         }
         print(json.dumps(out))
     if world > 1:

@@ -183,13 +183,13 @@ def main():
         st = kss.stats()
         total = sum(s.n_keys for s in sets)
         spss = {
-            "bytes_per_kmer": (st["packed_bytes"] + st["strings"]) / total,
+            "bytes_per_kmer": (st["packed_bytes"] + st["length_bytes"]) / total,
             "chars_per_kmer_before": st["initial_spss_weight"] / total,
             "chars_per_kmer_after": st["final_spss_weight"] / total,
             "nodes": st["nodes"], "iterations": int(kss.trace()[0].shape[0]),
             "loop_mkmers_per_s": st["n_processed"] / lwall / 1e6, "loop_wall_ms": lwall * 1e3,
             "note": "whole KmerSetSet constructor on the same %d sets, one run, outside the timed "
-                    "region; bytes = sum ceil(2 * Weight / 8) + 1 byte per string length" % n_sets,
+                    "region; bytes = sum over nodes of ceil(2 * Weight / 8) + StreamVByte-0124 size of the lengths" % n_sets,
         }
         kss.close()
 

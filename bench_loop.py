@@ -71,7 +71,7 @@ def main():
         "sum_input_kmers": sum(sizes),
         "chars_per_kmer_before": st["initial_spss_weight"] / sum(sizes),
         "chars_per_kmer_after": st["final_spss_weight"] / sum(sizes),
-        "bytes_per_kmer_after_spss": (st["packed_bytes"] + st["strings"]) / sum(sizes),
+        "bytes_per_kmer_after_spss": (st["packed_bytes"] + st["length_bytes"]) / sum(sizes),
         "config": {"workload": "%d canonical k=%d sets of %d k-mers, full KmerSetSet loop" % (n_sets, k, size),
                    "input_build_s": t_inputs},
     }

@@ -164,6 +164,15 @@ int ksh_spss_decode_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s
 int ksh_spss_decode_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int canonical,
                           int64_t* d_offsets, void* d_keys, int64_t* n_keys);
 
+/* ---- StreamVByte "0124" pack of the string lengths ---------------------------------------
+ * The in-memory form of KmerSetCompact::lengths_compressed_
+ * (lib/core/kmer_set_compact.h:257-265 streamvbyte_encode_0124, :269-287 decode; format in
+ * csrc/ksh_svb.hip).  encode: d_out holds ceil(n/4) + 4n bytes (streamvbyte_max_compressedbytes)
+ * or is NULL to get the size only; *bytes = compressed size.  decode: n values out. */
+int ksh_svb_encode_0124(ksh_ctx* ctx, const uint32_t* d_in, int64_t n, uint8_t* d_out, int64_t* bytes);
+int ksh_svb_decode_0124(ksh_ctx* ctx, const uint8_t* d_in, int64_t n, uint32_t* d_out,
+                        int64_t* bytes_read);
+
 /* ---- SPSS encode ----------------------------------------------------------------------
  * mode 0: KmerSetCompact::FromKmerSet(set, canonical = true, fast = true)
  *         = GetSPSSCanonical (lib/core/spss.h:1835-1858: unitigs, greedy path cover,
@@ -211,7 +220,9 @@ int ksh_kss_trace(const ksh_kss* k, int64_t* n_iterations, const int64_t** rows,
                   const float** improvements);
 int ksh_kss_initial_weights(const ksh_kss* k, const int64_t** weights, int64_t* n);
 /* stats = { initial total_size, final total_size, initial total_spss_weight, N_proc
- * (SURVEY.md 8d), final total_spss_weight, sum ceil(2 Weight / 8) bytes, strings, nodes }. */
+ * (SURVEY.md 8d), final total_spss_weight, sum over nodes of ceil(2 Weight / 8) bytes, sum
+ * over nodes of the StreamVByte-0124 size of the lengths, nodes }: bytes/k-mer after SPSS =
+ * (stats[5] + stats[6]) / sum of the input set sizes (metric 2). */
 int ksh_kss_stats(const ksh_kss* k, int64_t stats[8]);
 /* KmerSetSet::Get(i) (:433-454): union over the nodes reachable from i.  Returns new
  * device buffers (release with ksh_free). */

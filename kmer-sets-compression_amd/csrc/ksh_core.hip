@@ -165,13 +165,38 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_add(int64_t* __restrict__
   }
 }
 
-__global__ void k_store_total(const int64_t* __restrict__ block_prefix_last,
-                              const int64_t* __restrict__ block_sums_last, int64_t* total) {
-  *total = *block_prefix_last + *block_sums_last;
+// Second (last) launch of the mid-size scan: every block sums the totals of the blocks
+// before it (at most kScanFixMaxBlocks values) and adds that base to its tile.
+constexpr int64_t kScanFixMaxBlocks = 4096;
+
+__global__ __launch_bounds__(kScanThreads) void k_scan_fix(int64_t* __restrict__ out,
+                                                            const int64_t* __restrict__ block_sums,
+                                                            int64_t n, int64_t n_blocks,
+                                                            int64_t* __restrict__ total_out) {
+  __shared__ int64_t lds4[4];
+  int64_t mine = 0;
+  const int64_t upto = total_out && blockIdx.x == 0 ? n_blocks : int64_t(blockIdx.x);
+  for (int64_t b = threadIdx.x; b < upto; b += kScanThreads) mine += block_sums[b];
+  // block reduce
+  int64_t acc = mine;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d, 64);
+  if ((threadIdx.x & 63) == 0) lds4[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  const int64_t sum = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+  if (blockIdx.x == 0) {
+    if (total_out && threadIdx.x == 0) *total_out = sum;  // block 0 summed every block
+    return;                                                // its own base is 0
+  }
+  const int64_t base = int64_t(blockIdx.x) * kScanTile + int64_t(threadIdx.x) * kScanItems;
+#pragma unroll
+  for (int i = 0; i < kScanItems; i++) {
+    if (base + i < n) out[base + i] += sum;
+  }
 }
 
 // Small inputs (bucket counts, tile counts): one 1024-thread workgroup, one launch.
-constexpr int64_t kScanSmallMax = 20000;  // beyond this one CU's bandwidth is the limit
+constexpr int64_t kScanSmallMax = 16640;  // bucket-count scans; beyond this one CU's bandwidth is the limit
 
 __global__ __launch_bounds__(1024) void k_scan_small(const int64_t* __restrict__ in,
                                                       int64_t* __restrict__ out, int64_t n,
@@ -212,6 +237,16 @@ int scan_exclusive_i64(ksh_ctx* ctx, const int64_t* d_in, int64_t* d_out, int64_
     return KSH_OK;
   }
   const int64_t blocks = (n + kScanTile - 1) / kScanTile;
+  if (blocks <= kScanFixMaxBlocks) {
+    int64_t* bsums = static_cast<int64_t*>(arena_alloc(ctx, size_t(blocks) * sizeof(int64_t)));
+    if (!bsums) return fail(KSH_INTERNAL, "scan: scratch arena too small");
+    hipLaunchKernelGGL(k_scan_tiles, dim3(unsigned(blocks)), dim3(kScanThreads), 0, ctx->stream, d_in,
+                       d_out, bsums, n);
+    hipLaunchKernelGGL(k_scan_fix, dim3(unsigned(blocks)), dim3(kScanThreads), 0, ctx->stream, d_out,
+                       bsums, n, blocks, d_total);
+    KSH_HIP(hipGetLastError());
+    return KSH_OK;
+  }
   int64_t* sums = static_cast<int64_t*>(arena_alloc(ctx, size_t(blocks) * sizeof(int64_t)));
   int64_t* sums_total = static_cast<int64_t*>(arena_alloc(ctx, sizeof(int64_t)));
   if (!sums || !sums_total) return fail(KSH_INTERNAL, "scan: scratch arena too small");

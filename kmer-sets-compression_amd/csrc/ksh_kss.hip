@@ -361,13 +361,15 @@ int ksh_kss_stats(const ksh_kss* k, int64_t stats[8]) {
   stats[2] = k->initial_spss_weight;
   stats[3] = k->n_processed;
   stats[4] = k->final_spss_weight;
-  int64_t bytes = 0, strings = 0;
+  int64_t bytes = 0, len_bytes = 0;
   for (const KssCompact& c : k->compacts) {
     bytes += (2 * c.n_bases + 7) / 8;
-    strings += c.n_strings;
+    int64_t b = 0;
+    KSH_TRY(ksh_svb_encode_0124(k->ctx, c.lens, c.n_strings, nullptr, &b));
+    len_bytes += b;
   }
-  stats[5] = bytes;    // sum over nodes of ceil(2 * Weight / 8)
-  stats[6] = strings;  // sum over nodes of the string count (the lengths' side)
+  stats[5] = bytes;      // sum over nodes of ceil(2 * Weight / 8)
+  stats[6] = len_bytes;  // sum over nodes of |lengths_compressed| (StreamVByte 0124)
   stats[7] = int64_t(k->compacts.size());
   return KSH_OK;
 }

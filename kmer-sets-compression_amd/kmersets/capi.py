@@ -100,6 +100,8 @@ def lib():
         "ksh_spss_encode_release": (C.c_int, [vp]),
         "ksh_set_union_plan": (C.c_int, [vp, GP, SP, SP, vp, C.POINTER(i64)]),
         "ksh_set_union_write": (C.c_int, [vp, GP, SP, SP, vp]),
+        "ksh_svb_encode_0124": (C.c_int, [vp, vp, i64, vp, C.POINTER(i64)]),
+        "ksh_svb_decode_0124": (C.c_int, [vp, vp, i64, vp, C.POINTER(i64)]),
         "ksh_kss_build": (C.c_int, [vp, GP, C.POINTER(SpssView), i32, C.POINTER(i32), i32, C.c_int,
                                     i32, C.POINTER(vp)]),
         "ksh_kss_destroy": (C.c_int, [vp]),
@@ -366,6 +368,28 @@ class Context:
             o.n_keys = int(n)
         return outs
 
+    def svb_encode(self, values):
+        """StreamVByte-0124 bytes of a uint32 array (device round trip)."""
+        import torch
+
+        v = np.ascontiguousarray(values, dtype=np.uint32)
+        d_in = torch.from_numpy(v.view(np.int32).copy()).to(self.device) if v.size else torch.zeros(1, dtype=torch.int32, device=self.device)
+        cap = (v.size + 3) // 4 + 4 * v.size
+        d_out = torch.empty(max(cap, 16), dtype=torch.uint8, device=self.device)
+        n = C.c_int64()
+        check(lib().ksh_svb_encode_0124(self.h, d_in.data_ptr(), v.size, d_out.data_ptr(), C.byref(n)))
+        return d_out[: n.value].cpu().numpy()
+
+    def svb_decode(self, data, n):
+        import torch
+
+        d = np.ascontiguousarray(data, dtype=np.uint8)
+        d_in = torch.from_numpy(d.copy()).to(self.device) if d.size else torch.zeros(16, dtype=torch.uint8, device=self.device)
+        d_out = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        used = C.c_int64()
+        check(lib().ksh_svb_decode_0124(self.h, d_in.data_ptr(), n, d_out.data_ptr(), C.byref(used)))
+        return d_out[:n].cpu().numpy().view(np.uint32), used.value
+
     def set_union(self, a, b):
         """KmerSet::Add: A | B as a new DeviceSet."""
         import torch
@@ -497,7 +521,7 @@ class DeviceKmerSetSet:
         st = (C.c_int64 * 8)()
         check(lib().ksh_kss_stats(self.h, st))
         keys = ["initial_total_size", "final_total_size", "initial_spss_weight", "n_processed",
-                "final_spss_weight", "packed_bytes", "strings", "nodes"]
+                "final_spss_weight", "packed_bytes", "length_bytes", "nodes"]
         return dict(zip(keys, [int(x) for x in st]))
 
     def get_kmers(self, i):

@@ -165,3 +165,25 @@ def test_encode_roundtrip_large(ctx):
         un = ctx.spss_encode(s, mode=1)
         assert un.n_strings >= sp.n_strings
         assert ctx.set_diff(ctx.spss_decode(un), s) == 0
+
+
+def test_streamvbyte_0124(ctx):
+    """kmer_set_compact.h:257-265,272: device pack/unpack of the lengths vs the oracle's codec,
+    byte for byte, and the compact's in-memory lengths of an encoded set."""
+    L = ol.lib()
+    rng = np.random.default_rng(5)
+    for n in (0, 1, 3, 4, 5, 1000, 100003):
+        v = rng.choice(np.array([0, 1, 7, 255, 256, 65535, 65536, 2**32 - 1], dtype=np.uint32), size=n)
+        v = np.ascontiguousarray(v, dtype=np.uint32)
+        want = np.zeros(max(1, L.ko_svb_max_compressed_bytes(n)), dtype=np.uint8)
+        size = L.ko_svb_encode_0124(v if n else np.zeros(1, np.uint32), n, want)
+        got = ctx.svb_encode(v)
+        assert got.size == size and np.array_equal(got, want[:size])
+        back, used = ctx.svb_decode(got, n)
+        assert used == size and np.array_equal(back, v)
+    k, n_bits, kb = 23, 14, 4
+    kmers = synth.phylogeny_sets(k, 1, 20000, seed=8)[0]
+    oset = ol.Set.from_kmers(k, n_bits, kb, np.setdiff1d(kmers, kmers[::7]))
+    sp = ctx.spss_encode(dev_set(ctx, k, n_bits, oset.kmers()), mode=0)
+    lens = sp.lens[: sp.n_strings].cpu().numpy().view(np.uint32)
+    assert np.array_equal(ctx.svb_encode(lens), oset.compact().lengths_compressed())

@@ -69,13 +69,22 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
+    # Rehearsal on a one-GPU box: KSH_BENCH_BACKEND=gloo puts every rank on cuda:0 and runs
+    # the collectives on CPU tensors (RCCL refuses two ranks on one device).
+    backend = os.environ.get("KSH_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
 
     from kmersets import capi, synth
 
@@ -90,7 +99,7 @@ def main():
     pairs = [(i, j) for i in range(n_sets) for j in range(i + 1, n_sets)]
     units_per_step = sum(sets[i].n_keys + sets[j].n_keys for i, j in pairs)
 
-    diff_local = torch.zeros(len(pairs), dtype=torch.int64, device=dev)
+    diff_local = torch.zeros(len(pairs), dtype=torch.int64, device=coll_dev)
     gathered = [torch.zeros_like(diff_local) for _ in range(world)] if world > 1 else None
     algo_bytes = [0.0]
 
@@ -130,10 +139,10 @@ def main():
     ctx.enable_timing(False)
 
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        u = torch.tensor([units_per_step], dtype=torch.int64, device=dev)
+        u = torch.tensor([units_per_step], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(u, op=dist.ReduceOp.SUM)
         total_units_per_step = int(u.item())
     else:

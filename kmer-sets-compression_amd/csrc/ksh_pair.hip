@@ -190,7 +190,7 @@ __global__ __launch_bounds__(kThreads) void k_tile_merge(
     const TileDesc* __restrict__ desc, const int64_t* __restrict__ total_tiles,
     int64_t* __restrict__ tile_m, const int64_t* __restrict__ tile_ioff, KeyT* __restrict__ out_i,
     KeyT* __restrict__ out_amb, KeyT* __restrict__ out_bma) {
-  __shared__ KeyT lds[kTileCap];
+  __shared__ KeyT lds[kTileCap + 1];  // + 1: a clamped read past an empty B range stays inside
 
   const int64_t t = blockIdx.x;
   constexpr bool kWrite = kMode != 0;
@@ -217,32 +217,36 @@ __global__ __launch_bounds__(kThreads) void k_tile_merge(
   }
   int i = lo, j = d0 - lo;
 
+  // Branch-free merge: both heads are (re)loaded every step with clamped indices and the
+  // lane advances one of them; divergent lanes would otherwise execute both sides of every
+  // branch.  last_a is the A key merged just before (possibly by the previous lane): a B
+  // key equal to it is the second half of a common pair.
   KeyT vals[kVT];
   uint32_t cls_bits = 0;  // 2 bits per step: 0 = A&B, 1 = A\B, 2 = B\A, 3 = nothing
   int n_i = 0, n_a = 0, n_b = 0;
+  bool has_last = i > 0;
+  KeyT last_a = sa[has_last ? i - 1 : 0];
 #pragma unroll
   for (int step = 0; step < kVT; step++) {
-    uint32_t c = 3;
-    KeyT v = KeyT(0);
-    if (d0 + step < d1) {
-      const bool has_a = i < ca, has_b = j < cb;
-      const KeyT av = has_a ? sa[i] : KeyT(0);
-      const KeyT bv = has_b ? sb[j] : KeyT(0);
-      if (has_a && (!has_b || av <= bv)) {
-        v = av;
-        c = (has_b && av == bv) ? 0u : 1u;
-        i++;
-      } else {
-        v = bv;
-        c = (i > 0 && sa[i - 1] == bv) ? 3u : 2u;
-        j++;
-      }
-    }
-    vals[step] = v;
+    const bool active = d0 + step < d1;
+    const bool has_a = i < ca, has_b = j < cb;
+    const KeyT av = sa[has_a ? i : 0];
+    const KeyT bv = sb[has_b ? j : 0];
+    const bool take_a = has_a && (!has_b || av <= bv);
+    const bool eq_ab = has_a && has_b && av == bv;
+    const bool eq_prev = has_last && last_a == bv;
+    uint32_t c = take_a ? (eq_ab ? 0u : 1u) : (eq_prev ? 3u : 2u);
+    c = active ? c : 3u;
+    vals[step] = take_a ? av : bv;
     cls_bits |= c << (2 * step);
     n_i += c == 0;
     n_a += c == 1;
     n_b += c == 2;
+    const bool adv_a = take_a && active;
+    last_a = adv_a ? av : last_a;
+    has_last = has_last || adv_a;
+    i += adv_a ? 1 : 0;
+    j += (!take_a && active) ? 1 : 0;
   }
 
   // wave scan of the three counts, packed into one word
@@ -282,9 +286,11 @@ __global__ __launch_bounds__(kThreads) void k_tile_merge(
 #pragma unroll
   for (int step = 0; step < kVT; step++) {
     const uint32_t c = (cls_bits >> (2 * step)) & 3;
-    if (c == 0) lds[p_i++] = vals[step];
-    else if (c == 1) lds[p_a++] = vals[step];
-    else if (c == 2) lds[p_b++] = vals[step];
+    const int pos = c == 0 ? p_i : (c == 1 ? p_a : p_b);
+    if (c != 3) lds[pos] = vals[step];
+    p_i += c == 0;
+    p_a += c == 1;
+    p_b += c == 2;
   }
   __syncthreads();
   if (out_i) {

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <iterator>
 #include <type_traits>
 
 namespace ksh {
@@ -73,6 +74,62 @@ int slot_reserve(ksh_ctx* ctx, int which, size_t bytes) {
   KSH_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->slot[which]), want));
   ctx->slot_bytes[which] = want;
   return KSH_OK;
+}
+
+static size_t pool_round(size_t bytes) {
+  if (bytes < 4096) return 4096;
+  size_t gran = 4096;
+  while (gran * 16 <= bytes) gran <<= 1;  // gran in (bytes/16, bytes/8]: at most 12.5 % slack
+  return (bytes + gran - 1) / gran * gran;
+}
+
+int pool_alloc(ksh_ctx* ctx, size_t bytes, void** out) {
+  const size_t want = pool_round(bytes);
+  auto it = ctx->pool_free_blocks.lower_bound(want);
+  if (it != ctx->pool_free_blocks.end() && it->first <= want + want / 4) {
+    *out = it->second;
+    ctx->pool_cached_bytes -= it->first;
+    ctx->pool_free_blocks.erase(it);
+    return KSH_OK;
+  }
+  hipError_t e = hipMalloc(out, want);
+  if (e != hipSuccess) {
+    pool_trim(ctx);  // give the cached blocks back and retry once
+    e = hipMalloc(out, want);
+    if (e != hipSuccess)
+      return fail(KSH_INTERNAL, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+  }
+  ctx->pool_sizes[*out] = want;
+  return KSH_OK;
+}
+
+void pool_free(ksh_ctx* ctx, void* p) {
+  if (!p) return;
+  auto it = ctx->pool_sizes.find(p);
+  if (it == ctx->pool_sizes.end()) {
+    (void)hipFree(p);
+    return;
+  }
+  ctx->pool_free_blocks.emplace(it->second, p);
+  ctx->pool_cached_bytes += it->second;
+  // keep the cache bounded: drop the largest blocks beyond 96 GiB
+  while (ctx->pool_cached_bytes > (size_t(96) << 30) && !ctx->pool_free_blocks.empty()) {
+    auto last = std::prev(ctx->pool_free_blocks.end());
+    ctx->pool_cached_bytes -= last->first;
+    ctx->pool_sizes.erase(last->second);
+    (void)hipFree(last->second);
+    ctx->pool_free_blocks.erase(last);
+  }
+}
+
+void pool_trim(ksh_ctx* ctx) {
+  (void)hipStreamSynchronize(ctx->stream);
+  for (auto& kv : ctx->pool_free_blocks) {
+    ctx->pool_sizes.erase(kv.second);
+    (void)hipFree(kv.second);
+  }
+  ctx->pool_free_blocks.clear();
+  ctx->pool_cached_bytes = 0;
 }
 
 hipEvent_t timer_event(ksh_ctx* ctx, size_t* index) {
@@ -403,6 +460,7 @@ int ksh_ctx_destroy(ksh_ctx* ctx) {
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   free_plan(ctx);
+  pool_trim(ctx);
   if (ctx->arena) (void)hipFree(ctx->arena);
   if (ctx->plan) (void)hipFree(ctx->plan);
   for (int i = 0; i < 2; i++)

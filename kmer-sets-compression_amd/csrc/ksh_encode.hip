@@ -728,7 +728,7 @@ T* carve(char*& at, size_t count) {
 void free_plan(ksh_ctx* ctx) {
   EncPlan* p = static_cast<EncPlan*>(ctx->enc_state);
   if (!p) return;
-  if (p->ublock) (void)hipFree(p->ublock);
+  if (p->ublock) pool_free(ctx, p->ublock);
   delete p;
   ctx->enc_state = nullptr;
 }
@@ -827,7 +827,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, int m
   const size_t ub = 10 * al(size_t(n_u) * 4) + al(size_t(8 * n_u) * 4) + 2 * al(size_t(2 * n_u) * 4) +
                     al(size_t(2 * n_u) * 8) + 3 * al(size_t(n_u)) + 4 * al(size_t(n_u + 1) * 8) +
                     3 * al(size_t(n_u) * 4) + 4096;
-  KSH_HIP(hipMalloc(reinterpret_cast<void**>(&p->ublock), ub));
+  KSH_TRY(pool_alloc(ctx, ub, reinterpret_cast<void**>(&p->ublock)));
   at = p->ublock;
   p->u_head = carve<uint32_t>(at, size_t(n_u));
   p->u_first = carve<uint32_t>(at, size_t(n_u));
@@ -930,7 +930,7 @@ int encode_write_t(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens) {
   if (need <= size_t(2 * n) * 4) {
     bytes = reinterpret_cast<uint8_t*>(p->nbr);
   } else {
-    KSH_HIP(hipMalloc(&tmp, need));
+    KSH_TRY(pool_alloc(ctx, need, &tmp));
     bytes = static_cast<uint8_t*>(tmp);
   }
   hipLaunchKernelGGL((k_emit<KeyT>), dim3(nblk(n)), dim3(256), 0, st, set, p->head, p->pos, p->ori,
@@ -940,10 +940,7 @@ int encode_write_t(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens) {
                      d_words);
   KSH_HIP(hipMemcpyAsync(d_lens, p->lens, size_t(p->n_strings) * 4, hipMemcpyDeviceToDevice, st));
   KSH_HIP(hipGetLastError());
-  if (tmp) {
-    KSH_HIP(hipStreamSynchronize(st));
-    KSH_HIP(hipFree(tmp));
-  }
+  if (tmp) pool_free(ctx, tmp);
   return KSH_OK;
 }
 

@@ -8,7 +8,9 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <map>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "kmersets_hip.h"
@@ -71,6 +73,14 @@ struct ksh_ctx {
   const void* plan_b_keys = nullptr;
   int64_t plan_buckets = 0;
 
+  // caching allocator for the loop's per-iteration buffers (ksh::pool_alloc / pool_free):
+  // freed blocks are kept and reused, because hipMalloc / hipFree of 100 MB-scale blocks
+  // cost milliseconds and hipFree synchronises the device.  Single stream, so reuse after
+  // free is ordered.
+  std::multimap<size_t, void*> pool_free_blocks;
+  std::unordered_map<void*, size_t> pool_sizes;
+  size_t pool_cached_bytes = 0;
+
   // kernel timers: when enabled, every launch of a timed kind gets its own event
   // pair from a pool; ksh_ctx_timing_read sums them after a stream sync.
   bool timing = false;
@@ -88,6 +98,9 @@ void* arena_alloc(ksh_ctx* ctx, size_t bytes);
 int plan_reserve(ksh_ctx* ctx, size_t bytes);
 enum { kSlotDecode = 0, kSlotEncode = 1 };
 int slot_reserve(ksh_ctx* ctx, int which, size_t bytes);
+int pool_alloc(ksh_ctx* ctx, size_t bytes, void** out);
+void pool_free(ksh_ctx* ctx, void* p);
+void pool_trim(ksh_ctx* ctx);
 
 int check_geom(const ksh_geom* g);
 inline int64_t n_buckets(const ksh_geom* g) { return int64_t(1) << g->n_bucket_bits; }

@@ -51,16 +51,16 @@ struct ksh_kss {
 
 namespace ksh {
 
-static void free_set(KssSet* s) {
-  if (s->off) (void)hipFree(s->off);
-  if (s->keys) (void)hipFree(s->keys);
+static void free_set(ksh_ctx* ctx, KssSet* s) {
+  pool_free(ctx, s->off);
+  pool_free(ctx, s->keys);
   *s = KssSet{};
 }
 
-static void free_compact(KssCompact* c) {
+static void free_compact(ksh_ctx* ctx, KssCompact* c) {
   if (c->owned) {
-    if (c->words) (void)hipFree(c->words);
-    if (c->lens) (void)hipFree(c->lens);
+    pool_free(ctx, c->words);
+    pool_free(ctx, c->lens);
   }
   *c = KssCompact{};
 }
@@ -70,21 +70,21 @@ static ksh_spss_view view_of(const KssCompact& c) {
   return ksh_spss_view{c.words, c.lens, c.n_strings, c.n_bases};
 }
 
-static int alloc_set(const ksh_geom* g, int64_t n_keys, KssSet* out) {
-  const int64_t nb = n_buckets(g);
-  KSH_HIP(hipMalloc(reinterpret_cast<void**>(&out->off), size_t(nb + 1) * 8));
-  KSH_HIP(hipMalloc(&out->keys, std::max<size_t>(size_t(n_keys) * g->key_bytes, 16)));
+static int alloc_offsets(ksh_ctx* ctx, const ksh_geom* g, KssSet* out) {
+  return pool_alloc(ctx, size_t(n_buckets(g) + 1) * 8, reinterpret_cast<void**>(&out->off));
+}
+
+static int alloc_keys(ksh_ctx* ctx, const ksh_geom* g, int64_t n_keys, KssSet* out) {
   out->n = n_keys;
-  return KSH_OK;
+  return pool_alloc(ctx, std::max<size_t>(size_t(n_keys) * g->key_bytes, 16), &out->keys);
 }
 
 static int decode_to_set(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* sp, int canonical_flag,
                          KssSet* out) {
-  const int64_t nb = n_buckets(g);
-  KSH_HIP(hipMalloc(reinterpret_cast<void**>(&out->off), size_t(nb + 1) * 8));
+  KSH_TRY(alloc_offsets(ctx, g, out));
   int64_t n = 0;
   KSH_TRY(ksh_spss_decode_plan(ctx, g, sp, canonical_flag, out->off, &n));
-  KSH_HIP(hipMalloc(&out->keys, std::max<size_t>(size_t(n) * g->key_bytes, 16)));
+  KSH_TRY(alloc_keys(ctx, g, n, out));
   KSH_TRY(ksh_spss_decode_write(ctx, g, sp, canonical_flag, out->off, out->keys, &n));
   out->n = n;
   return KSH_OK;
@@ -95,8 +95,9 @@ static int encode_set(ksh_ctx* ctx, const ksh_geom* g, const KssSet& s, KssCompa
   int64_t ns = 0, nbases = 0;
   KSH_TRY(ksh_spss_encode_plan(ctx, g, &v, 1, 0, &ns, &nbases));
   out->owned = true;
-  KSH_HIP(hipMalloc(reinterpret_cast<void**>(&out->words), std::max<size_t>(size_t((nbases + 31) / 32) * 8, 16)));
-  KSH_HIP(hipMalloc(reinterpret_cast<void**>(&out->lens), std::max<size_t>(size_t(ns) * 4, 16)));
+  KSH_TRY(pool_alloc(ctx, std::max<size_t>(size_t((nbases + 31) / 32) * 8, 16),
+                     reinterpret_cast<void**>(&out->words)));
+  KSH_TRY(pool_alloc(ctx, std::max<size_t>(size_t(ns) * 4, 16), reinterpret_cast<void**>(&out->lens)));
   KSH_TRY(ksh_spss_encode_write(ctx, out->words, out->lens));
   out->n_strings = ns;
   out->n_bases = nbases;
@@ -201,35 +202,29 @@ static int build(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs,
     {
       const ksh_set_view vj = view_of(k->sets[j]), vk = view_of(k->sets[kk]);
       KssSet sn, sj, sk;
-      const int64_t nb = n_buckets(g);
-      KSH_HIP(hipMalloc(reinterpret_cast<void**>(&sn.off), size_t(nb + 1) * 8));
-      KSH_HIP(hipMalloc(reinterpret_cast<void**>(&sj.off), size_t(nb + 1) * 8));
-      KSH_HIP(hipMalloc(reinterpret_cast<void**>(&sk.off), size_t(nb + 1) * 8));
+      KSH_TRY(alloc_offsets(ctx, g, &sn));
+      KSH_TRY(alloc_offsets(ctx, g, &sj));
+      KSH_TRY(alloc_offsets(ctx, g, &sk));
       int64_t totals[3];
       KSH_TRY(ksh_pair_plan(ctx, g, &vj, &vk, sn.off, sj.off, sk.off, totals));
-      sn.n = totals[0];
-      sj.n = totals[1];
-      sk.n = totals[2];
-      KSH_HIP(hipMalloc(&sn.keys, std::max<size_t>(size_t(sn.n) * g->key_bytes, 16)));
-      KSH_HIP(hipMalloc(&sj.keys, std::max<size_t>(size_t(sj.n) * g->key_bytes, 16)));
-      KSH_HIP(hipMalloc(&sk.keys, std::max<size_t>(size_t(sk.n) * g->key_bytes, 16)));
+      KSH_TRY(alloc_keys(ctx, g, totals[0], &sn));
+      KSH_TRY(alloc_keys(ctx, g, totals[1], &sj));
+      KSH_TRY(alloc_keys(ctx, g, totals[2], &sk));
       KSH_TRY(ksh_pair_write(ctx, g, &vj, &vk, sn.keys, sj.keys, sk.keys));
-      KSH_HIP(hipStreamSynchronize(ctx->stream));
 
       KssCompact cn, cj, ck;
       KSH_TRY(encode_set(ctx, g, sn, &cn));
       KSH_TRY(encode_set(ctx, g, sj, &cj));
       KSH_TRY(encode_set(ctx, g, sk, &ck));
-      KSH_HIP(hipStreamSynchronize(ctx->stream));
 
       k->sets.push_back(sn);
       k->compacts.push_back(cn);
-      free_set(&k->sets[j]);
-      free_compact(&k->compacts[j]);
+      free_set(ctx, &k->sets[j]);
+      free_compact(ctx, &k->compacts[j]);
       k->sets[j] = sj;
       k->compacts[j] = cj;
-      free_set(&k->sets[kk]);
-      free_compact(&k->compacts[kk]);
+      free_set(ctx, &k->sets[kk]);
+      free_compact(ctx, &k->compacts[kk]);
       k->sets[kk] = sk;
       k->compacts[kk] = ck;
       k->children[j].push_back(n);
@@ -297,8 +292,8 @@ int ksh_kss_destroy(ksh_kss* k) {
   if (!k) return KSH_OK;
   (void)hipSetDevice(k->ctx->device);
   (void)hipStreamSynchronize(k->ctx->stream);
-  for (KssSet& s : k->sets) free_set(&s);
-  for (KssCompact& c : k->compacts) free_compact(&c);
+  for (KssSet& s : k->sets) free_set(k->ctx, &s);
+  for (KssCompact& c : k->compacts) free_compact(k->ctx, &c);
   delete k;
   return KSH_OK;
 }
@@ -384,7 +379,8 @@ int ksh_kss_get(const ksh_kss* k, int32_t i, int64_t** d_offsets, void** d_keys,
   KSH_HIP(hipSetDevice(ctx->device));
   const int64_t nb = n_buckets(g);
   KssSet acc;
-  KSH_TRY(alloc_set(g, 0, &acc));
+  KSH_TRY(alloc_offsets(ctx, g, &acc));
+  KSH_TRY(alloc_keys(ctx, g, 0, &acc));
   KSH_HIP(hipMemsetAsync(acc.off, 0, size_t(nb + 1) * 8, ctx->stream));
   std::queue<int> queue;
   queue.push(i);
@@ -393,18 +389,30 @@ int ksh_kss_get(const ksh_kss* k, int32_t i, int64_t** d_offsets, void** d_keys,
     queue.pop();
     const ksh_set_view va = view_of(acc), vb = view_of(k->sets[current]);
     KssSet next;
-    KSH_HIP(hipMalloc(reinterpret_cast<void**>(&next.off), size_t(nb + 1) * 8));
+    KSH_TRY(alloc_offsets(ctx, g, &next));
     int64_t total = 0;
     KSH_TRY(ksh_set_union_plan(ctx, g, &va, &vb, next.off, &total));
-    KSH_HIP(hipMalloc(&next.keys, std::max<size_t>(size_t(total) * g->key_bytes, 16)));
-    next.n = total;
+    KSH_TRY(alloc_keys(ctx, g, total, &next));
     KSH_TRY(ksh_set_union_write(ctx, g, &va, &vb, next.keys));
-    KSH_HIP(hipStreamSynchronize(ctx->stream));
-    free_set(&acc);
+    free_set(ctx, &acc);
     acc = next;
     auto it = k->children.find(current);
     if (it != k->children.end())
       for (int child : it->second) queue.push(child);
+  }
+  // hand the result over in plain hipMalloc'ed buffers (the caller releases them with ksh_free)
+  {
+    KssSet out;
+    KSH_HIP(hipMalloc(reinterpret_cast<void**>(&out.off), size_t(nb + 1) * 8));
+    KSH_HIP(hipMalloc(&out.keys, std::max<size_t>(size_t(acc.n) * g->key_bytes, 16)));
+    KSH_HIP(hipMemcpyAsync(out.off, acc.off, size_t(nb + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+    if (acc.n)
+      KSH_HIP(hipMemcpyAsync(out.keys, acc.keys, size_t(acc.n) * g->key_bytes, hipMemcpyDeviceToDevice,
+                             ctx->stream));
+    KSH_HIP(hipStreamSynchronize(ctx->stream));
+    out.n = acc.n;
+    free_set(ctx, &acc);
+    acc = out;
   }
   *d_offsets = acc.off;
   *d_keys = acc.keys;

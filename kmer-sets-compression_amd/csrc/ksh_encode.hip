@@ -92,8 +92,7 @@ __global__ __launch_bounds__(256) void k_adjacency(DevSet<KeyT> set, uint32_t* _
   }
 }
 
-// One thread per k-mer: both links, and the initial chain-rank record of its two states
-// ((itself, 0) for a state that ends its chain, unset otherwise).
+// One thread per k-mer: both links; the chain-rank records of its two states start unset.
 __global__ __launch_bounds__(256) void k_links(const uint32_t* __restrict__ nbr, int64_t n,
                                                 uint32_t* __restrict__ link,
                                                 unsigned long long* __restrict__ info) {
@@ -112,19 +111,19 @@ __global__ __launch_bounds__(256) void k_links(const uint32_t* __restrict__ nbr,
     }
   }
   reinterpret_cast<uint2*>(link)[t] = make_uint2(out[0], out[1]);
-  // state 2t leaves through side 1, state 2t+1 through side 0
-  info[2 * t] = out[1] == kNone ? (uint64_t(2 * t) << 32) : kUnset;
-  info[2 * t + 1] = out[0] == kNone ? (uint64_t(2 * t + 1) << 32) : kUnset;
+  reinterpret_cast<ulonglong2*>(info)[t] = make_ulonglong2(kUnset, kUnset);  // chain-rank records
 }
 
 // ---------------------------------------------------------------------------------- E2
 // Chains of states are ranked with a sparse ruler set instead of one serial walk per
 // chain (a 10^7-k-mer unitig would otherwise be a 10^7-step dependent walk):
-//   rulers = chain starts, chain ends and a hashed 1-in-32 sample of the states;
-//   k_ruler_walk  every ruler walks to the next ruler (about 16 steps): info[r] = (next, steps);
-//   k_ruler_jump  pointer jumping over the sampled rulers only, until each points at its
-//                 chain's end with the full distance (log2(rulers per chain) rounds);
-//   k_ruler_fill  every ruler walks its segment again: info[s] = (end state, distance to end).
+//   rulers = both states of every 16th k-mer (index order is unrelated to chain order);
+//   k_ruler_walk  every sampled ruler walks to the next one (about 16 steps), stamping the
+//                 states it passes with (ruler, offset);  k_ruler_heads does the same for the
+//                 head segment of a chain that starts between two sampled k-mers;
+//   k_ruler_jump  pointer jumping over the dense ruler array only (1/16 of the states), until
+//                 each ruler holds (chain end, distance to it);
+//   k_choose      resolves every state through its ruler: (end state, distance to end).
 // Rulers on a non-branching loop never reach an end; they and their segments stay unset
 // and k_loops handles the loop.
 // Both links of the k-mer of state s in one 8-byte load: .x = link[2t], .y = link[2t+1].
@@ -143,92 +142,147 @@ __device__ __forceinline__ uint32_t step_to(uint32_t s, uint32_t lk) {
 // chain ends; "is a ruler" needs only the state's own link pair, which the walk loads anyway.
 __device__ __forceinline__ bool sampled_ruler(uint32_t s) { return (s & 30u) == 0; }
 
-// kDense: thread i is the i-th sampled ruler.  !kDense: thread i is state i and acts only
-// if it starts a chain and is not sampled.  Chain ends never act (they are (itself, 0)).
-template <bool kDense>
-__device__ __forceinline__ bool ruler_of_thread(const uint32_t* __restrict__ link, int64_t n_states,
-                                                uint32_t* r, uint32_t* leave) {
-  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  const int64_t s = kDense ? (32 * (i >> 1) + (i & 1)) : i;
-  if (s >= n_states) return false;
-  const uint2 pr = link_pair(link, uint32_t(s));
-  const uint32_t lv = leave_link(pr, uint32_t(s));
-  if (lv == kNone) return false;  // a chain end
-  if (!kDense && (sampled_ruler(uint32_t(s)) || enter_link(pr, uint32_t(s)) != kNone)) return false;
-  *r = uint32_t(s);
-  *leave = lv;
-  return true;
+// Chain-rank records.
+//   rinfo[i] (one per sampled ruler, dense index i): end_flag:1 | dist:31 | next:32 -- the next
+//            ruler (or, once end_flag is set, the chain's end state) and the distance to it.
+//   rec[s]   (one per state): kind:2 | off:30 | ref:32
+//            kind 0: s lies `off` steps after sampled ruler `ref` (dense index)
+//            kind 1: s lies `off` steps before sampled ruler `ref` (head segment of a chain)
+//            kind 2: the chain's end state is `ref`, `off` steps ahead (no sampled ruler between)
+// The dense ruler array is 1/16 of the states (L2/MALL resident at 10^8 k-mers), so pointer
+// jumping and the final lookups stay on-chip; every state's link pair is read once and its
+// record written once.
+constexpr uint64_t kRecUnset = ~uint64_t(0);
+constexpr uint64_t kEndFlag = uint64_t(1) << 63;
+
+__device__ __forceinline__ uint32_t dense_index(uint32_t s) { return ((s >> 5) << 1) | (s & 1); }
+__device__ __forceinline__ uint64_t make_rec(uint32_t kind, uint32_t off, uint32_t ref) {
+  return (uint64_t(kind) << 62) | (uint64_t(off & 0x3FFFFFFFu) << 32) | ref;
+}
+__device__ __forceinline__ uint64_t make_rinfo(bool end, uint32_t dist, uint32_t nx) {
+  return (end ? kEndFlag : 0) | (uint64_t(dist & 0x7FFFFFFFu) << 32) | nx;
 }
 
-template <bool kDense>
+// One thread per sampled ruler (dense index i <-> state 32 * (i >> 1) + (i & 1)).
 __global__ __launch_bounds__(256) void k_ruler_walk(const uint32_t* __restrict__ link,
-                                                     int64_t n_states,
-                                                     unsigned long long* __restrict__ info) {
-  uint32_t r, lk;
-  if (!ruler_of_thread<kDense>(link, n_states, &r, &lk)) return;
+                                                     int64_t n_states, int64_t n_dense,
+                                                     unsigned long long* __restrict__ rinfo,
+                                                     unsigned long long* __restrict__ rec) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_dense) return;
+  const int64_t s64 = 32 * (i >> 1) + (i & 1);
+  if (s64 >= n_states) {
+    rinfo[i] = make_rinfo(true, 0, 0);
+    return;
+  }
+  const uint32_t r = uint32_t(s64);
+  uint32_t lk = leave_link(link_pair(link, r), r);
+  rec[r] = make_rec(0, 0, uint32_t(i));
+  if (lk == kNone) {
+    rinfo[i] = make_rinfo(true, 0, r);
+    return;
+  }
   uint32_t cur = r, steps = 0;
   while (true) {
     cur = step_to(cur, lk);
     steps++;
+    if (sampled_ruler(cur) || steps >= 0x3FFFFFFFu) {
+      rinfo[i] = make_rinfo(false, steps, cur);
+      return;
+    }
+    rec[cur] = make_rec(0, steps, uint32_t(i));
     lk = leave_link(link_pair(link, cur), cur);
-    if (lk == kNone || sampled_ruler(cur) || steps == 0xFFFFFFFFu) break;  // next ruler
+    if (lk == kNone) {
+      rinfo[i] = make_rinfo(true, steps, cur);
+      return;
+    }
   }
-  info[r] = (uint64_t(cur) << 32) | steps;
 }
 
-// Pointer jumping over the sampled rulers (dense) until they all point at a chain end.
-__global__ __launch_bounds__(256) void k_ruler_jump(const uint32_t* __restrict__ link,
-                                                     int64_t n_states,
-                                                     unsigned long long* __restrict__ info,
+// One thread per state; acts on chain starts that are not sampled: their head segment is
+// ranked relative to the first sampled ruler ahead (kind 1) or to the chain's end (kind 2).
+__global__ __launch_bounds__(256) void k_ruler_heads(const uint32_t* __restrict__ link,
+                                                      int64_t n_states,
+                                                      unsigned long long* __restrict__ rec) {
+  const int64_t s64 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (s64 >= n_states) return;
+  const uint32_t s0 = uint32_t(s64);
+  if (sampled_ruler(s0)) return;
+  const uint2 pr = link_pair(link, s0);
+  if (enter_link(pr, s0) != kNone) return;  // not a chain start
+  const uint32_t lk0 = leave_link(pr, s0);
+  if (lk0 == kNone) {
+    rec[s0] = make_rec(2, 0, s0);  // a one-state chain
+    return;
+  }
+  // first walk: what lies ahead
+  uint32_t cur = s0, steps = 0, lk = lk0, kind, ref;
+  while (true) {
+    cur = step_to(cur, lk);
+    steps++;
+    if (sampled_ruler(cur)) {
+      kind = 1;
+      ref = dense_index(cur);
+      break;
+    }
+    lk = leave_link(link_pair(link, cur), cur);
+    if (lk == kNone || steps >= 0x3FFFFFFFu) {
+      kind = 2;
+      ref = cur;
+      break;
+    }
+  }
+  // second walk: stamp the head segment (the target ruler stamps itself; an end state is ours)
+  uint32_t d = steps;
+  cur = s0;
+  lk = lk0;
+  while (true) {
+    rec[cur] = make_rec(kind, d, ref);
+    if (d == 0) break;
+    cur = step_to(cur, lk);
+    d--;
+    if (d == 0 && kind == 1) break;
+    lk = leave_link(link_pair(link, cur), cur);
+  }
+}
+
+// Pointer jumping over the dense ruler array until every ruler on a path points at its end.
+__global__ __launch_bounds__(256) void k_ruler_jump(int64_t n_dense,
+                                                     unsigned long long* __restrict__ rinfo,
                                                      int* __restrict__ changed) {
-  uint32_t r, lk;
-  if (!ruler_of_thread<true>(link, n_states, &r, &lk)) return;
-  const uint64_t mine = info[r];
-  const uint32_t nx = uint32_t(mine >> 32);
-  if (nx == r) return;
-  const uint64_t theirs = info[nx];
-  const uint32_t nx2 = uint32_t(theirs >> 32);
-  if (nx2 == nx) return;  // nx is a chain end (or the only ruler of a loop)
-  info[r] = (uint64_t(nx2) << 32) | uint32_t(uint32_t(mine) + uint32_t(theirs));
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_dense) return;
+  const uint64_t mine = rinfo[i];
+  if (mine & kEndFlag) return;
+  const uint64_t theirs = rinfo[dense_index(uint32_t(mine))];
+  const uint32_t dist = uint32_t((mine >> 32) & 0x7FFFFFFFu) + uint32_t((theirs >> 32) & 0x7FFFFFFFu);
+  rinfo[i] = (theirs & kEndFlag) | (uint64_t(dist & 0x7FFFFFFFu) << 32) | uint32_t(theirs);
   *changed = 1;
 }
 
-// Final hop of the unsampled chain starts, then every ruler stamps its segment.
-template <bool kDense>
-__global__ __launch_bounds__(256) void k_ruler_fill(const uint32_t* __restrict__ link,
-                                                     int64_t n_states,
-                                                     unsigned long long* __restrict__ info) {
-  uint32_t r, lk;
-  if (!ruler_of_thread<kDense>(link, n_states, &r, &lk)) return;
-  uint64_t mine = info[r];
-  uint32_t e = uint32_t(mine >> 32);
-  if (!kDense) {
-    // its next ruler is sampled (and converged) or a chain end
-    const uint64_t theirs = info[e];
-    mine = (theirs & 0xFFFFFFFF00000000ull) | uint32_t(uint32_t(mine) + uint32_t(theirs));
-    e = uint32_t(mine >> 32);
+// (end state, distance to it) of a state from its record; false on a non-branching loop.
+__device__ __forceinline__ bool resolve_rec(uint64_t r, const unsigned long long* __restrict__ rinfo,
+                                            uint32_t* end, uint32_t* dist) {
+  if (r == kRecUnset) return false;
+  const uint32_t kind = uint32_t(r >> 62), off = uint32_t((r >> 32) & 0x3FFFFFFFu), ref = uint32_t(r);
+  if (kind == 2) {
+    *end = ref;
+    *dist = off;
+    return true;
   }
-  const bool ends = leave_link(link_pair(link, e), e) == kNone;
-  if (!ends) {  // never reached an end: a ruler on a non-branching loop
-    info[r] = kUnset;
-    return;
-  }
-  if (!kDense) info[r] = mine;
-  uint32_t d = uint32_t(mine);
-  uint32_t cur = r;
-  while (true) {
-    cur = step_to(cur, lk);
-    d--;
-    lk = leave_link(link_pair(link, cur), cur);
-    if (lk == kNone || sampled_ruler(cur)) break;
-    info[cur] = (uint64_t(e) << 32) | d;
-  }
+  const uint64_t ri = rinfo[ref];
+  if (!(ri & kEndFlag)) return false;  // the ruler never reached an end: it is on a loop
+  const uint32_t rd = uint32_t((ri >> 32) & 0x7FFFFFFFu);
+  *end = uint32_t(ri);
+  *dist = kind == 0 ? rd - off : rd + off;
+  return true;
 }
 
-// info[s] = (end state of s's chain, distance from s to it).  For k-mer t the chain of
-// (t, 0) ends at E0 and the chain of (t, 1) ends at E1, i.e. the forward chain runs from
-// k-mer E1 >> 1 to k-mer E0 >> 1; the spelling starts at the larger end (spss.h:511,555).
-__global__ __launch_bounds__(256) void k_choose(const unsigned long long* __restrict__ info,
+// For k-mer t the chain of (t, 0) ends at E0 and the chain of (t, 1) ends at E1, i.e. the
+// forward chain runs from k-mer E1 >> 1 to k-mer E0 >> 1; the spelling starts at the larger
+// end (spss.h:511,555).  hcls: 0xFE marks a k-mer on a non-branching loop (k_loops fills it in).
+__global__ __launch_bounds__(256) void k_choose(const unsigned long long* __restrict__ rec,
+                                                 const unsigned long long* __restrict__ rinfo,
                                                  int64_t n, uint32_t* __restrict__ head,
                                                  uint32_t* __restrict__ pos,
                                                  uint8_t* __restrict__ ori,
@@ -237,14 +291,15 @@ __global__ __launch_bounds__(256) void k_choose(const unsigned long long* __rest
                                                  uint32_t* __restrict__ hlast) {
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= n) return;
-  const uint64_t i0 = info[2 * t], i1 = info[2 * t + 1];
-  hcls[t] = 0xFF;
-  if (i0 == kUnset || i1 == kUnset) {  // on a loop: k_loops fills it in
+  const ulonglong2 both = reinterpret_cast<const ulonglong2*>(rec)[t];
+  uint32_t e0, d0, e1, d1;
+  const bool ok = resolve_rec(both.x, rinfo, &e0, &d0) && resolve_rec(both.y, rinfo, &e1, &d1);
+  if (!ok) {
     head[t] = kNone;
+    hcls[t] = 0xFE;
     return;
   }
-  const uint32_t e0 = uint32_t(i0 >> 32), e1 = uint32_t(i1 >> 32);
-  const uint32_t d0 = uint32_t(i0), d1 = uint32_t(i1);
+  hcls[t] = 0xFF;
   const uint32_t fwd_start = e1 >> 1, fwd_end = e0 >> 1;
   const uint32_t d = fwd_start >= fwd_end ? 0u : 1u;
   const uint32_t start_state = (d ? e0 : e1) ^ 1;
@@ -260,7 +315,6 @@ __global__ __launch_bounds__(256) void k_choose(const unsigned long long* __rest
 }
 
 __global__ __launch_bounds__(256) void k_loops(const uint32_t* __restrict__ link,
-                                                const unsigned long long* __restrict__ info,
                                                 int64_t n, uint32_t* __restrict__ head,
                                                 uint32_t* __restrict__ pos,
                                                 uint8_t* __restrict__ ori,
@@ -269,7 +323,7 @@ __global__ __launch_bounds__(256) void k_loops(const uint32_t* __restrict__ link
                                                 uint32_t* __restrict__ hlast) {
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= n) return;
-  if (info[2 * t] != kUnset) return;
+  if (hcls[t] != 0xFE) return;  // only its own flag: the loop's smallest k-mer rewrites just its own
   const uint32_t start = uint32_t(2 * t);
   uint32_t s = start;
   int64_t steps = 0;
@@ -318,7 +372,7 @@ __global__ __launch_bounds__(256) void k_unitig_fill(
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const uint8_t c = hcls[t];
-  if (c == 0xFF) return;
+  if (c > 3) return;
   int64_t u;
   if (c == 0) u = c01[t] & 0xFFFFFFFF;
   else if (c == 1) u = base1 + (c01[t] >> 32);
@@ -787,29 +841,26 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, int m
     if (!changed) return fail(KSH_INTERNAL, "scratch arena too small");
     const int64_t ns2 = 2 * n;
     const int64_t n_dense = 2 * ((n + 15) / 16);
-    hipLaunchKernelGGL(k_ruler_walk<true>, dim3(nblk(n_dense)), dim3(256), 0, st, p->link, ns2,
+    unsigned long long* rinfo = reinterpret_cast<unsigned long long*>(p->c01);  // n_dense * 8 <= 8n
+    hipLaunchKernelGGL(k_ruler_walk, dim3(nblk(n_dense)), dim3(256), 0, st, p->link, ns2, n_dense, rinfo,
                        p->info);
-    hipLaunchKernelGGL(k_ruler_walk<false>, dim3(nblk(ns2)), dim3(256), 0, st, p->link, ns2, p->info);
+    hipLaunchKernelGGL(k_ruler_heads, dim3(nblk(ns2)), dim3(256), 0, st, p->link, ns2, p->info);
     int max_rounds = 2;
     for (int64_t x = n_dense; x > 1; x >>= 1) max_rounds++;
     for (int round = 0; round < max_rounds;) {
       KSH_HIP(hipMemsetAsync(changed, 0, sizeof(int), st));
       for (int b = 0; b < 4 && round < max_rounds; b++, round++)
-        hipLaunchKernelGGL(k_ruler_jump, dim3(nblk(n_dense)), dim3(256), 0, st, p->link, ns2, p->info,
-                           changed);
+        hipLaunchKernelGGL(k_ruler_jump, dim3(nblk(n_dense)), dim3(256), 0, st, n_dense, rinfo, changed);
       KSH_HIP(hipMemcpyAsync(ctx->h_pinned, changed, sizeof(int), hipMemcpyDeviceToHost, st));
       KSH_HIP(hipStreamSynchronize(st));
       if (*reinterpret_cast<int*>(ctx->h_pinned) == 0) break;
     }
-    // sparse first: it reads the converged records of the sampled rulers it points at
-    hipLaunchKernelGGL(k_ruler_fill<false>, dim3(nblk(ns2)), dim3(256), 0, st, p->link, ns2, p->info);
-    hipLaunchKernelGGL(k_ruler_fill<true>, dim3(nblk(n_dense)), dim3(256), 0, st, p->link, ns2,
-                       p->info);
   }
-  hipLaunchKernelGGL(k_choose, dim3(nblk(n)), dim3(256), 0, st, p->info, n, p->head, p->pos, p->ori,
+  hipLaunchKernelGGL(k_choose, dim3(nblk(n)), dim3(256), 0, st, p->info,
+                     reinterpret_cast<const unsigned long long*>(p->c01), n, p->head, p->pos, p->ori,
                      p->hcls, p->hlen, p->hlast);
-  hipLaunchKernelGGL(k_loops, dim3(nblk(n)), dim3(256), 0, st, p->link, p->info, n, p->head, p->pos,
-                     p->ori, p->hcls, p->hlen, p->hlast);
+  hipLaunchKernelGGL(k_loops, dim3(nblk(n)), dim3(256), 0, st, p->link, n, p->head, p->pos, p->ori,
+                     p->hcls, p->hlen, p->hlast);
   hipLaunchKernelGGL(k_head_counts, dim3(nblk(n)), dim3(256), 0, st, p->hcls, n, p->c01, p->c23);
   int64_t* d_tot = static_cast<int64_t*>(arena_alloc(ctx, 16));
   if (!d_tot) return fail(KSH_INTERNAL, "scratch arena too small");

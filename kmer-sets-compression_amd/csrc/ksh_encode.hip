@@ -69,28 +69,55 @@ __global__ __launch_bounds__(256) void k_fine_index(const int64_t* __restrict__ 
 
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_adjacency(DevSet<KeyT> set, uint32_t* __restrict__ nbr) {
+  __shared__ int64_t s_bucket;
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t x = set.kmer_in_block(t, &s_bucket);
   if (t >= set.n) return;
   const int k = set.k;
-  const uint64_t x = set.kmer(t);
+  // The 8 candidates of the reference (Next / Prev of x, each as is or reverse-complemented,
+  // spss.h:238-273) in two kinds.  The four Next(x, c) are consecutive values, and so are the
+  // four Next(rc(x), c) = rc(Prev(x, 3 - c)): one bounded search each finds all of their
+  // members that are in the set (only a canonical k-mer can be).  The other candidates,
+  // Prev(x, c) and Prev(rc(x), c) = rc(Next(x, 3 - c)), sit in four different buckets and are
+  // probed one by one, and only when they are the canonical form.
+  const uint64_t rx = revcomp(x, k);
+  int cnt[2] = {0, 0};
+  uint32_t single[2] = {kNone, kNone};
 #pragma unroll
   for (int side = 0; side < 2; side++) {
-    int cnt = 0;
-    uint32_t single = kNone;
+    // group: side 1 -> Next(x, .) (neighbour as is);  side 0 -> Next(rc(x), .) (neighbour
+    // reverse-complemented, i.e. a same-side edge)
+    const uint64_t g0 = kmer_next(side ? x : rx, k, 0);
+    int64_t end;
+    const int64_t p0 = set.lower_bound(g0, &end);
+    const uint64_t gkey = g0 & set.key_mask();
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int64_t idx = p0 + e;
+      if (idx >= end) break;
+      const uint64_t kk = uint64_t(set.keys[idx]);
+      if (kk - gkey >= 4) break;
+      if (idx == t) continue;  // kmer != next (spss.h:242,248)
+      cnt[side]++;
+      single[side] = (uint32_t(idx) << 1) | (side ? 0u : 1u);
+    }
+    // singles: side 1 -> Prev(rc(x), c) = rc(Next(x, 3 - c));  side 0 -> Prev(x, c) as is
+    const uint64_t base = side ? rx : x;
 #pragma unroll
     for (int c = 0; c < 4; c++) {
-      const uint64_t y = side ? kmer_next(x, k, c) : kmer_prev(x, k, c);
-      const uint64_t r = revcomp(y, k);
-      const uint64_t z = y < r ? y : r;
-      if (z == x) continue;  // kmer != next / next_complement (spss.h:242,248)
+      const uint64_t z = kmer_prev(base, k, c);
+      if (revcomp(z, k) < z) continue;  // not canonical: cannot be in the set
+      if (z == x) continue;
       const int64_t idx = set.find(z);
       if (idx < 0) continue;
-      cnt++;
-      single = (uint32_t(idx) << 1) | uint32_t(z != y);
+      cnt[side]++;
+      single[side] = (uint32_t(idx) << 1) | (side ? 1u : 0u);
     }
-    nbr[2 * t + side] = cnt == 0 ? kNone : (cnt == 1 ? single : kMulti);
   }
+  nbr[2 * t] = cnt[0] == 0 ? kNone : (cnt[0] == 1 ? single[0] : kMulti);
+  nbr[2 * t + 1] = cnt[1] == 0 ? kNone : (cnt[1] == 1 ? single[1] : kMulti);
 }
+
 
 // One thread per k-mer: both links; the chain-rank records of its two states start unset.
 __global__ __launch_bounds__(256) void k_links(const uint32_t* __restrict__ nbr, int64_t n,
@@ -693,28 +720,52 @@ __global__ __launch_bounds__(256) void k_unitig_strings(const uint32_t* __restri
 }
 
 // ---------------------------------------------------------------------------------- E8
+// Where a unitig's k-mers go in the output base stream.
+struct UnitigPlace {
+  int64_t base;    // base position of the unitig's first k-mer slot (in traversal order)
+  uint32_t len;    // k-mers in the unitig
+  uint32_t flags;  // bit 0: traversed reverse-complemented, bit 1: last unitig of its string
+};
+
+__global__ __launch_bounds__(256) void k_unitig_place(const uint32_t* __restrict__ u_len,
+                                                       const uint32_t* __restrict__ u_sid,
+                                                       const uint32_t* __restrict__ u_koff,
+                                                       const uint8_t* __restrict__ u_flip,
+                                                       const int64_t* __restrict__ str_start,
+                                                       const uint32_t* __restrict__ lens, int64_t n_u,
+                                                       UnitigPlace* __restrict__ place) {
+  const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (u >= n_u) return;
+  const uint32_t sid = u_sid[u];
+  UnitigPlace pl;
+  pl.base = str_start[sid] + u_koff[u];
+  pl.len = u_len[u];
+  const bool is_last = u_koff[u] + u_len[u] == lens[sid] + 1;  // lens = k-mers in the string - 1
+  pl.flags = uint32_t(u_flip[u] & 1) | (is_last ? 2u : 0u);
+  place[u] = pl;
+}
+
 template <typename KeyT>
-__global__ __launch_bounds__(256) void k_emit(
-    DevSet<KeyT> set, const uint32_t* __restrict__ head, const uint32_t* __restrict__ pos,
-    const uint8_t* __restrict__ ori, const uint32_t* __restrict__ uid,
-    const uint32_t* __restrict__ u_len, const uint32_t* __restrict__ u_sid,
-    const uint32_t* __restrict__ u_koff, const uint8_t* __restrict__ u_flip,
-    const int64_t* __restrict__ str_start, const uint32_t* __restrict__ lens,
-    uint8_t* __restrict__ bytes) {
+__global__ __launch_bounds__(256) void k_emit(DevSet<KeyT> set, const uint32_t* __restrict__ head,
+                                               const uint32_t* __restrict__ pos,
+                                               const uint8_t* __restrict__ ori,
+                                               const uint32_t* __restrict__ uid,
+                                               const UnitigPlace* __restrict__ place,
+                                               uint8_t* __restrict__ bytes) {
+  __shared__ int64_t s_bucket;
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t x = set.kmer_in_block(t, &s_bucket);
   if (t >= set.n) return;
   const uint32_t h = head[t];
   if (h == kNone) return;
-  const uint32_t u = uid[h];
-  const uint32_t sid = u_sid[u];
-  const uint32_t flip = u_flip[u];
-  const uint32_t q = u_koff[u] + (flip ? (u_len[u] - 1 - pos[t]) : pos[t]);
+  const UnitigPlace pl = place[uid[h]];
+  const uint32_t flip = pl.flags & 1;
+  const uint32_t q = flip ? (pl.len - 1 - pos[t]) : pos[t];
   const int k = set.k;
-  const uint64_t x = set.kmer(t);
   const uint64_t o = (uint32_t(ori[t]) ^ flip) ? revcomp(x, k) : x;
-  const int64_t at = str_start[sid] + q;
+  const int64_t at = pl.base + q;
   bytes[at] = uint8_t((o >> (2 * (k - 1))) & 3);
-  if (q == lens[sid]) {  // last k-mer of the string: its remaining K - 1 bases
+  if ((pl.flags & 2) && q == pl.len - 1) {  // last k-mer of the string: its remaining K - 1 bases
     for (int i = 1; i < k; i++) bytes[at + i] = uint8_t((o >> (2 * (k - 1 - i))) & 3);
   }
 }
@@ -766,6 +817,7 @@ struct EncPlan {
   uint8_t *visited = nullptr, *scls = nullptr, *u_flip = nullptr;
   int64_t *s_nk = nullptr, *sc01 = nullptr, *sc2 = nullptr, *str_start = nullptr;
   int* any_live = nullptr;
+  UnitigPlace* place = nullptr;
   int rounds = 0;
 };
 
@@ -875,11 +927,12 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, int m
   p->n_u = n_u;
 
   // unitig-level block
-  const size_t ub = 10 * al(size_t(n_u) * 4) + al(size_t(8 * n_u) * 4) + 2 * al(size_t(2 * n_u) * 4) +
+  const size_t ub = al(size_t(n_u) * sizeof(UnitigPlace)) + 10 * al(size_t(n_u) * 4) + al(size_t(8 * n_u) * 4) + 2 * al(size_t(2 * n_u) * 4) +
                     al(size_t(2 * n_u) * 8) + 3 * al(size_t(n_u)) + 4 * al(size_t(n_u + 1) * 8) +
                     3 * al(size_t(n_u) * 4) + 4096;
   KSH_TRY(pool_alloc(ctx, ub, reinterpret_cast<void**>(&p->ublock)));
   at = p->ublock;
+  p->place = carve<UnitigPlace>(at, size_t(n_u));
   p->u_head = carve<uint32_t>(at, size_t(n_u));
   p->u_first = carve<uint32_t>(at, size_t(n_u));
   p->u_last = carve<uint32_t>(at, size_t(n_u));
@@ -954,6 +1007,8 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, int m
   // string starts in bases
   arena_reset(ctx);
   KSH_TRY(scan_exclusive_i64(ctx, p->str_start, p->str_start, ns, p->str_start + ns));
+  hipLaunchKernelGGL(k_unitig_place, dim3(nblk(n_u)), dim3(256), 0, st, p->u_len, p->u_sid, p->u_koff,
+                     p->u_flip, p->str_start, p->lens, n_u, p->place);
   KSH_HIP(hipGetLastError());
   KSH_HIP(hipMemcpyAsync(ctx->h_pinned, p->str_start + ns, 8, hipMemcpyDeviceToHost, st));
   KSH_HIP(hipStreamSynchronize(st));
@@ -985,7 +1040,7 @@ int encode_write_t(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens) {
     bytes = static_cast<uint8_t*>(tmp);
   }
   hipLaunchKernelGGL((k_emit<KeyT>), dim3(nblk(n)), dim3(256), 0, st, set, p->head, p->pos, p->ori,
-                     p->uid, p->u_len, p->u_sid, p->u_koff, p->u_flip, p->str_start, p->lens, bytes);
+                     p->uid, p->place, bytes);
   const int64_t n_words = (p->n_bases + 31) / 32;
   hipLaunchKernelGGL(k_pack, dim3(nblk(n_words)), dim3(256), 0, st, bytes, p->n_bases, n_words,
                      d_words);

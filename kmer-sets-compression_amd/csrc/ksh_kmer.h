@@ -74,6 +74,27 @@ struct DevSet {
     return (lo < end && keys[lo] == key) ? lo : int64_t(-1);
   }
 
+  // First index whose k-mer is >= z inside z's bucket; *end = end of that bucket.
+  __device__ int64_t lower_bound(uint64_t z, int64_t* end) const {
+    const int64_t b = int64_t(z >> key_bits);
+    const KeyT key = KeyT(z & key_mask());
+    int64_t lo, hi;
+    if (fine) {
+      const int64_t f = (b << 8) + int64_t(uint64_t(key) >> (key_bits - 8));
+      lo = fine[f];
+      hi = fine[f + 1];
+    } else {
+      lo = off[b];
+      hi = off[b + 1];
+    }
+    while (lo < hi) {
+      const int64_t mid = (lo + hi) >> 1;
+      if (keys[mid] < key) lo = mid + 1; else hi = mid;
+    }
+    *end = off[b + 1];
+    return lo;
+  }
+
   // Bucket holding index t (largest b with off[b] <= t).
   __device__ int64_t bucket_of(int64_t t) const {
     int64_t lo = 0, hi = n_buckets;
@@ -86,6 +107,20 @@ struct DevSet {
 
   __device__ __forceinline__ uint64_t kmer(int64_t t) const {
     return (uint64_t(bucket_of(t)) << key_bits) | uint64_t(keys[t]);
+  }
+
+  // For kernels whose workgroup owns 256 consecutive indices: one binary search per
+  // workgroup (its first index), then every thread steps forward from that bucket.
+  __device__ __forceinline__ uint64_t kmer_in_block(int64_t t, int64_t* lds_first_bucket) const {
+    if (threadIdx.x == 0) {
+      const int64_t t0 = int64_t(blockIdx.x) * blockDim.x;
+      *lds_first_bucket = bucket_of(t0 < n ? t0 : n - 1);
+    }
+    __syncthreads();
+    if (t >= n) return 0;
+    int64_t b = *lds_first_bucket;
+    while (off[b + 1] <= t) b++;
+    return (uint64_t(b) << key_bits) | uint64_t(keys[t]);
   }
 };
 

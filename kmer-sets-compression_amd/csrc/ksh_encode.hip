@@ -122,7 +122,8 @@ __global__ __launch_bounds__(256) void k_adjacency(DevSet<KeyT> set, uint32_t* _
 // One thread per k-mer: both links; the chain-rank records of its two states start unset.
 __global__ __launch_bounds__(256) void k_links(const uint32_t* __restrict__ nbr, int64_t n,
                                                 uint32_t* __restrict__ link,
-                                                unsigned long long* __restrict__ info) {
+                                                unsigned long long* __restrict__ info,
+                                                uint8_t* __restrict__ start_flags) {
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const uint2 nb2 = reinterpret_cast<const uint2*>(nbr)[t];
@@ -139,6 +140,10 @@ __global__ __launch_bounds__(256) void k_links(const uint32_t* __restrict__ nbr,
   }
   reinterpret_cast<uint2*>(link)[t] = make_uint2(out[0], out[1]);
   reinterpret_cast<ulonglong2*>(info)[t] = make_ulonglong2(kUnset, kUnset);  // chain-rank records
+  // which of its two states start a chain without being a sampled ruler (k_ruler_heads):
+  // state 2t enters through side 0, state 2t + 1 through side 1
+  const bool sampled = (t & 15) == 0;
+  start_flags[t] = sampled ? 0 : uint8_t((out[0] == kNone ? 1 : 0) | (out[1] == kNone ? 2 : 0));
 }
 
 // ---------------------------------------------------------------------------------- E2
@@ -226,50 +231,54 @@ __global__ __launch_bounds__(256) void k_ruler_walk(const uint32_t* __restrict__
   }
 }
 
-// One thread per state; acts on chain starts that are not sampled: their head segment is
-// ranked relative to the first sampled ruler ahead (kind 1) or to the chain's end (kind 2).
+// One thread per k-mer; acts on those of its two states that start a chain without being a
+// sampled ruler (flags from k_links): the head segment is ranked relative to the first
+// sampled ruler ahead (kind 1) or to the chain's end (kind 2).
 __global__ __launch_bounds__(256) void k_ruler_heads(const uint32_t* __restrict__ link,
-                                                      int64_t n_states,
+                                                      const uint8_t* __restrict__ start_flags,
+                                                      int64_t n,
                                                       unsigned long long* __restrict__ rec) {
-  const int64_t s64 = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (s64 >= n_states) return;
-  const uint32_t s0 = uint32_t(s64);
-  if (sampled_ruler(s0)) return;
-  const uint2 pr = link_pair(link, s0);
-  if (enter_link(pr, s0) != kNone) return;  // not a chain start
-  const uint32_t lk0 = leave_link(pr, s0);
-  if (lk0 == kNone) {
-    rec[s0] = make_rec(2, 0, s0);  // a one-state chain
-    return;
-  }
-  // first walk: what lies ahead
-  uint32_t cur = s0, steps = 0, lk = lk0, kind, ref;
-  while (true) {
-    cur = step_to(cur, lk);
-    steps++;
-    if (sampled_ruler(cur)) {
-      kind = 1;
-      ref = dense_index(cur);
-      break;
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= n) return;
+  const uint32_t flags = start_flags[t];
+  if (!flags) return;
+  for (uint32_t d = 0; d < 2; d++) {
+    if (!(flags & (1u << d))) continue;
+    const uint32_t s0 = uint32_t(2 * t) | d;
+    const uint32_t lk0 = leave_link(link_pair(link, s0), s0);
+    if (lk0 == kNone) {
+      rec[s0] = make_rec(2, 0, s0);  // a one-state chain
+      continue;
     }
-    lk = leave_link(link_pair(link, cur), cur);
-    if (lk == kNone || steps >= 0x3FFFFFFFu) {
-      kind = 2;
-      ref = cur;
-      break;
+    // first walk: what lies ahead
+    uint32_t cur = s0, steps = 0, lk = lk0, kind, ref;
+    while (true) {
+      cur = step_to(cur, lk);
+      steps++;
+      if (sampled_ruler(cur)) {
+        kind = 1;
+        ref = dense_index(cur);
+        break;
+      }
+      lk = leave_link(link_pair(link, cur), cur);
+      if (lk == kNone || steps >= 0x3FFFFFFFu) {
+        kind = 2;
+        ref = cur;
+        break;
+      }
     }
-  }
-  // second walk: stamp the head segment (the target ruler stamps itself; an end state is ours)
-  uint32_t d = steps;
-  cur = s0;
-  lk = lk0;
-  while (true) {
-    rec[cur] = make_rec(kind, d, ref);
-    if (d == 0) break;
-    cur = step_to(cur, lk);
-    d--;
-    if (d == 0 && kind == 1) break;
-    lk = leave_link(link_pair(link, cur), cur);
+    // second walk: stamp the head segment (the target ruler stamps itself; an end state is ours)
+    uint32_t left = steps;
+    cur = s0;
+    lk = lk0;
+    while (true) {
+      rec[cur] = make_rec(kind, left, ref);
+      if (left == 0) break;
+      cur = step_to(cur, lk);
+      left--;
+      if (left == 0 && kind == 1) break;
+      lk = leave_link(link_pair(link, cur), cur);
+    }
   }
 }
 
@@ -887,7 +896,8 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, int m
     set.fine = p->fine;
   }
   hipLaunchKernelGGL((k_adjacency<KeyT>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr);
-  hipLaunchKernelGGL(k_links, dim3(nblk(n)), dim3(256), 0, st, p->nbr, n, p->link, p->info);
+  hipLaunchKernelGGL(k_links, dim3(nblk(n)), dim3(256), 0, st, p->nbr, n, p->link, p->info,
+                     p->hcls);  // hcls doubles as the start-flag bytes until k_choose
   {
     int* changed = static_cast<int*>(arena_alloc(ctx, 16));
     if (!changed) return fail(KSH_INTERNAL, "scratch arena too small");
@@ -896,7 +906,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, int m
     unsigned long long* rinfo = reinterpret_cast<unsigned long long*>(p->c01);  // n_dense * 8 <= 8n
     hipLaunchKernelGGL(k_ruler_walk, dim3(nblk(n_dense)), dim3(256), 0, st, p->link, ns2, n_dense, rinfo,
                        p->info);
-    hipLaunchKernelGGL(k_ruler_heads, dim3(nblk(ns2)), dim3(256), 0, st, p->link, ns2, p->info);
+    hipLaunchKernelGGL(k_ruler_heads, dim3(nblk(n)), dim3(256), 0, st, p->link, p->hcls, n, p->info);
     int max_rounds = 2;
     for (int64_t x = n_dense; x > 1; x >>= 1) max_rounds++;
     for (int round = 0; round < max_rounds;) {

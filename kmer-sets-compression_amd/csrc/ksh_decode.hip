@@ -24,12 +24,13 @@
 #include "ksh_kmer.h"
 
 #include <algorithm>
+#include <vector>
 
 namespace ksh {
 
 constexpr int kDecThreads = 256;
 constexpr int kMaxLdsBuckets = 16384;   // 64 KiB of u32 counters
-constexpr int kSortLdsBytes = 49152;   // + 8 KiB of sub-bin counters stays under 64 KiB
+constexpr int kSortLdsBytes = 40960;   // + 2 x 8 KiB of counters stays under 64 KiB
 constexpr int kMaxSubBits = 11;
 
 __global__ __launch_bounds__(256) void k_str_bases(const uint32_t* __restrict__ lens, int64_t n,
@@ -136,15 +137,153 @@ __global__ __launch_bounds__(256) void k_hist_columns(uint32_t* __restrict__ his
   totals[b] = run;
 }
 
-// Sorts keys[lo, hi) ascending and drops duplicates; uniq[b] = number kept.
+// ---- per-bucket sort --------------------------------------------------------------------------
+struct SortLds {
+  uint32_t sub_cnt[(1 << kMaxSubBits) + 1];
+  int wave_cnt[4];
+  int overflow;
+  int kept;
+};
+
+// Sorts src[0, cnt) (cnt <= capacity of `lds`) into `lds`, ascending.  Keys that differ only in
+// their low `eff_bits` bits: one distribution pass on the top bits of those leaves sub-bins of
+// a few keys each (keys of a bucket are close to uniform), finished by insertion sort, one
+// thread per sub-bin; a skewed range (a sub-bin over 64 keys) is sorted by a bitonic network
+// instead (all-ascending form, so the slots past cnt stay virtual).
+template <typename KeyT>
+__device__ void block_sort_into_lds(const KeyT* __restrict__ src, int cnt, int eff_bits,
+                                    KeyT* __restrict__ lds, SortLds* __restrict__ sh) {
+  int bits = 0;
+  while ((4 << bits) < cnt && bits < kMaxSubBits) bits++;
+  if (bits > eff_bits) bits = eff_bits;
+  const int n_sub = 1 << bits;
+  const int shift = eff_bits - bits;
+  for (int i = threadIdx.x; i <= n_sub; i += 256) sh->sub_cnt[i] = 0;
+  if (threadIdx.x == 0) sh->overflow = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < cnt; i += 256)
+    atomicAdd(&sh->sub_cnt[uint32_t(uint64_t(src[i]) >> shift) & uint32_t(n_sub - 1)], 1u);
+  __syncthreads();
+  {  // exclusive scan of the sub-bin counts
+    const int per = (n_sub + 255) / 256;
+    const int c0 = min(int(threadIdx.x) * per, n_sub), c1 = min(c0 + per, n_sub);
+    int mine = 0;
+    for (int i = c0; i < c1; i++) mine += int(sh->sub_cnt[i]);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int inc = mine;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) sh->wave_cnt[wave] = inc;
+    __syncthreads();
+    int run = inc - mine;
+    for (int w = 0; w < wave; w++) run += sh->wave_cnt[w];
+    for (int i = c0; i < c1; i++) {
+      const int c = int(sh->sub_cnt[i]);
+      sh->sub_cnt[i] = uint32_t(run);
+      run += c;
+    }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < cnt; i += 256) {
+    const KeyT key = src[i];
+    const uint32_t pos = atomicAdd(&sh->sub_cnt[uint32_t(uint64_t(key) >> shift) & uint32_t(n_sub - 1)], 1u);
+    lds[pos] = key;
+  }
+  __syncthreads();
+  // sub_cnt[b] is now the end of sub-bin b (= start of b + 1)
+  for (int b2 = threadIdx.x; b2 < n_sub; b2 += 256) {
+    const int s0 = b2 ? int(sh->sub_cnt[b2 - 1]) : 0, s1 = int(sh->sub_cnt[b2]);
+    if (s1 - s0 > 64) {
+      sh->overflow = 1;
+    } else {
+      for (int i = s0 + 1; i < s1; i++) {
+        const KeyT x = lds[i];
+        int j = i - 1;
+        while (j >= s0 && lds[j] > x) {
+          lds[j + 1] = lds[j];
+          j--;
+        }
+        lds[j + 1] = x;
+      }
+    }
+  }
+  __syncthreads();
+  if (sh->overflow == 0) return;
+  int padded = 1;
+  while (padded < cnt) padded <<= 1;
+  const int half = padded >> 1;
+  for (int size = 2; size <= padded; size <<= 1) {
+    const int hs = size >> 1;
+    for (int p = threadIdx.x; p < half; p += 256) {
+      const int block = p / hs, o = p - block * hs;
+      const int i = block * size + o, j = block * size + size - 1 - o;
+      if (j < cnt) {
+        const KeyT x = lds[i], y = lds[j];
+        if (x > y) {
+          lds[i] = y;
+          lds[j] = x;
+        }
+      }
+    }
+    __syncthreads();
+    for (int stride = size >> 2; stride > 0; stride >>= 1) {
+      for (int p = threadIdx.x; p < half; p += 256) {
+        const int i = 2 * stride * (p / stride) + (p % stride), j = i + stride;
+        if (j < cnt) {
+          const KeyT x = lds[i], y = lds[j];
+          if (x > y) {
+            lds[i] = y;
+            lds[j] = x;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+}
+
+// Writes the distinct keys of the sorted lds[0, cnt) to dst; returns how many (block-uniform).
+template <typename KeyT>
+__device__ int block_unique_write(const KeyT* __restrict__ lds, int cnt, KeyT* __restrict__ dst,
+                                  SortLds* __restrict__ sh) {
+  const int per = (cnt + 255) / 256;
+  const int c0 = min(int(threadIdx.x) * per, cnt), c1 = min(c0 + per, cnt);
+  int mine = 0;
+  for (int i = c0; i < c1; i++) mine += (i == 0 || lds[i] != lds[i - 1]);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int inc = mine;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  __syncthreads();  // wave_cnt may still be read by the scan of a previous call
+  if (lane == 63) sh->wave_cnt[wave] = inc;
+  __syncthreads();
+  int at = inc - mine;
+  for (int w = 0; w < wave; w++) at += sh->wave_cnt[w];
+  const int total = sh->wave_cnt[0] + sh->wave_cnt[1] + sh->wave_cnt[2] + sh->wave_cnt[3];
+  for (int i = c0; i < c1; i++)
+    if (i == 0 || lds[i] != lds[i - 1]) dst[at++] = lds[i];
+  __syncthreads();
+  return total;
+}
+
+// One workgroup per bucket: sorts keys[lo, hi) ascending and drops duplicates; uniq[b] = number
+// kept.  A bucket that fits the LDS is sorted there in one go.  A larger one (5 x 10^8 keys per
+// set put 30 k keys in a bucket) is first partitioned by its top key bits into `scratch`
+// (same index range as `keys`), then every part is sorted in LDS and written back in order.
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_bucket_sort(const int64_t* __restrict__ offsets,
                                                       KeyT* __restrict__ keys,
+                                                      KeyT* __restrict__ scratch,
                                                       int64_t* __restrict__ uniq, int key_bits) {
   extern __shared__ unsigned char lds_raw[];
-  __shared__ int lds_cnt[4];
-  __shared__ uint32_t sub_cnt[(1 << kMaxSubBits) + 1];
-  __shared__ int s_overflow;
+  __shared__ SortLds sh;
+  __shared__ uint32_t part_end[(1 << kMaxSubBits) + 1];
   KeyT* lds = reinterpret_cast<KeyT*>(lds_raw);
   constexpr int kCap = kSortLdsBytes / int(sizeof(KeyT));
   const int64_t b = blockIdx.x;
@@ -155,145 +294,95 @@ __global__ __launch_bounds__(256) void k_bucket_sort(const int64_t* __restrict__
     return;
   }
   KeyT* g = keys + lo;
-  const bool in_lds = cnt64 <= kCap;
-  int64_t padded = 1;
-  while (padded < cnt64) padded <<= 1;
-  KeyT* buf = in_lds ? lds : g;
-  bool sorted = false;
-  if (in_lds) {
-    // Distribution sort: keys of one bucket are close to uniform, so one pass on the top
-    // `bits` key bits leaves sub-bins of a few keys each, finished by insertion sort (one
-    // thread per sub-bin).  A skewed bucket (a sub-bin over 64 keys) falls back to the
-    // bitonic network below.
-    const int cnt = int(cnt64);
-    int bits = 0;
-    while ((4 << bits) < cnt && bits < kMaxSubBits) bits++;
-    if (bits > key_bits) bits = key_bits;
-    const int n_sub = 1 << bits;
-    const int sh = key_bits - bits;
-    for (int i = threadIdx.x; i <= n_sub; i += 256) sub_cnt[i] = 0;
-    if (threadIdx.x == 0) s_overflow = 0;
-    __syncthreads();
-    for (int i = threadIdx.x; i < cnt; i += 256)
-      atomicAdd(&sub_cnt[uint32_t(uint64_t(g[i]) >> sh) & uint32_t(n_sub - 1)], 1u);
-    __syncthreads();
-    {  // exclusive scan of the sub-bin counts
-      const int per = (n_sub + 255) / 256;
-      const int c0 = min(int(threadIdx.x) * per, n_sub), c1 = min(c0 + per, n_sub);
-      int mine = 0;
-      for (int i = c0; i < c1; i++) mine += int(sub_cnt[i]);
-      const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-      int inc = mine;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const int o = __shfl_up(inc, d, 64);
-        if (lane >= d) inc += o;
-      }
-      if (lane == 63) lds_cnt[wave] = inc;
-      __syncthreads();
-      int run = inc - mine;
-      for (int w = 0; w < wave; w++) run += lds_cnt[w];
-      for (int i = c0; i < c1; i++) {
-        const int c = int(sub_cnt[i]);
-        sub_cnt[i] = uint32_t(run);
-        run += c;
-      }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < cnt; i += 256) {
-      const KeyT key = g[i];
-      const uint32_t pos = atomicAdd(&sub_cnt[uint32_t(uint64_t(key) >> sh) & uint32_t(n_sub - 1)], 1u);
-      lds[pos] = key;
-    }
-    __syncthreads();
-    // sub_cnt[b] is now the end of sub-bin b (= start of b + 1)
-    for (int b2 = threadIdx.x; b2 < n_sub; b2 += 256) {
-      const int s0 = b2 ? int(sub_cnt[b2 - 1]) : 0, s1 = int(sub_cnt[b2]);
-      if (s1 - s0 > 64) {
-        s_overflow = 1;
-      } else {
-        for (int i = s0 + 1; i < s1; i++) {
-          const KeyT x = lds[i];
-          int j = i - 1;
-          while (j >= s0 && lds[j] > x) {
-            lds[j + 1] = lds[j];
-            j--;
-          }
-          lds[j + 1] = x;
-        }
-      }
-    }
-    __syncthreads();
-    sorted = s_overflow == 0;
-  }
-  // Bitonic network in its all-ascending form (each merge starts with a mirror step), so
-  // the slots in [cnt64, padded) can stay virtual: a real key never moves above them.
-  const int64_t half = padded >> 1;
-  for (int64_t size = 2; !sorted && size <= padded; size <<= 1) {
-    const int64_t hs = size >> 1;
-    for (int64_t p = threadIdx.x; p < half; p += 256) {
-      const int64_t block = p / hs, o = p - block * hs;
-      const int64_t i = block * size + o, j = block * size + size - 1 - o;
-      if (j < cnt64) {
-        const KeyT x = buf[i], y = buf[j];
-        if (x > y) {
-          buf[i] = y;
-          buf[j] = x;
-        }
-      }
-    }
-    __syncthreads();
-    for (int64_t stride = size >> 2; stride > 0; stride >>= 1) {
-      for (int64_t p = threadIdx.x; p < half; p += 256) {
-        const int64_t i = 2 * stride * (p / stride) + (p % stride), j = i + stride;
-        if (j < cnt64) {
-          const KeyT x = buf[i], y = buf[j];
-          if (x > y) {
-            buf[i] = y;
-            buf[j] = x;
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
-  // duplicates
-  int kept_before = 0;
-  int64_t total = 0;
-  if (in_lds) {
-    // each thread owns a contiguous chunk
-    const int64_t per = (cnt64 + 255) / 256;
-    const int64_t c0 = min(int64_t(threadIdx.x) * per, cnt64), c1 = min(c0 + per, cnt64);
-    int mine = 0;
-    for (int64_t i = c0; i < c1; i++) mine += (i == 0 || buf[i] != buf[i - 1]);
-    // block exclusive scan of `mine`
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int inc = mine;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-      int o = __shfl_up(inc, d, 64);
-      if (lane >= d) inc += o;
-    }
-    if (lane == 63) lds_cnt[wave] = inc;
-    __syncthreads();
-    for (int w = 0; w < wave; w++) kept_before += lds_cnt[w];
-    total = lds_cnt[0] + lds_cnt[1] + lds_cnt[2] + lds_cnt[3];
-    kept_before += inc - mine;
-    int64_t at = kept_before;
-    for (int64_t i = c0; i < c1; i++)
-      if (i == 0 || buf[i] != buf[i - 1]) g[at++] = buf[i];
-  } else {
-    // serial compaction by one thread (oversize buckets are rare and already slow)
-    if (threadIdx.x == 0) {
-      int64_t at = 0;
-      for (int64_t i = 0; i < cnt64; i++)
-        if (i == 0 || g[i] != g[i - 1]) g[at++] = g[i];
-      lds_cnt[0] = 0;
-      uniq[b] = at;
-    }
+  if (cnt64 <= kCap) {
+    block_sort_into_lds(g, int(cnt64), key_bits, lds, &sh);
+    const int kept = block_unique_write(lds, int(cnt64), g, &sh);
+    if (threadIdx.x == 0) uniq[b] = kept;
     return;
   }
-  if (threadIdx.x == 0) uniq[b] = total;
+  // ---- oversize bucket: partition by the top `bits` key bits so that a part holds about
+  // kCap / 4 keys, then sort part by part
+  KeyT* tmp = scratch + lo;
+  int bits = 1;
+  while ((cnt64 >> bits) > kCap / 4 && bits < kMaxSubBits) bits++;
+  if (bits > key_bits) bits = key_bits;
+  const int n_part = 1 << bits;
+  const int shift = key_bits - bits;
+  for (int i = threadIdx.x; i <= n_part; i += 256) part_end[i] = 0;
+  __syncthreads();
+  for (int64_t i = threadIdx.x; i < cnt64; i += 256)
+    atomicAdd(&part_end[uint32_t(uint64_t(g[i]) >> shift) & uint32_t(n_part - 1)], 1u);
+  __syncthreads();
+  if (threadIdx.x == 0) {  // serial exclusive scan of <= 2048 counters
+    uint32_t run = 0;
+    for (int i = 0; i < n_part; i++) {
+      const uint32_t c = part_end[i];
+      part_end[i] = run;
+      run += c;
+    }
+  }
+  __syncthreads();
+  for (int64_t i = threadIdx.x; i < cnt64; i += 256) {
+    const KeyT key = g[i];
+    const uint32_t pos = atomicAdd(&part_end[uint32_t(uint64_t(key) >> shift) & uint32_t(n_part - 1)], 1u);
+    tmp[pos] = key;
+  }
+  __syncthreads();
+  // part_end[p] is now the end of part p
+  int64_t out = 0;
+  for (int p = 0; p < n_part; p++) {
+    const int64_t s0 = p ? int64_t(part_end[p - 1]) : 0, s1 = int64_t(part_end[p]);
+    const int64_t pc = s1 - s0;
+    if (pc == 0) continue;
+    if (pc <= kCap) {
+      block_sort_into_lds(tmp + s0, int(pc), shift, lds, &sh);
+      out += block_unique_write(lds, int(pc), g + out, &sh);
+    } else {
+      // a part that still does not fit (heavily skewed keys): bitonic network in global memory
+      KeyT* buf = tmp + s0;
+      int64_t padded = 1;
+      while (padded < pc) padded <<= 1;
+      const int64_t half = padded >> 1;
+      for (int64_t size = 2; size <= padded; size <<= 1) {
+        const int64_t hs = size >> 1;
+        for (int64_t q = threadIdx.x; q < half; q += 256) {
+          const int64_t block = q / hs, o = q - block * hs;
+          const int64_t i = block * size + o, j = block * size + size - 1 - o;
+          if (j < pc) {
+            const KeyT x = buf[i], y = buf[j];
+            if (x > y) {
+              buf[i] = y;
+              buf[j] = x;
+            }
+          }
+        }
+        __syncthreads();
+        for (int64_t stride = size >> 2; stride > 0; stride >>= 1) {
+          for (int64_t q = threadIdx.x; q < half; q += 256) {
+            const int64_t i = 2 * stride * (q / stride) + (q % stride), j = i + stride;
+            if (j < pc) {
+              const KeyT x = buf[i], y = buf[j];
+              if (x > y) {
+                buf[i] = y;
+                buf[j] = x;
+              }
+            }
+          }
+          __syncthreads();
+        }
+      }
+      if (threadIdx.x == 0) {
+        int64_t at = out;
+        for (int64_t i = 0; i < pc; i++)
+          if (i == 0 || buf[i] != buf[i - 1]) g[at++] = buf[i];
+        sh.kept = int(at - out);
+      }
+      __syncthreads();
+      out += sh.kept;
+      __syncthreads();
+    }
+  }
+  if (threadIdx.x == 0) uniq[b] = out;
 }
 
 template <typename KeyT>
@@ -419,9 +508,26 @@ int decode_write_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int 
                      size_t(nb) * 4, ctx->stream, s->d_words, n_words, s->n_bases, st.end_bits,
                      n_end_words, g->k, key_bits(g), int(nb), canonical_flag, wpg, st.hist, d_offsets,
                      keys);
-  // per-bucket sort + duplicate removal; uniq counts reuse st.totals
+  // per-bucket sort + duplicate removal; uniq counts reuse st.totals.  Buckets larger than the
+  // LDS capacity are partitioned through a scratch copy first; whether any exists is read off
+  // the bucket offsets (128 KiB to the host).
+  KeyT* scratch = nullptr;
+  {
+    std::vector<int64_t> h_off(static_cast<size_t>(nb + 1));
+    KSH_HIP(hipMemcpyAsync(h_off.data(), d_offsets, size_t(nb + 1) * 8, hipMemcpyDeviceToHost,
+                           ctx->stream));
+    KSH_HIP(hipStreamSynchronize(ctx->stream));
+    int64_t max_bucket = 0;
+    for (int64_t b = 0; b < nb; b++) max_bucket = std::max(max_bucket, h_off[b + 1] - h_off[b]);
+    if (max_bucket > int64_t(kSortLdsBytes / sizeof(KeyT))) {
+      void* ptr = nullptr;
+      KSH_TRY(pool_alloc(ctx, size_t(ctx->dec_kmers) * sizeof(KeyT), &ptr));
+      scratch = static_cast<KeyT*>(ptr);
+    }
+  }
   hipLaunchKernelGGL((k_bucket_sort<KeyT>), dim3(unsigned(nb)), dim3(256), kSortLdsBytes, ctx->stream,
-                     d_offsets, keys, st.totals, key_bits(g));
+                     d_offsets, keys, scratch, st.totals, key_bits(g));
+  if (scratch) pool_free(ctx, scratch);
   KSH_HIP(hipGetLastError());
   arena_reset(ctx);
   KSH_TRY(arena_reserve(ctx, a256(size_t(nb + 1) * 8) + (1u << 16)));

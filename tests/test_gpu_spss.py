@@ -187,3 +187,22 @@ def test_streamvbyte_0124(ctx):
     sp = ctx.spss_encode(dev_set(ctx, k, n_bits, oset.kmers()), mode=0)
     lens = sp.lens[: sp.n_strings].cpu().numpy().view(np.uint32)
     assert np.array_equal(ctx.svb_encode(lens), oset.compact().lengths_compressed())
+
+
+@pytest.mark.parametrize("geom", [(13, 2, 4), (19, 2, 8), (13, 1, 4)])
+def test_decode_oversize_buckets(ctx, geom):
+    """Buckets larger than the LDS sort capacity (what 5 x 10^8 keys per set produce at N = 14)
+    go through the partition path; forced here with very few buckets.  Repeated k-mers across
+    lines must still collapse."""
+    k, n, kb = geom
+    kmers = synth.random_read_kmers(k, 60000, seed=31 + k, canonical=True)
+    oset = ol.Set.from_kmers(k, n, kb, kmers)
+    strings = oset.spss()
+    strings = strings + strings[:50]          # duplicates
+    sp = capi.DeviceSpss.from_strings(capi.geom(k, n), strings, ctx.device)
+    got = ctx.spss_decode(sp)
+    assert got.n_keys == oset.size()
+    assert np.array_equal(got.kmers(), oset.kmers())
+    # and the encoder on such a set (probes through big buckets)
+    d = dev_set(ctx, k, n, oset.kmers())
+    assert ctx.spss_encode(d, mode=0).to_strings() == oset.spss()

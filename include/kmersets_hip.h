@@ -197,7 +197,10 @@ int ksh_spss_encode_release(ksh_ctx* ctx);
  * KmerSetCompact containers (device); bucket_ids replaces the unseeded
  * GetRandomInts((1 << N) / 50, ...) of :123-124 (HOST array, ascending);
  * max_iterations < 0 runs to the reference's stopping rule.  The input containers
- * must stay alive while they are nodes of the result. */
+ * must stay alive while they are nodes of the result, and the context must outlive the
+ * result.  The three re-encodes of a merge (:345-360) are deferred to the points where the
+ * reference reads them (Weight() at the convergence checks, :287, and the final nodes): same
+ * values, fewer encodes.  Synchronises the stream before returning. */
 typedef struct ksh_kss ksh_kss;
 int ksh_kss_build(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* inputs, int32_t n_inputs,
                   const int32_t* bucket_ids, int32_t n_ids, int canonical, int32_t max_iterations,

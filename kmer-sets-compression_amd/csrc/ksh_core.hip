@@ -434,7 +434,9 @@ int ksh_ctx_create(int device, void* stream, ksh_ctx** out) {
   if (stream) {
     ctx->stream = static_cast<hipStream_t>(stream);
   } else {
-    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    // a blocking stream: the plain hipMemcpy calls behind ksh_memcpy_* (legacy default stream)
+    // then order themselves after the kernels enqueued here
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamDefault);
     if (e != hipSuccess) {
       delete ctx;
       return fail(KSH_INTERNAL, "hipStreamCreate failed: %s", hipGetErrorString(e));

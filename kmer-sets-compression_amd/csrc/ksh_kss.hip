@@ -31,6 +31,7 @@ struct KssCompact {
   uint32_t* lens = nullptr;
   int64_t n_strings = 0, n_bases = 0, size = 0;
   bool owned = false;
+  bool valid = true;  // false: the node's set changed and its SPSS has not been re-encoded yet
 };
 
 struct ksh_kss {
@@ -46,6 +47,7 @@ struct ksh_kss {
   std::vector<int64_t> initial_weights;
   int64_t initial_total_size = 0, final_total_size = 0, initial_spss_weight = 0, n_processed = 0;
   int64_t final_spss_weight = 0;
+  int64_t n_encodes = 0, n_encoded_kmers = 0;
   std::string meta;
 };
 
@@ -102,6 +104,23 @@ static int encode_set(ksh_ctx* ctx, const ksh_geom* g, const KssSet& s, KssCompa
   out->n_strings = ns;
   out->n_bases = nbases;
   out->size = s.n;
+  out->valid = true;
+  return KSH_OK;
+}
+
+// The reference re-encodes the three nodes of every merge at once (kmer_set_set.h:345-360), but
+// reads the result only through Weight() at the convergence checks (:287) and at the end.  A
+// node that is merged again before the next check never needs its intermediate SPSS, so the
+// encode is deferred to the points where the reference looks: same values, fewer encodes.
+static int ensure_compacts(ksh_kss* k) {
+  for (size_t i = 0; i < k->compacts.size(); i++) {
+    if (k->compacts[i].valid) continue;
+    KssCompact c;
+    KSH_TRY(encode_set(k->ctx, &k->g, k->sets[i], &c));
+    k->compacts[i] = c;
+    k->n_encodes++;
+    k->n_encoded_kmers += k->sets[i].n;
+  }
   return KSH_OK;
 }
 
@@ -164,12 +183,14 @@ static int build(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs,
   k->initial_total_size = total_size;
   k->n_processed = total_size;
 
-  const auto total_spss_weight_now = [&] {
-    int64_t total = 0;
-    for (const KssCompact& c : k->compacts) total += c.n_bases;
-    return total;
+  const auto total_spss_weight_now = [&](int64_t* total) {
+    KSH_TRY(ensure_compacts(k));
+    *total = 0;
+    for (const KssCompact& c : k->compacts) *total += c.n_bases;
+    return KSH_OK;
   };
-  int64_t total_spss_weight = total_spss_weight_now();
+  int64_t total_spss_weight = 0;
+  KSH_TRY(total_spss_weight_now(&total_spss_weight));
   k->initial_spss_weight = total_spss_weight;
 
   const int interval = int(k->compacts.size() / 8 + 1);
@@ -178,7 +199,8 @@ static int build(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs,
   for (int i = 0;; i++) {
     if (max_iterations >= 0 && i >= max_iterations) break;
     if (i > 0 && i % interval == 0) {
-      const int64_t updated = total_spss_weight_now();
+      int64_t updated = 0;
+      KSH_TRY(total_spss_weight_now(&updated));
       const float improvement = static_cast<float>(total_spss_weight - updated) / total_spss_weight;
       const bool stop = improvement <= improvement_threshold;
       k->checkpoints.insert(k->checkpoints.end(), {int64_t(i), total_spss_weight, updated, int64_t(stop)});
@@ -212,10 +234,11 @@ static int build(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs,
       KSH_TRY(alloc_keys(ctx, g, totals[2], &sk));
       KSH_TRY(ksh_pair_write(ctx, g, &vj, &vk, sn.keys, sj.keys, sk.keys));
 
-      KssCompact cn, cj, ck;
-      KSH_TRY(encode_set(ctx, g, sn, &cn));
-      KSH_TRY(encode_set(ctx, g, sj, &cj));
-      KSH_TRY(encode_set(ctx, g, sk, &ck));
+      KssCompact cn, cj, ck;  // encoded lazily (ensure_compacts)
+      cn.valid = cj.valid = ck.valid = false;
+      cn.size = sn.n;
+      cj.size = sj.n;
+      ck.size = sk.n;
 
       k->sets.push_back(sn);
       k->compacts.push_back(cn);
@@ -253,7 +276,8 @@ static int build(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs,
     }
   }
   k->final_total_size = total_size;
-  k->final_spss_weight = total_spss_weight_now();
+  KSH_TRY(total_spss_weight_now(&k->final_spss_weight));
+  KSH_HIP(hipStreamSynchronize(ctx->stream));  // the node views are usable when build returns
   k->meta = serialize_children(k->children);
   return KSH_OK;
 }

@@ -5,7 +5,9 @@
 
 Workload at N = 1 (BASELINE.json configs[1]): 4 synthetic canonical k=23 sets of
 10^7 k-mers each (seeded phylogeny family), resident in HBM as
-bucketed sorted keys; one step = the pair algebra of all 6 pairs -- for each pair
+bucketed sorted keys; one step = the pair algebra of all 6 pairs (one
+ksh_pair_algebra_batch call: the pairs are independent, so their passes are enqueued back to
+back and one stream synchronisation returns all the sizes) -- for each pair
 (A, B): A&B, A\\B, B\\A with their bucket offsets and the three counts (what one
 KmerSetSet iteration asks for, lib/core/kmer_set_set.h:339-343), Diff = |A\\B| +
 |B\\A| derived from them.  Units = sum over pairs of (|A| + |B|) k-mers.
@@ -53,6 +55,9 @@ def main():
     ap.add_argument("--two-pass", action="store_true",
                     help="use ksh_pair_plan + allocate + ksh_pair_write (exact-size outputs) "
                          "instead of the one-call ksh_pair_algebra (upper-bound outputs)")
+    ap.add_argument("--per-pair-sync", action="store_true",
+                    help="one ksh_pair_algebra call (and one stream sync) per pair instead of one "
+                         "ksh_pair_algebra_batch call per step")
     ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
     args = ap.parse_args()
 
@@ -108,8 +113,11 @@ def main():
 
     def step(record):
         diffs = []
-        for (i, j) in pairs:
-            inter, amb, bma = algebra(sets[i], sets[j])
+        if args.per_pair_sync or args.two_pass:
+            results = [algebra(sets[i], sets[j]) for (i, j) in pairs]
+        else:
+            results = ctx.pair_algebra_batch([(sets[i], sets[j]) for (i, j) in pairs])
+        for (i, j), (inter, amb, bma) in zip(pairs, results):
             diffs.append(amb.n_keys + bma.n_keys)
             if record:
                 union = sets[i].n_keys + bma.n_keys

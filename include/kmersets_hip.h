@@ -115,6 +115,17 @@ int ksh_pair_algebra(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, con
                      int64_t* d_off_i, int64_t* d_off_amb, int64_t* d_off_bma, void* d_keys_i,
                      void* d_keys_amb, void* d_keys_bma, int64_t totals[3]);
 
+/* Many independent pairs (a pairwise diff matrix, the reference's pooled loops over pairs,
+ * lib/core/kmer_set_set.h:205-216): every pair's two passes are enqueued back to back and one
+ * stream synchronisation returns all totals.  Buffers as for ksh_pair_algebra. */
+typedef struct ksh_pair_job {
+  ksh_set_view a, b;
+  int64_t *d_off_i, *d_off_amb, *d_off_bma; /* int64[2^N + 1] each                         */
+  void *d_keys_i, *d_keys_amb, *d_keys_bma; /* >= min(|A|,|B|), |A|, |B| keys               */
+  int64_t totals[3];                        /* out: |A & B|, |A \ B|, |B \ A|               */
+} ksh_pair_job;
+int ksh_pair_algebra_batch(ksh_ctx* ctx, const ksh_geom* g, ksh_pair_job* jobs, int32_t n_jobs);
+
 /* KmerSet::Add(other) / free Add (lib/core/kmer_set.h:164-174,286-290): A | B, same
  * two-call shape.  d_off_u is int64[2^N + 1]; d_keys_u holds `total` keys. */
 int ksh_set_union_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a,

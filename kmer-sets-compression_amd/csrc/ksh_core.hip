@@ -468,6 +468,7 @@ int ksh_ctx_destroy(ksh_ctx* ctx) {
   for (int i = 0; i < 2; i++)
     if (ctx->slot[i]) (void)hipFree(ctx->slot[i]);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
+  if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
   for (hipEvent_t ev : ctx->ev_pool)
     if (ev) (void)hipEventDestroy(ev);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);

@@ -52,6 +52,8 @@ struct ksh_ctx {
 
   // pinned host staging for small read-backs
   int64_t* h_pinned = nullptr;  // 64 int64
+  int64_t* h_batch = nullptr;   // pinned, grown on demand (ksh_pair_algebra_batch totals)
+  size_t h_batch_count = 0;
 
   // persistent device buffers that must survive between two calls
   // (decode plan -> write, encode plan -> write)

@@ -18,6 +18,7 @@
 #include "ksh_internal.h"
 
 #include <algorithm>
+#include <type_traits>
 #include <vector>
 
 namespace ksh {
@@ -467,14 +468,18 @@ int pair_write_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const k
 
 // Plan + write back to back with caller-provided upper-bound buffers: one stream sync
 // (for the totals) instead of two and no allocation between the passes.
+inline size_t pair_scratch_bytes(int64_t nb, int64_t max_tiles) {
+  return plan_bytes(nb, max_tiles) + size_t(max_tiles / 256 + 4096) * 8 + (1u << 16);
+}
+
+// Enqueues both passes of one pair; the three totals land in d_totals (device).  The scratch
+// arena must already be large enough (reuse across consecutive pairs is stream-ordered).
 template <typename KeyT>
-int pair_algebra_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
-                   int64_t* d_off_i, int64_t* d_off_amb, int64_t* d_off_bma, void* d_keys_i,
-                   void* d_keys_amb, void* d_keys_bma, int64_t totals[3]) {
+int pair_algebra_enqueue(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
+                         int64_t* d_off_i, int64_t* d_off_amb, int64_t* d_off_bma, void* d_keys_i,
+                         void* d_keys_amb, void* d_keys_bma, int64_t* d_totals) {
   const int64_t nb = n_buckets(g);
   const int64_t max_tiles = nb + (a->n_keys + b->n_keys) / kTile + 1;
-  if (max_tiles > int64_t(0x7FFFFFF0)) return fail(KSH_INVALID_ARGUMENT, "pair too large for one launch");
-  KSH_TRY(arena_reserve(ctx, plan_bytes(nb, max_tiles) + size_t(max_tiles / 256 + 4096) * 8 + (1u << 16)));
   arena_reset(ctx);
   char* base = static_cast<char*>(arena_alloc(ctx, plan_bytes(nb, max_tiles)));
   Plan p;
@@ -483,8 +488,6 @@ int pair_algebra_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const
                         static_cast<const KeyT*>(b->d_keys), b->d_offsets};
   KSH_TRY((plan_tile_base<KeyT>(ctx, segs, nb, p.tile_base)));
   KSH_TRY((plan_count<KeyT>(ctx, segs, p, 1)));
-  int64_t* d_totals = static_cast<int64_t*>(arena_alloc(ctx, 3 * sizeof(int64_t)));
-  if (!d_totals) return fail(KSH_INTERNAL, "scratch arena too small");
   hipLaunchKernelGGL(k_result_offsets, dim3(blocks_for(nb + 1, 256)), dim3(256), 0, ctx->stream,
                      a->d_offsets, b->d_offsets, p.tile_base, p.tile_ioff, p.total_m, nb, d_off_i,
                      d_off_amb, d_off_bma, d_totals);
@@ -496,12 +499,56 @@ int pair_algebra_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const
                        static_cast<KeyT*>(d_keys_bma));
   }
   KSH_HIP(hipGetLastError());
-  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, d_totals, 3 * sizeof(int64_t), hipMemcpyDeviceToHost,
-                         ctx->stream));
-  KSH_HIP(hipStreamSynchronize(ctx->stream));
-  totals[0] = ctx->h_pinned[0];
-  totals[1] = ctx->h_pinned[1];
-  totals[2] = ctx->h_pinned[2];
+  return KSH_OK;
+}
+
+// One pair or many: all pairs are enqueued back to back and ONE stream synchronisation brings
+// every pair's totals to the host (the pairs of a batch are independent, as in the reference's
+// pooled loops over pairs, kmer_set_set.h:205-216).
+template <typename KeyT>
+int pair_algebra_batch_t(ksh_ctx* ctx, const ksh_geom* g, ksh_pair_job* jobs, int32_t n_jobs) {
+  const int64_t nb = n_buckets(g);
+  size_t need = 0;
+  for (int32_t i = 0; i < n_jobs; i++) {
+    const int64_t max_tiles = nb + (jobs[i].a.n_keys + jobs[i].b.n_keys) / kTile + 1;
+    if (max_tiles > int64_t(0x7FFFFFF0)) return fail(KSH_INVALID_ARGUMENT, "pair too large for one launch");
+    need = std::max(need, pair_scratch_bytes(nb, max_tiles));
+  }
+  KSH_TRY(arena_reserve(ctx, need));
+  void* tot = nullptr;
+  KSH_TRY(pool_alloc(ctx, size_t(n_jobs) * 3 * sizeof(int64_t), &tot));
+  int64_t* d_totals = static_cast<int64_t*>(tot);
+  int rc = KSH_OK;
+  for (int32_t i = 0; i < n_jobs && rc == KSH_OK; i++) {
+    ksh_pair_job& j = jobs[i];
+    rc = pair_algebra_enqueue<KeyT>(ctx, g, &j.a, &j.b, j.d_off_i, j.d_off_amb, j.d_off_bma, j.d_keys_i,
+                                    j.d_keys_amb, j.d_keys_bma, d_totals + 3 * i);
+  }
+  const size_t n_vals = static_cast<size_t>(n_jobs) * 3;
+  int64_t* h = ctx->h_pinned;  // 64 values
+  if (n_vals > 64) {
+    if (ctx->h_batch_count < n_vals) {
+      if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
+      ctx->h_batch = nullptr;
+      ctx->h_batch_count = 0;
+      if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_batch), n_vals * 2 * sizeof(int64_t)) != hipSuccess) {
+        pool_free(ctx, tot);
+        return fail(KSH_INTERNAL, "hipHostMalloc failed");
+      }
+      ctx->h_batch_count = n_vals * 2;
+    }
+    h = ctx->h_batch;
+  }
+  if (rc == KSH_OK) {
+    hipError_t e = hipMemcpyAsync(h, d_totals, n_vals * sizeof(int64_t), hipMemcpyDeviceToHost,
+                                  ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) rc = fail(KSH_INTERNAL, "totals read-back failed: %s", hipGetErrorString(e));
+  }
+  pool_free(ctx, tot);
+  if (rc != KSH_OK) return rc;
+  for (int32_t i = 0; i < n_jobs; i++)
+    for (int q = 0; q < 3; q++) jobs[i].totals[q] = h[size_t(3 * i + q)];
   return KSH_OK;
 }
 
@@ -687,10 +734,30 @@ int ksh_pair_algebra(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, con
   KSH_TRY(check_view(a, "a"));
   KSH_TRY(check_view(b, "b"));
   KSH_HIP(hipSetDevice(ctx->device));
-  return g->key_bytes == 4 ? pair_algebra_t<uint32_t>(ctx, g, a, b, d_off_i, d_off_amb, d_off_bma,
-                                                      d_keys_i, d_keys_amb, d_keys_bma, totals)
-                           : pair_algebra_t<uint64_t>(ctx, g, a, b, d_off_i, d_off_amb, d_off_bma,
-                                                      d_keys_i, d_keys_amb, d_keys_bma, totals);
+  ksh_pair_job job{*a, *b, d_off_i, d_off_amb, d_off_bma, d_keys_i, d_keys_amb, d_keys_bma, {0, 0, 0}};
+  const int rc = g->key_bytes == 4 ? pair_algebra_batch_t<uint32_t>(ctx, g, &job, 1)
+                                   : pair_algebra_batch_t<uint64_t>(ctx, g, &job, 1);
+  if (rc != KSH_OK) return rc;
+  totals[0] = job.totals[0];
+  totals[1] = job.totals[1];
+  totals[2] = job.totals[2];
+  return KSH_OK;
+}
+
+int ksh_pair_algebra_batch(ksh_ctx* ctx, const ksh_geom* g, ksh_pair_job* jobs, int32_t n_jobs) {
+  if (!ctx || (n_jobs > 0 && !jobs)) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  KSH_TRY(check_geom(g));
+  if (n_jobs <= 0) return KSH_OK;
+  for (int32_t i = 0; i < n_jobs; i++) {
+    KSH_TRY(check_view(&jobs[i].a, "jobs[i].a"));
+    KSH_TRY(check_view(&jobs[i].b, "jobs[i].b"));
+    if (!jobs[i].d_off_i || !jobs[i].d_off_amb || !jobs[i].d_off_bma || !jobs[i].d_keys_i ||
+        !jobs[i].d_keys_amb || !jobs[i].d_keys_bma)
+      return fail(KSH_INVALID_ARGUMENT, "jobs[%d] has a NULL output", i);
+  }
+  KSH_HIP(hipSetDevice(ctx->device));
+  return g->key_bytes == 4 ? pair_algebra_batch_t<uint32_t>(ctx, g, jobs, n_jobs)
+                           : pair_algebra_batch_t<uint64_t>(ctx, g, jobs, n_jobs);
 }
 
 int ksh_set_union_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a,

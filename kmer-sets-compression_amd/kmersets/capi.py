@@ -39,6 +39,12 @@ class SpssView(C.Structure):
                 ("n_bases", C.c_int64)]
 
 
+class PairJob(C.Structure):
+    _fields_ = [("a", SetView), ("b", SetView), ("d_off_i", C.c_void_p), ("d_off_amb", C.c_void_p),
+                ("d_off_bma", C.c_void_p), ("d_keys_i", C.c_void_p), ("d_keys_amb", C.c_void_p),
+                ("d_keys_bma", C.c_void_p), ("totals", C.c_int64 * 3)]
+
+
 def build(force=False):
     """Compiles the HIP sources for gfx950 (hipcc cross-compiles without a GPU)."""
     srcs = [os.path.join(CSRC_DIR, f) for f in os.listdir(CSRC_DIR) if f.endswith((".hip", ".h"))]
@@ -88,6 +94,7 @@ def lib():
         "ksh_pair_write": (C.c_int, [vp, GP, SP, SP, vp, vp, vp]),
         "ksh_set_diff": (C.c_int, [vp, GP, SP, SP, C.POINTER(i64)]),
         "ksh_pair_algebra": (C.c_int, [vp, GP, SP, SP, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]),
+        "ksh_pair_algebra_batch": (C.c_int, [vp, GP, C.POINTER(PairJob), i32]),
         "ksh_pair_weights": (C.c_int, [vp, GP, SP, i32, C.POINTER(i32), i32, C.POINTER(i32), i32,
                                        C.POINTER(i64)]),
         "ksh_spss_size": (C.c_int, [vp, GP, C.POINTER(SpssView), C.POINTER(i64)]),
@@ -389,6 +396,32 @@ class Context:
         used = C.c_int64()
         check(lib().ksh_svb_decode_0124(self.h, d_in.data_ptr(), n, d_out.data_ptr(), C.byref(used)))
         return d_out[:n].cpu().numpy().view(np.uint32), used.value
+
+    def pair_algebra_batch(self, pairs):
+        """[(A, B), ...] -> [(A & B, A \\ B, B \\ A), ...]: all pairs enqueued back to back, one
+        stream synchronisation for every pair's sizes (ksh_pair_algebra_batch)."""
+        import torch
+
+        g = pairs[0][0].g
+        jobs = (PairJob * len(pairs))()
+        outs = []
+        for idx, (a, b) in enumerate(pairs):
+            caps = (min(a.n_keys, b.n_keys), a.n_keys, b.n_keys)
+            trio = []
+            for cap in caps:
+                o = DeviceSet.empty_like_offsets(g, 0, self.device)
+                o.keys = torch.empty(max(cap * g.key_bytes, 16), dtype=torch.uint8, device=self.device)
+                trio.append(o)
+            outs.append(trio)
+            j = jobs[idx]
+            j.a, j.b = a.view(), b.view()
+            j.d_off_i, j.d_off_amb, j.d_off_bma = (t.offsets.data_ptr() for t in trio)
+            j.d_keys_i, j.d_keys_amb, j.d_keys_bma = (t.keys.data_ptr() for t in trio)
+        check(lib().ksh_pair_algebra_batch(self.h, C.byref(g), jobs, len(pairs)))
+        for idx, trio in enumerate(outs):
+            for o, n in zip(trio, jobs[idx].totals):
+                o.n_keys = int(n)
+        return outs
 
     def set_union(self, a, b):
         """KmerSet::Add: A | B as a new DeviceSet."""

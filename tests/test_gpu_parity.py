@@ -170,6 +170,8 @@ def test_config2_properties(ctx):
             a, b = d[i], d[j]
             inter, amb, bma = ctx.pair_algebra(a, b)
             i1, a1, b1 = ctx.pair_algebra_onepass(a, b)
+            i2, a2, b2 = ctx.pair_algebra_batch([(a, b), (b, a)])[1]     # batch form, swapped pair
+            assert ctx.set_diff(i2, inter) == 0 and ctx.set_diff(a2, bma) == 0 and ctx.set_diff(b2, amb) == 0
             assert ctx.set_diff(i1, inter) == 0 and ctx.set_diff(a1, amb) == 0 and ctx.set_diff(b1, bma) == 0
             assert bool(torch.equal(i1.offsets, inter.offsets)) and bool(torch.equal(b1.offsets, bma.offsets))
             assert inter.n_keys + amb.n_keys == a.n_keys

@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kScanThreads) void k_scan_fix(int64_t* __restrict__
 }
 
 // Small inputs (bucket counts, tile counts): one 1024-thread workgroup, one launch.
-constexpr int64_t kScanSmallMax = 16640;  // bucket-count scans; beyond this one CU's bandwidth is the limit
+constexpr int64_t kScanSmallMax = 4096;  // beyond this the two-launch tiled scan is faster than one CU
 
 __global__ __launch_bounds__(1024) void k_scan_small(const int64_t* __restrict__ in,
                                                       int64_t* __restrict__ out, int64_t n,

@@ -6,9 +6,9 @@
 // A set is one ascending array of k-mers with a bucket index, so every one of
 // these is a merge of two sorted ranges per bucket.  The work is cut into
 // *segments* (one per bucket of a pair, or one per (pair, sampled bucket)) and each
-// segment into *tiles* of at most kTileCap (1024) merged keys by merge-path; one
+// segment into *tiles* of a bounded number of merged keys (TileCfg) by merge-path; one
 // wavefront per tile stages the tile's two key ranges in LDS with 16-byte coalesced
-// loads, every lane merges kVT (16) keys from LDS, and the three result streams are
+// loads, every lane merges up to kVT keys from LDS, and the three result streams are
 // compacted in LDS and written back coalesced.  HBM-bound integer work; no MFMA.
 //
 // Tie rule: on equal keys the A key is merged first, so a common key shows up as
@@ -18,19 +18,35 @@
 #include "ksh_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include <vector>
 
 namespace ksh {
 
-// One wavefront per tile: 64 lanes x 16 keys.  Tiles are bounded by buckets (about 1.2 k
-// merged keys per bucket at 10^7 keys per set), so the kernel is latency-bound per tile;
-// single-wave workgroups put 4x more tiles in flight per CU than 256-thread ones and need
-// no cross-wave scan.
+// One wavefront per tile: 64 lanes x up to kVT keys each.  A bucket of a pair holds about
+// 1.2 k merged keys at 10^7 keys per set, and the per-tile fixed cost (descriptor and key
+// loads, the split search, the wave scan) is what a small tile pays for, so 4-byte keys use
+// tiles large enough to take such a bucket whole.  Single-wave workgroups need no cross-wave
+// scan and no barrier that waits for another wave.  The LDS footprint (6 KB) keeps 26
+// tiles in flight per CU; 8-byte keys use smaller tiles to stay at that occupancy.
 constexpr int kThreads = 64;
-constexpr int kVT = 16;                    // merged keys per lane
-constexpr int kTile = kThreads * kVT - 1;  // diagonal spacing (the +1 is the tie fix-up)
-constexpr int kTileCap = kThreads * kVT;   // LDS capacity in keys
+
+template <typename KeyT>
+struct TileCfg {
+#ifndef KSH_VT32
+#define KSH_VT32 15
+#endif
+  static constexpr int kVT = sizeof(KeyT) == 4 ? KSH_VT32 : 11;  // merged keys per lane, at most (odd)
+  static constexpr int kTile = kThreads * kVT - 1;          // largest diagonal span (+1: tie fix-up)
+  static constexpr int kCap = kThreads * kVT;               // keys in a tile, at most
+  static constexpr int kPer = 16 / int(sizeof(KeyT));       // keys per 16-byte vector
+  // A and B each keep their 16-byte phase (up to kPer - 1 slots before each, and the last
+  // vector of each side may run kPer - 1 past it); kVT + 1 slots after B are only read.
+  static constexpr int kLds = (kCap + 4 * (kPer - 1) + kVT + 1 + 63) & ~63;
+  // 16-byte vectors that cover a tile's two ranges, per lane (both ranges rounded outwards)
+  static constexpr int kVecs = (kCap / kPer + 2 + kThreads - 1) / kThreads;
+};
 
 // ---- segment sources -------------------------------------------------------------
 // One segment per bucket of a pair of sets.
@@ -97,7 +113,7 @@ __global__ __launch_bounds__(256) void k_seg_tiles(Segs segs, int64_t n_segs,
   int64_t a_lo, a_hi, b_lo, b_hi;
   segs.get(s, a, a_lo, a_hi, b, b_lo, b_hi);
   const int64_t len = (a_hi - a_lo) + (b_hi - b_lo);
-  tiles_per_seg[s] = (len + kTile - 1) / kTile;
+  tiles_per_seg[s] = (len + TileCfg<KeyT>::kTile - 1) / TileCfg<KeyT>::kTile;
 }
 
 // Merge-path split of (a[0, na), b[0, nb)) at `diag` (A first on ties); a common key's
@@ -137,10 +153,14 @@ __global__ __launch_bounds__(256) void k_tile_split(Segs segs, int64_t n_segs,
   int64_t a_lo, a_hi, b_lo, b_hi;
   segs.get(s, a, a_lo, a_hi, b, b_lo, b_hi);
   const int64_t na = a_hi - a_lo, nb = b_hi - b_lo;
-  const int64_t diag = (t - tile_base[s]) * kTile;
+  // the segment's tiles share its keys evenly (each at most TileCfg::kTile): the merge kernel's cost
+  // follows the keys in a tile, not the tile count
+  const int64_t q = t - tile_base[s], n_tiles = tile_base[s + 1] - tile_base[s];
+  const int64_t diag = q * (na + nb) / n_tiles;
+  const int64_t diag_end = (q + 1) * (na + nb) / n_tiles;
   int64_t i0, j0, i1 = na, j1 = nb;
   merge_path_split(a + a_lo, na, b + b_lo, nb, diag, &i0, &j0);
-  if (diag + kTile < na + nb) merge_path_split(a + a_lo, na, b + b_lo, nb, diag + kTile, &i1, &j1);
+  if (q + 1 < n_tiles) merge_path_split(a + a_lo, na, b + b_lo, nb, diag_end, &i1, &j1);
   TileDesc d;
   d.pa = a + a_lo + i0;
   d.pb = b + b_lo + j0;
@@ -151,160 +171,283 @@ __global__ __launch_bounds__(256) void k_tile_split(Segs segs, int64_t n_segs,
   desc[t] = d;
 }
 
-// Coalesced staging of src[0, cnt) into LDS by one wave: 16-byte global loads on the
-// aligned interior, scalar loads on the ragged ends.
+// A tile's keys travel global -> registers -> LDS as whole 16-byte vectors, A's vectors
+// first and B's after them: vector v of the wave is A's v-th vector if v < va, else B's
+// (v - va)-th.  The vector holding a range's first key goes to a 16-byte aligned LDS slot, so
+// key k of the range lands `mis` slots after it (mis = the range's position inside its
+// 16-byte chunk in global memory), global loads are 16 B per lane and LDS writes are
+// ds_write_b128.  The first and last vector of a range may carry up to kPer - 1 keys that
+// are not part of it; they belong to the same aligned 16-byte chunk of the key array as a
+// key that is, so the loads stay inside the array's memory.  Keys live in device memory:
+// address space 1 keeps the loads global_load instead of flat_load.
 template <typename KeyT>
-__device__ __forceinline__ void stage(const KeyT* __restrict__ src, int cnt, KeyT* __restrict__ dst) {
-  constexpr int kPer = 16 / int(sizeof(KeyT));
-  const int mis = int((reinterpret_cast<uintptr_t>(src) / sizeof(KeyT)) & (kPer - 1));
-  const int head = (kPer - mis) & (kPer - 1);
-  const int h = head < cnt ? head : cnt;
-  if (int(threadIdx.x) < h) dst[threadIdx.x] = src[threadIdx.x];
-  const int n_vec = (cnt - h) / kPer;
-  using Vec = typename std::conditional<sizeof(KeyT) == 4, uint4, ulonglong2>::type;
-  const Vec* vp = reinterpret_cast<const Vec*>(src + h);
-  for (int v = threadIdx.x; v < n_vec; v += kThreads) {
-    const Vec x = vp[v];
-    KeyT* d = dst + h + v * kPer;
-    if constexpr (sizeof(KeyT) == 4) {
-      d[0] = x.x;
-      d[1] = x.y;
-      d[2] = x.z;
-      d[3] = x.w;
-    } else {
-      d[0] = x.x;
-      d[1] = x.y;
+struct TileStage {
+  using Cfg = TileCfg<KeyT>;
+  static constexpr int kPer = Cfg::kPer;
+  typedef KeyT Vec __attribute__((ext_vector_type(kPer)));
+  typedef const Vec __attribute__((address_space(1))) * GlobalVecs;
+
+  int a_lo, a_hi, b_lo, b_hi;  // LDS key indices of the two ranges
+  uint32_t va, vb, b_vec0;     // vectors of A, of B; LDS vector index of B's first vector
+  GlobalVecs ga, gb;
+
+  __device__ __forceinline__ void init(const TileDesc& d) {
+    const uintptr_t pa = reinterpret_cast<uintptr_t>(d.pa), pb = reinterpret_cast<uintptr_t>(d.pb);
+    const int mis_a = int((pa / sizeof(KeyT)) & (kPer - 1)), mis_b = int((pb / sizeof(KeyT)) & (kPer - 1));
+    ga = (GlobalVecs)(pa & ~uintptr_t(15));
+    gb = (GlobalVecs)(pb & ~uintptr_t(15));
+    va = d.ca > 0 ? uint32_t(mis_a + d.ca + kPer - 1) / kPer : 0u;
+    vb = d.cb > 0 ? uint32_t(mis_b + d.cb + kPer - 1) / kPer : 0u;
+    a_lo = mis_a;
+    a_hi = a_lo + d.ca;
+    b_vec0 = uint32_t(a_hi + kPer - 1) / kPer;
+    b_lo = int(b_vec0) * kPer + mis_b;
+    b_hi = b_lo + d.cb;
+  }
+  // global -> LDS, one range after the other
+  __device__ __forceinline__ void copy(KeyT* lds) const {
+    Vec* l = reinterpret_cast<Vec*>(lds);
+    for (uint32_t v = threadIdx.x; v < va; v += kThreads) l[v] = ga[v];
+    for (uint32_t v = threadIdx.x; v < vb; v += kThreads) l[b_vec0 + v] = gb[v];
+  }
+  __device__ __forceinline__ void load(Vec (&r)[Cfg::kVecs]) const {
+#pragma unroll
+    for (int j = 0; j < Cfg::kVecs; j++) {
+      const uint32_t v = threadIdx.x + j * kThreads;
+      if (v < va + vb) r[j] = *(v < va ? ga + v : gb + (v - va));
     }
   }
-  const int done = h + n_vec * kPer;
-  if (int(threadIdx.x) < cnt - done) dst[done + threadIdx.x] = src[done + threadIdx.x];
+  __device__ __forceinline__ void store(const Vec (&r)[Cfg::kVecs], KeyT* lds) const {
+    Vec* l = reinterpret_cast<Vec*>(lds);
+#pragma unroll
+    for (int j = 0; j < Cfg::kVecs; j++) {
+      const uint32_t v = threadIdx.x + j * kThreads;
+      if (v < va + vb) l[v < va ? v : b_vec0 + (v - va)] = r[j];
+    }
+  }
+};
+
+// Copies cnt keys from LDS (starting at key index lds_first) to out[0, cnt), one wave,
+// coalesced.  Offsets are 32-bit byte offsets from a wave-uniform base, which lets the
+// stores use the scalar-base addressing form.
+template <typename KeyT>
+__device__ __forceinline__ void copy_out(const KeyT* __restrict__ lds, uint32_t lds_first,
+                                         uint32_t cnt, KeyT* out) {
+  typedef char __attribute__((address_space(1))) * GlobalBytes;
+  typedef KeyT __attribute__((address_space(1))) * GlobalKeys;
+  GlobalBytes o = (GlobalBytes)out;
+  const char* l = reinterpret_cast<const char*>(lds + lds_first);
+  const uint32_t end = cnt * uint32_t(sizeof(KeyT));
+#pragma unroll 2
+  for (uint32_t x = threadIdx.x * uint32_t(sizeof(KeyT)); x < end; x += kThreads * uint32_t(sizeof(KeyT)))
+    *(GlobalKeys)(o + x) = *reinterpret_cast<const KeyT*>(l + x);
 }
 
-// ---- the merge kernel ------------------------------------------------------------------------
-// kMode == 0: tile_m[t] = number of common keys in tile t.
-// kMode == 1: compacts the tile's A&B / A\B / B\A keys and writes them at
-//             tile_ioff[t], a0 - tile_ioff[t], b0 - tile_ioff[t].
-// kMode == 2: writes the tile's A|B keys (merged order, common keys once) to out_i at
-//             a0 + b0 - tile_ioff[t]  (KmerSet::Add, kmer_set.h:164-174).
+// Inclusive prefix sum across the wave's 64 lanes on the DPP cross-lane path (no LDS):
+// four shifts inside each row of 16 lanes, then the last lane of row 0 / 2 is added to the
+// row after it and the last lane of row 1 to rows 2 and 3.
+__device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
+  constexpr int kRowShr1 = 0x111, kRowShr2 = 0x112, kRowShr4 = 0x114, kRowShr8 = 0x118;
+  constexpr int kRowBcast15 = 0x142, kRowBcast31 = 0x143;
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), kRowShr1, 0xf, 0xf, false));
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), kRowShr2, 0xf, 0xf, false));
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), kRowShr4, 0xf, 0xf, false));
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), kRowShr8, 0xf, 0xf, false));
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), kRowBcast15, 0xa, 0xf, false));
+  v += uint32_t(__builtin_amdgcn_update_dpp(0, int(v), kRowBcast31, 0xc, 0xf, false));
+  return v;
+}
+
+// Build with -DKSH_TRACE to record s_memtime at the phases of every tile (debugging aid for
+// the latency breakdown in DESIGN.md; compiled out otherwise).
+#ifdef KSH_TRACE
+__device__ unsigned long long* g_tile_trace = nullptr;
+__device__ int g_tile_stop_after = 0;  // 1: return once the tile's keys are in LDS
+#define KSH_MARK(k, tile)                                                                      \
+  do {                                                                                   \
+    if (g_tile_trace && threadIdx.x == 0)                                                \
+      g_tile_trace[(int64_t(kMode != 0) * max_tiles + (tile)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define KSH_MARK(k, tile) do { } while (0)
+#endif
+
 template <typename KeyT, int kMode>
 __global__ __launch_bounds__(kThreads) void k_tile_merge(
-    const TileDesc* __restrict__ desc, const int64_t* __restrict__ total_tiles,
-    int64_t* __restrict__ tile_m, const int64_t* __restrict__ tile_ioff, KeyT* __restrict__ out_i,
-    KeyT* __restrict__ out_amb, KeyT* __restrict__ out_bma) {
-  __shared__ KeyT lds[kTileCap + 1];  // + 1: a clamped read past an empty B range stays inside
-
-  const int64_t t = blockIdx.x;
+    const TileDesc* __restrict__ desc, const int64_t* __restrict__ total_tiles, int64_t max_tiles,
+    int tiles_per_wave, int64_t* __restrict__ tile_m, const int64_t* __restrict__ tile_ioff,
+    uint16_t* __restrict__ split, KeyT* __restrict__ out_i, KeyT* __restrict__ out_amb,
+    KeyT* __restrict__ out_bma) {
+  using Cfg = TileCfg<KeyT>;
+  using Stage = TileStage<KeyT>;
+  constexpr int kVT = Cfg::kVT;
   constexpr bool kWrite = kMode != 0;
-  if (t >= *total_tiles) {
-    if (!kWrite && threadIdx.x == 0) tile_m[t] = 0;
-    return;
-  }
-  const TileDesc d = desc[t];
-  const int ca = d.ca, cb = d.cb;
-  KeyT* sa = lds;
-  KeyT* sb = lds + ca;
-  stage(static_cast<const KeyT*>(d.pa), ca, sa);
-  stage(static_cast<const KeyT*>(d.pb), cb, sb);
-  __syncthreads();
+  __shared__ __attribute__((aligned(16))) KeyT lds[Cfg::kLds];
 
-  const int n = ca + cb;
-  const int d0 = min(int(threadIdx.x) * kVT, n);
-  const int d1 = min(d0 + kVT, n);
-  // merge-path split of this lane's diagonal (A first on ties)
-  int lo = max(0, d0 - cb), hi = min(d0, ca);
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (sa[mid] <= sb[d0 - 1 - mid]) lo = mid + 1; else hi = mid;
-  }
-  int i = lo, j = d0 - lo;
-
-  // Branch-free merge: both heads are (re)loaded every step with clamped indices and the
-  // lane advances one of them; divergent lanes would otherwise execute both sides of every
-  // branch.  last_a is the A key merged just before (possibly by the previous lane): a B
-  // key equal to it is the second half of a common pair.
-  KeyT vals[kVT];
-  uint32_t cls_bits = 0;  // 2 bits per step: 0 = A&B, 1 = A\B, 2 = B\A, 3 = nothing
-  int n_i = 0, n_a = 0, n_b = 0;
-  bool has_last = i > 0;
-  KeyT last_a = sa[has_last ? i - 1 : 0];
-#pragma unroll
-  for (int step = 0; step < kVT; step++) {
-    const bool active = d0 + step < d1;
-    const bool has_a = i < ca, has_b = j < cb;
-    const KeyT av = sa[has_a ? i : 0];
-    const KeyT bv = sb[has_b ? j : 0];
-    const bool take_a = has_a && (!has_b || av <= bv);
-    const bool eq_ab = has_a && has_b && av == bv;
-    const bool eq_prev = has_last && last_a == bv;
-    uint32_t c = take_a ? (eq_ab ? 0u : 1u) : (eq_prev ? 3u : 2u);
-    c = active ? c : 3u;
-    vals[step] = take_a ? av : bv;
-    cls_bits |= c << (2 * step);
-    n_i += c == 0;
-    n_a += c == 1;
-    n_b += c == 2;
-    const bool adv_a = take_a && active;
-    last_a = adv_a ? av : last_a;
-    has_last = has_last || adv_a;
-    i += adv_a ? 1 : 0;
-    j += (!take_a && active) ? 1 : 0;
-  }
-
-  // wave scan of the three counts, packed into one word
-  const uint64_t packed = uint64_t(n_i) | (uint64_t(n_a) << 20) | (uint64_t(n_b) << 40);
-  uint64_t inc = packed;
+  // This wave owns tiles [t_first, t_end): consecutive tiles, so consecutive memory.  The
+  // keys of tile t + 1 are loaded into registers before tile t is merged: the wave's HBM
+  // latency overlaps its own compute instead of waiting for another wave to cover it.
   const int lane = threadIdx.x;
-#pragma unroll
-  for (int dd = 1; dd < 64; dd <<= 1) {
-    const uint64_t o = __shfl_up(inc, dd, 64);
-    if (lane >= dd) inc += o;
-  }
-  const uint64_t tot = __shfl(inc, 63, 64);
-  const uint64_t excl = inc - packed;
-  const int tot_i = int(tot & 0xFFFFF), tot_a = int((tot >> 20) & 0xFFFFF), tot_b = int(tot >> 40);
-
+  const int64_t t_first = int64_t(blockIdx.x) * tiles_per_wave;
+  const int64_t n_tiles = *total_tiles;
+  const int64_t t_end = min(t_first + tiles_per_wave, n_tiles);
   if (!kWrite) {
-    if (lane == 0) tile_m[t] = tot_i;
-    return;
+    // the prefix scan over tile_m runs to max_tiles: tiles that do not exist count zero
+    const int64_t z = max(t_first, n_tiles) + lane;
+    if (z < min(t_first + tiles_per_wave, max_tiles)) tile_m[z] = 0;
   }
+  if (t_first >= t_end) return;
 
-  __syncthreads();  // every lane is done reading sa / sb: reuse the LDS for compaction
-  const int64_t ioff = tile_ioff[t];
-  if (kMode == 2) {
-    int p_u = int(excl & 0xFFFFF) + int((excl >> 20) & 0xFFFFF) + int(excl >> 40);
+  KSH_MARK(0, t_first);
+  // Everything after a tile's keys are in LDS (and a barrier has passed).
+  auto process = [&](const TileDesc& d, const Stage& st, int64_t t) {
+    KSH_MARK(2, t);
+#ifdef KSH_TRACE
+    if (g_tile_stop_after == 1) {
+      if (!kWrite && lane == 0) tile_m[t] = lds[st.a_lo] == lds[st.b_lo];
+      __syncthreads();
+      return;
+    }
+#endif
+    const int ca = d.ca, cb = d.cb;
+    const int a_lo = st.a_lo, a_hi = st.a_hi, b_lo = st.b_lo, b_hi = st.b_hi;
+
+    const int n = ca + cb;
+    // keys per lane for this tile: enough for n keys, odd (bank spread), at most kVT
+    const int n_steps = min(kVT, ((n + kThreads - 1) / kThreads) | 1);
+    const int d0 = min(lane * n_steps, n);
+    // Merge-path split of this lane's diagonal (A first on ties), in LDS indices: a[m] is
+    // lds[a_lo + m] and b[d0 - 1 - m] is lds[s0 - 1 - (a_lo + m)].  The count pass searches
+    // and, when a write pass follows, leaves every lane's split in `split`; the write pass
+    // reads it back.
+    const int s0 = a_lo + b_lo + d0;  // i + (LDS index of B's head) at step 0
+    int i;                            // LDS index of A's head
+    if constexpr (kWrite) {
+      i = a_lo + int(split[t * kThreads + lane]);
+    } else {
+      // The answer is the number of m in [m_lo, m_hi) with a[m] <= b[d0 - 1 - m] (true for a
+      // prefix).  Bit-by-bit descent with a wave-uniform trip count: `pos` is the last index
+      // known to satisfy it; a candidate beyond the lane's own range fails on the range
+      // test.  Ranges are at most min(ca, cb) long, so a candidate is never more than that
+      // past the range: the A-side read stays below B's end and the B-side read at or above
+      // A's start.
+      const int m_hi = a_lo + min(d0, ca);
+      int pos = a_lo + max(0, d0 - cb) - 1;
+      const int range = min(ca, cb);
+      for (int stride = range > 0 ? (1 << (31 - __builtin_clz(range))) : 0; stride > 0; stride >>= 1) {
+        const int cand = pos + stride;
+        const bool ok = (cand < m_hi) & (lds[cand] <= lds[s0 - 1 - cand]);
+        pos = ok ? cand : pos;
+      }
+      i = pos + 1;
+      if (split) split[t * kThreads + lane] = uint16_t(i - a_lo);
+    }
+    KSH_MARK(3, t);
+    // the key merged just before this lane's first one is a common A key (its B half is ours)
+    const bool straddle = i > a_lo && s0 - i < b_hi && lds[i - 1] == lds[s0 - i];
+    bool prev_common = straddle;
+
+    KeyT vals[kVT];
+    uint32_t m_a = 0, m_x = 0;  // bit (kVT - 1 - step) belongs to `step`
+    int n_i = 0, n_a = 0;
 #pragma unroll
-    for (int step = 0; step < kVT; step++)
-      if (((cls_bits >> (2 * step)) & 3) != 3) lds[p_u++] = vals[step];
+    for (int step = 0; step < kVT; step++) {
+      if (step < n_steps) {  // wave-uniform
+        const int jj = s0 + step - i;
+        const KeyT av = lds[i];
+        const KeyT bv = lds[jj];
+        const bool has_a = i < a_hi, has_b = jj < b_hi;
+        const bool take_a = has_a & (!has_b | (av <= bv));
+        const bool common = take_a & has_b & (av == bv);
+        if constexpr (kWrite) {
+          const bool keep_b = !take_a & has_b & !prev_common;
+          const bool x = (take_a & !common) | (!take_a & !keep_b);
+          vals[step] = take_a ? av : bv;
+          m_a = m_a + m_a + uint32_t(take_a);
+          m_x = m_x + m_x + uint32_t(x);
+          prev_common = common;
+        } else {
+          n_i += int(common);
+        }
+        i += int(take_a);
+      }
+    }
+    if constexpr (kWrite) {
+      m_a <<= kVT - n_steps;  // step's bit is bit (kVT - 1 - step) whatever n_steps is
+      m_x = (m_x << (kVT - n_steps)) | ((1u << (kVT - n_steps)) - 1);  // steps not run: dropped
+      n_i = __popc(m_a & ~m_x);
+      n_a = __popc(m_a & m_x);
+    }
+    KSH_MARK(4, t);
+
+    // Wave scan of the A&B and A\B counts, packed into one word.  The B\A prefix follows
+    // from them: the lanes before this one merged d0 keys, each common pair among those is
+    // one A&B key plus one dropped B key, except that the pair straddling into this lane
+    // has not dropped its B key yet.
+    static_assert(Cfg::kCap < 65536, "packed 16-bit counters");
+    const uint32_t packed = uint32_t(n_i) | (uint32_t(n_a) << 16);
+    const uint32_t inc = wave_inclusive_scan_u32(packed);
+    const uint32_t tot = __builtin_amdgcn_readlane(inc, 63);
+    const uint32_t excl = inc - packed;
+    const uint32_t tot_i = tot & 0xFFFF, tot_a = tot >> 16, tot_b = uint32_t(n) - 2 * tot_i - tot_a;
+
+    if constexpr (!kWrite) {
+      if (lane == 0) tile_m[t] = tot_i;
+      KSH_MARK(5, t);
+      __syncthreads();  // all reads of this tile's keys are done before the next tile lands
+    } else {
+      KSH_MARK(5, t);
+      const uint32_t excl_i = excl & 0xFFFF, excl_a = excl >> 16;
+      const uint32_t excl_b = uint32_t(d0) - 2 * excl_i - excl_a + uint32_t(straddle);
+      __syncthreads();  // every lane is done reading the inputs: reuse the LDS for compaction
+      const int64_t ioff = tile_ioff[t];
+      // A&B keys go to [0, tot_i), A\B keys to [tot_i, tot_i + tot_a), B\A keys after them
+      // (union: every kept key, in merged order).  The three write positions travel in one
+      // register, 10 bits each.
+      static_assert(Cfg::kCap < 1024, "packed 10-bit positions");
+      uint32_t pos3 = kMode == 2 ? excl_i + excl_a + excl_b
+                                 : excl_i + ((tot_i + excl_a) << 10) + ((tot_i + tot_a + excl_b) << 20);
+#pragma unroll
+      for (int step = 0; step < kVT; step++) {
+        if (step < n_steps) {
+          const uint32_t bit = 1u << (kVT - 1 - step);
+          const bool from_a = (m_a & bit) != 0, x = (m_x & bit) != 0;
+          const bool keep = from_a | !x;
+          if (kMode == 2) {
+            if (keep) lds[pos3] = vals[step];
+            pos3 += uint32_t(keep);
+          } else {
+            const uint32_t sh = from_a ? (x ? 10u : 0u) : 20u;
+            if (keep) lds[(pos3 >> sh) & 1023] = vals[step];
+            pos3 += keep ? (1u << sh) : 0u;
+          }
+        }
+      }
+      __syncthreads();
+      KSH_MARK(6, t);
+      if (kMode == 2) {
+        copy_out(lds, 0, tot_i + tot_a + tot_b, out_i + (d.a0 + d.b0 - ioff));
+      } else {
+        if (out_i) copy_out(lds, 0, tot_i, out_i + ioff);
+        if (out_amb) copy_out(lds, tot_i, tot_a, out_amb + (d.a0 - ioff));
+        if (out_bma) copy_out(lds, tot_i + tot_a, tot_b, out_bma + (d.b0 - ioff));
+      }
+      KSH_MARK(7, t);
+      __syncthreads();  // the compacted keys are read out before the next tile lands
+    }
+  };
+
+  // One tile after the other; the next tile's descriptor is fetched while this one is merged.
+  TileDesc d_next = desc[t_first];
+  for (int64_t t = t_first; t < t_end; t++) {
+    const TileDesc d = d_next;
+    if (t + 1 < t_end) d_next = desc[t + 1];
+    Stage st;
+    st.init(d);
+    KSH_MARK(1, t);
+    st.copy(lds);
     __syncthreads();
-    const int tot_u = tot_i + tot_a + tot_b;
-    KeyT* o = out_i + (d.a0 + d.b0 - ioff);
-    for (int x = lane; x < tot_u; x += kThreads) o[x] = lds[x];
-    return;
-  }
-  int p_i = int(excl & 0xFFFFF);
-  int p_a = tot_i + int((excl >> 20) & 0xFFFFF);
-  int p_b = tot_i + tot_a + int(excl >> 40);
-#pragma unroll
-  for (int step = 0; step < kVT; step++) {
-    const uint32_t c = (cls_bits >> (2 * step)) & 3;
-    const int pos = c == 0 ? p_i : (c == 1 ? p_a : p_b);
-    if (c != 3) lds[pos] = vals[step];
-    p_i += c == 0;
-    p_a += c == 1;
-    p_b += c == 2;
-  }
-  __syncthreads();
-  if (out_i) {
-    KeyT* o = out_i + ioff;
-    for (int x = lane; x < tot_i; x += kThreads) o[x] = lds[x];
-  }
-  if (out_amb) {
-    KeyT* o = out_amb + (d.a0 - ioff);
-    for (int x = lane; x < tot_a; x += kThreads) o[x] = lds[tot_i + x];
-  }
-  if (out_bma) {
-    KeyT* o = out_bma + (d.b0 - ioff);
-    for (int x = lane; x < tot_b; x += kThreads) o[x] = lds[tot_i + tot_a + x];
+    process(d, st, t);
   }
 }
 
@@ -345,6 +488,8 @@ __global__ __launch_bounds__(256) void k_pair_weight_gather(
 }
 
 // ---- host-side plan ------------------------------------------------------------------------------
+constexpr int kSplitPerTile = kThreads;
+
 struct Plan {
   int64_t n_segs = 0;
   int64_t max_tiles = 0;
@@ -352,13 +497,14 @@ struct Plan {
   TileDesc* desc = nullptr;      // max_tiles
   int64_t* tile_ioff = nullptr;  // max_tiles (count, then exclusive prefix in place)
   int64_t* total_m = nullptr;    // 1
+  uint16_t* split = nullptr;     // max_tiles * kSplitPerTile: every chain's merge-path split (count pass -> write pass)
 };
 
 inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
 inline size_t plan_bytes(int64_t n_segs, int64_t max_tiles) {
   return align256(size_t(n_segs + 1) * 8) + align256(size_t(max_tiles) * sizeof(TileDesc)) +
-         align256(size_t(max_tiles) * 8) + 256;
+         align256(size_t(max_tiles) * 8) + 256 + align256(size_t(max_tiles) * kSplitPerTile * 2);
 }
 
 inline void plan_carve(char* base, int64_t n_segs, int64_t max_tiles, Plan* p) {
@@ -372,6 +518,30 @@ inline void plan_carve(char* base, int64_t n_segs, int64_t max_tiles, Plan* p) {
   p->tile_ioff = reinterpret_cast<int64_t*>(at);
   at += align256(size_t(max_tiles) * 8);
   p->total_m = reinterpret_cast<int64_t*>(at);
+  at += 256;
+  p->split = reinterpret_cast<uint16_t*>(at);
+}
+
+// Consecutive tiles handled by one wave of k_tile_merge: as many as still leave every wave
+// slot of the chip (256 CUs x 32) about two waves, at most 4.  The tile count is only known
+// on the device; the host bound max_tiles is close to it when buckets are evenly filled.
+inline int tiles_per_wave(int64_t max_tiles) {
+  static const int forced = [] {
+    const char* e = std::getenv("KSH_TILES_PER_WAVE");
+    return e ? std::atoi(e) : 0;
+  }();
+  if (forced > 0) return forced;
+  return int(std::min<int64_t>(4, std::max<int64_t>(1, max_tiles / (2 * 256 * 32))));
+}
+
+template <typename KeyT, int kMode>
+void launch_tile_merge(ksh_ctx* ctx, const Plan& p, int64_t* tile_m, const int64_t* tile_ioff,
+                       uint16_t* split, KeyT* out_i, KeyT* out_amb, KeyT* out_bma) {
+  const int tpw = tiles_per_wave(p.max_tiles);
+  const int64_t waves = (p.max_tiles + tpw - 1) / tpw;
+  hipLaunchKernelGGL((k_tile_merge<KeyT, kMode>), dim3(unsigned(waves)), dim3(kThreads), 0, ctx->stream,
+                     p.desc, p.tile_base + p.n_segs, p.max_tiles, tpw, tile_m, tile_ioff, split, out_i,
+                     out_amb, out_bma);
 }
 
 inline unsigned blocks_for(int64_t n, int per) { return unsigned(std::max<int64_t>(1, (n + per - 1) / per)); }
@@ -387,15 +557,14 @@ int plan_tile_base(ksh_ctx* ctx, const Segs& segs, int64_t n_segs, int64_t* tile
 
 // Splits + count pass + prefix of the per-tile counts.
 template <typename KeyT, typename Segs>
-int plan_count(ksh_ctx* ctx, const Segs& segs, const Plan& p, int timer_kind) {
+int plan_count(ksh_ctx* ctx, const Segs& segs, const Plan& p, int timer_kind, bool save_split) {
   hipLaunchKernelGGL((k_tile_split<KeyT, Segs>), dim3(blocks_for(p.max_tiles, 256)), dim3(256), 0,
                      ctx->stream, segs, p.n_segs, p.tile_base, p.desc);
   {
     Timer timer(ctx, timer_kind);
-    hipLaunchKernelGGL((k_tile_merge<KeyT, 0>), dim3(unsigned(p.max_tiles)), dim3(kThreads), 0,
-                       ctx->stream, p.desc, p.tile_base + p.n_segs, p.tile_ioff, nullptr,
-                       static_cast<KeyT*>(nullptr), static_cast<KeyT*>(nullptr),
-                       static_cast<KeyT*>(nullptr));
+    launch_tile_merge<KeyT, 0>(ctx, p, p.tile_ioff, nullptr, save_split ? p.split : nullptr,
+                               static_cast<KeyT*>(nullptr), static_cast<KeyT*>(nullptr),
+                               static_cast<KeyT*>(nullptr));
   }
   KSH_TRY(scan_exclusive_i64(ctx, p.tile_ioff, p.tile_ioff, p.max_tiles, p.total_m));
   KSH_HIP(hipGetLastError());
@@ -416,7 +585,7 @@ template <typename KeyT>
 int pair_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
                 int64_t* d_off_i, int64_t* d_off_amb, int64_t* d_off_bma, int64_t totals[3]) {
   const int64_t nb = n_buckets(g);
-  const int64_t max_tiles = nb + (a->n_keys + b->n_keys) / kTile + 1;
+  const int64_t max_tiles = nb + (a->n_keys + b->n_keys) / TileCfg<KeyT>::kTile + 1;
   if (max_tiles > int64_t(0x7FFFFFF0)) return fail(KSH_INVALID_ARGUMENT, "pair too large for one launch");
   KSH_TRY(plan_reserve(ctx, plan_bytes(nb, max_tiles)));
   KSH_TRY(arena_reserve(ctx, size_t(max_tiles / 256 + 4096) * 8 + (1u << 16)));
@@ -426,7 +595,7 @@ int pair_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ks
   BucketSegs<KeyT> segs{static_cast<const KeyT*>(a->d_keys), a->d_offsets,
                         static_cast<const KeyT*>(b->d_keys), b->d_offsets};
   KSH_TRY((plan_tile_base<KeyT>(ctx, segs, nb, p.tile_base)));
-  KSH_TRY((plan_count<KeyT>(ctx, segs, p, 1)));
+  KSH_TRY((plan_count<KeyT>(ctx, segs, p, 1, true)));
   int64_t* d_totals = static_cast<int64_t*>(arena_alloc(ctx, 3 * sizeof(int64_t)));
   if (!d_totals) return fail(KSH_INTERNAL, "scratch arena too small");
   hipLaunchKernelGGL(k_result_offsets, dim3(blocks_for(nb + 1, 256)), dim3(256), 0, ctx->stream,
@@ -457,10 +626,8 @@ int pair_write_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const k
   plan_carve(ctx->plan, nb, ctx->plan_tiles, &p);
   {
     Timer timer(ctx, 0);
-    hipLaunchKernelGGL((k_tile_merge<KeyT, 1>), dim3(unsigned(p.max_tiles)), dim3(kThreads), 0,
-                       ctx->stream, p.desc, p.tile_base + p.n_segs, nullptr, p.tile_ioff,
-                       static_cast<KeyT*>(d_keys_i), static_cast<KeyT*>(d_keys_amb),
-                       static_cast<KeyT*>(d_keys_bma));
+    launch_tile_merge<KeyT, 1>(ctx, p, nullptr, p.tile_ioff, p.split, static_cast<KeyT*>(d_keys_i),
+                               static_cast<KeyT*>(d_keys_amb), static_cast<KeyT*>(d_keys_bma));
   }
   KSH_HIP(hipGetLastError());
   return KSH_OK;
@@ -479,7 +646,7 @@ int pair_algebra_enqueue(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a,
                          int64_t* d_off_i, int64_t* d_off_amb, int64_t* d_off_bma, void* d_keys_i,
                          void* d_keys_amb, void* d_keys_bma, int64_t* d_totals) {
   const int64_t nb = n_buckets(g);
-  const int64_t max_tiles = nb + (a->n_keys + b->n_keys) / kTile + 1;
+  const int64_t max_tiles = nb + (a->n_keys + b->n_keys) / TileCfg<KeyT>::kTile + 1;
   arena_reset(ctx);
   char* base = static_cast<char*>(arena_alloc(ctx, plan_bytes(nb, max_tiles)));
   Plan p;
@@ -487,16 +654,14 @@ int pair_algebra_enqueue(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a,
   BucketSegs<KeyT> segs{static_cast<const KeyT*>(a->d_keys), a->d_offsets,
                         static_cast<const KeyT*>(b->d_keys), b->d_offsets};
   KSH_TRY((plan_tile_base<KeyT>(ctx, segs, nb, p.tile_base)));
-  KSH_TRY((plan_count<KeyT>(ctx, segs, p, 1)));
+  KSH_TRY((plan_count<KeyT>(ctx, segs, p, 1, true)));
   hipLaunchKernelGGL(k_result_offsets, dim3(blocks_for(nb + 1, 256)), dim3(256), 0, ctx->stream,
                      a->d_offsets, b->d_offsets, p.tile_base, p.tile_ioff, p.total_m, nb, d_off_i,
                      d_off_amb, d_off_bma, d_totals);
   {
     Timer timer(ctx, 0);
-    hipLaunchKernelGGL((k_tile_merge<KeyT, 1>), dim3(unsigned(p.max_tiles)), dim3(kThreads), 0,
-                       ctx->stream, p.desc, p.tile_base + p.n_segs, nullptr, p.tile_ioff,
-                       static_cast<KeyT*>(d_keys_i), static_cast<KeyT*>(d_keys_amb),
-                       static_cast<KeyT*>(d_keys_bma));
+    launch_tile_merge<KeyT, 1>(ctx, p, nullptr, p.tile_ioff, p.split, static_cast<KeyT*>(d_keys_i),
+                               static_cast<KeyT*>(d_keys_amb), static_cast<KeyT*>(d_keys_bma));
   }
   KSH_HIP(hipGetLastError());
   return KSH_OK;
@@ -510,7 +675,7 @@ int pair_algebra_batch_t(ksh_ctx* ctx, const ksh_geom* g, ksh_pair_job* jobs, in
   const int64_t nb = n_buckets(g);
   size_t need = 0;
   for (int32_t i = 0; i < n_jobs; i++) {
-    const int64_t max_tiles = nb + (jobs[i].a.n_keys + jobs[i].b.n_keys) / kTile + 1;
+    const int64_t max_tiles = nb + (jobs[i].a.n_keys + jobs[i].b.n_keys) / TileCfg<KeyT>::kTile + 1;
     if (max_tiles > int64_t(0x7FFFFFF0)) return fail(KSH_INVALID_ARGUMENT, "pair too large for one launch");
     need = std::max(need, pair_scratch_bytes(nb, max_tiles));
   }
@@ -571,7 +736,7 @@ template <typename KeyT>
 int union_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
                  int64_t* d_off_u, int64_t* total) {
   const int64_t nb = n_buckets(g);
-  const int64_t max_tiles = nb + (a->n_keys + b->n_keys) / kTile + 1;
+  const int64_t max_tiles = nb + (a->n_keys + b->n_keys) / TileCfg<KeyT>::kTile + 1;
   if (max_tiles > int64_t(0x7FFFFFF0)) return fail(KSH_INVALID_ARGUMENT, "pair too large for one launch");
   KSH_TRY(plan_reserve(ctx, plan_bytes(nb, max_tiles)));
   KSH_TRY(arena_reserve(ctx, size_t(max_tiles / 256 + 4096) * 8 + (1u << 16)));
@@ -581,7 +746,7 @@ int union_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const k
   BucketSegs<KeyT> segs{static_cast<const KeyT*>(a->d_keys), a->d_offsets,
                         static_cast<const KeyT*>(b->d_keys), b->d_offsets};
   KSH_TRY((plan_tile_base<KeyT>(ctx, segs, nb, p.tile_base)));
-  KSH_TRY((plan_count<KeyT>(ctx, segs, p, 1)));
+  KSH_TRY((plan_count<KeyT>(ctx, segs, p, 1, true)));
   int64_t* d_total = static_cast<int64_t*>(arena_alloc(ctx, sizeof(int64_t)));
   if (!d_total) return fail(KSH_INTERNAL, "scratch arena too small");
   hipLaunchKernelGGL(k_union_offsets, dim3(blocks_for(nb + 1, 256)), dim3(256), 0, ctx->stream,
@@ -607,10 +772,8 @@ int union_write_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const 
     return fail(KSH_FAILED_PRECONDITION, "ksh_set_union_write without a matching ksh_set_union_plan");
   Plan p;
   plan_carve(ctx->plan, nb, ctx->plan_tiles, &p);
-  hipLaunchKernelGGL((k_tile_merge<KeyT, 2>), dim3(unsigned(p.max_tiles)), dim3(kThreads), 0,
-                     ctx->stream, p.desc, p.tile_base + p.n_segs, nullptr, p.tile_ioff,
-                     static_cast<KeyT*>(d_keys_u), static_cast<KeyT*>(nullptr),
-                     static_cast<KeyT*>(nullptr));
+  launch_tile_merge<KeyT, 2>(ctx, p, nullptr, p.tile_ioff, p.split, static_cast<KeyT*>(d_keys_u),
+                             static_cast<KeyT*>(nullptr), static_cast<KeyT*>(nullptr));
   KSH_HIP(hipGetLastError());
   return KSH_OK;
 }
@@ -619,7 +782,7 @@ template <typename KeyT>
 int set_diff_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
                int64_t* diff) {
   const int64_t nb = n_buckets(g);
-  const int64_t max_tiles = nb + (a->n_keys + b->n_keys) / kTile + 1;
+  const int64_t max_tiles = nb + (a->n_keys + b->n_keys) / TileCfg<KeyT>::kTile + 1;
   if (max_tiles > int64_t(0x7FFFFFF0)) return fail(KSH_INVALID_ARGUMENT, "pair too large for one launch");
   KSH_TRY(arena_reserve(ctx, plan_bytes(nb, max_tiles) + size_t(max_tiles / 256 + 4096) * 8 + (1u << 16)));
   arena_reset(ctx);
@@ -629,7 +792,7 @@ int set_diff_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh
   BucketSegs<KeyT> segs{static_cast<const KeyT*>(a->d_keys), a->d_offsets,
                         static_cast<const KeyT*>(b->d_keys), b->d_offsets};
   KSH_TRY((plan_tile_base<KeyT>(ctx, segs, nb, p.tile_base)));
-  KSH_TRY((plan_count<KeyT>(ctx, segs, p, 1)));
+  KSH_TRY((plan_count<KeyT>(ctx, segs, p, 1, false)));
   KSH_HIP(hipMemcpyAsync(ctx->h_pinned, p.total_m, sizeof(int64_t), hipMemcpyDeviceToHost,
                          ctx->stream));
   KSH_HIP(hipStreamSynchronize(ctx->stream));
@@ -684,7 +847,7 @@ int pair_weights_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sets, in
   plan_carve(base, 0, n_tiles, &p);
   p.n_segs = n_segs;
   p.tile_base = tile_base;
-  KSH_TRY((plan_count<KeyT>(ctx, segs, p, 2)));
+  KSH_TRY((plan_count<KeyT>(ctx, segs, p, 2, false)));
   hipLaunchKernelGGL(k_pair_weight_gather, dim3(blocks_for(n_pairs, 256)), dim3(256), 0,
                      ctx->stream, p.tile_base, p.tile_ioff, p.total_m, n_segs, n_ids, n_pairs,
                      d_weights);
@@ -698,6 +861,16 @@ int pair_weights_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sets, in
 }  // namespace ksh
 
 using namespace ksh;
+
+#ifdef KSH_TRACE
+extern "C" int ksh_debug_set_tile_trace(void* d_buf) {
+  unsigned long long* p = static_cast<unsigned long long*>(d_buf);
+  return hipMemcpyToSymbol(HIP_SYMBOL(ksh::g_tile_trace), &p, sizeof(p)) == hipSuccess ? 0 : 13;
+}
+extern "C" int ksh_debug_set_tile_stop(int stop_after) {
+  return hipMemcpyToSymbol(HIP_SYMBOL(ksh::g_tile_stop_after), &stop_after, sizeof(int)) == hipSuccess ? 0 : 13;
+}
+#endif
 
 extern "C" {
 

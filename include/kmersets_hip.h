@@ -80,10 +80,12 @@ int ksh_ctx_destroy(ksh_ctx* ctx);
 int ksh_ctx_sync(ksh_ctx* ctx);
 /* Pre-sizes the scratch arena (otherwise it grows on demand). */
 int ksh_ctx_reserve(ksh_ctx* ctx, size_t bytes);
-/* Kernel timing for bench.py's roofline leg.  While enabled, every launch of a
- * timed kernel kind is bracketed by its own pair of HIP events on the context's
- * stream; ksh_ctx_timing_read synchronises the stream and returns the summed
- * duration and the number of launches since the last reset.
+/* Kernel timing for bench.py's roofline leg.  enable = n > 0: every n-th launch of a
+ * timed kernel kind (the 1st, the (n+1)-th, ...) is bracketed by its own pair of HIP
+ * events on the context's stream; an event pair costs the stream about 10 us of idle time,
+ * so a caller that also measures throughput samples (n > 1) rather than timing every
+ * launch.  ksh_ctx_timing_read synchronises the stream and returns the summed duration and
+ * the number of timed launches since the last reset.
  * kinds: 0 = pair merge, write pass   1 = pair merge, count pass
  *        2 = sampled-bucket weight count pass */
 int ksh_ctx_enable_timing(ksh_ctx* ctx, int enable);

@@ -1,6 +1,7 @@
 // Context, errors, device plumbing, prefix sum and the XOR-hash reduction.
 // gfx950 only; wavefront = 64.
 #include "ksh_internal.h"
+#include "ksh_scan.h"
 
 #include <algorithm>
 #include <cstring>
@@ -293,6 +294,10 @@ int scan_exclusive_i64(ksh_ctx* ctx, const int64_t* d_in, int64_t* d_out, int64_
     KSH_HIP(hipGetLastError());
     return KSH_OK;
   }
+  if (scan_exclusive_chained(ctx, LoadArray{d_in}, d_out, n, d_total)) {
+    KSH_HIP(hipGetLastError());
+    return KSH_OK;
+  }
   const int64_t blocks = (n + kScanTile - 1) / kScanTile;
   if (blocks <= kScanFixMaxBlocks) {
     int64_t* bsums = static_cast<int64_t*>(arena_alloc(ctx, size_t(blocks) * sizeof(int64_t)));
@@ -453,6 +458,12 @@ int ksh_ctx_create(int device, void* stream, ksh_ctx** out) {
     delete ctx;
     return rc;
   }
+  const size_t state_bytes = size_t(kChainMaxBlocks) * sizeof(unsigned long long);
+  if (hipMalloc(reinterpret_cast<void**>(&ctx->scan_state), state_bytes) != hipSuccess ||
+      hipMemset(ctx->scan_state, 0, state_bytes) != hipSuccess) {
+    ksh_ctx_destroy(ctx);
+    return fail(KSH_INTERNAL, "hipMalloc of the scan state failed");
+  }
   *out = ctx;
   return KSH_OK;
 }
@@ -464,6 +475,7 @@ int ksh_ctx_destroy(ksh_ctx* ctx) {
   free_plan(ctx);
   pool_trim(ctx);
   if (ctx->arena) (void)hipFree(ctx->arena);
+  if (ctx->scan_state) (void)hipFree(ctx->scan_state);
   if (ctx->plan) (void)hipFree(ctx->plan);
   for (int i = 0; i < 2; i++)
     if (ctx->slot[i]) (void)hipFree(ctx->slot[i]);
@@ -490,7 +502,8 @@ int ksh_ctx_reserve(ksh_ctx* ctx, size_t bytes) {
 
 int ksh_ctx_enable_timing(ksh_ctx* ctx, int enable) {
   if (!ctx) return fail(KSH_INVALID_ARGUMENT, "ctx is NULL");
-  ctx->timing = enable != 0;
+  ctx->timing = enable > 0;
+  ctx->timing_stride = enable > 0 ? enable : 1;
   return KSH_OK;
 }
 
@@ -498,7 +511,10 @@ int ksh_ctx_timing_reset(ksh_ctx* ctx) {
   if (!ctx) return fail(KSH_INVALID_ARGUMENT, "ctx is NULL");
   KSH_HIP(hipStreamSynchronize(ctx->stream));
   ctx->ev_next = 0;
-  for (int i = 0; i < kNumTimers; i++) ctx->ev_spans[i].clear();
+  for (int i = 0; i < kNumTimers; i++) {
+    ctx->ev_spans[i].clear();
+    ctx->timing_seen[i] = 0;
+  }
   return KSH_OK;
 }
 

@@ -75,6 +75,11 @@ struct ksh_ctx {
   const void* plan_b_keys = nullptr;
   int64_t plan_buckets = 0;
 
+  // chained scan (ksh_scan.h): the sums published by the workgroups of the running launch,
+  // tagged with the launch's epoch
+  unsigned long long* scan_state = nullptr;
+  uint32_t scan_epoch = 0;
+
   // caching allocator for the loop's per-iteration buffers (ksh::pool_alloc / pool_free):
   // freed blocks are kept and reused, because hipMalloc / hipFree of 100 MB-scale blocks
   // cost milliseconds and hipFree synchronises the device.  Single stream, so reuse after
@@ -86,6 +91,8 @@ struct ksh_ctx {
   // kernel timers: when enabled, every launch of a timed kind gets its own event
   // pair from a pool; ksh_ctx_timing_read sums them after a stream sync.
   bool timing = false;
+  int timing_stride = 1;                                 // every n-th launch of a kind is timed
+  int64_t timing_seen[ksh::kNumTimers] = {0, 0, 0, 0};   // launches of each kind since the reset
   std::vector<hipEvent_t> ev_pool;                       // all events ever created
   size_t ev_next = 0;                                    // next unused event in ev_pool
   std::vector<std::pair<size_t, size_t>> ev_spans[ksh::kNumTimers];  // (start, stop) indices
@@ -115,11 +122,13 @@ struct Timer {
   ksh_ctx* ctx;
   int kind;
   size_t i0 = 0;
+  bool on = false;
   Timer(ksh_ctx* c, int k) : ctx(c), kind(k) {
-    if (ctx->timing) (void)hipEventRecord(timer_event(ctx, &i0), ctx->stream);
+    on = ctx->timing && (ctx->timing_seen[kind]++ % ctx->timing_stride) == 0;
+    if (on) (void)hipEventRecord(timer_event(ctx, &i0), ctx->stream);
   }
   ~Timer() {
-    if (ctx->timing) {
+    if (on) {
       size_t i1;
       (void)hipEventRecord(timer_event(ctx, &i1), ctx->stream);
       ctx->ev_spans[kind].emplace_back(i0, i1);

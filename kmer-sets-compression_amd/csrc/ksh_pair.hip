@@ -16,6 +16,7 @@
 // pair (the split kernel moves the B boundary by one when it would), which makes
 // every tile self-contained: matches are decided from LDS only.
 #include "ksh_internal.h"
+#include "ksh_scan.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -94,26 +95,54 @@ struct PairSegs {
   }
 };
 
-// Everything a tile needs, in one 40-byte record (one dependent load in the merge kernel).
+// Everything a tile needs, in one 48-byte record (one dependent load in the merge kernel):
+// the two key arrays and the tile's index ranges [a0, a1) and [b0, b1) in them.
 struct TileDesc {
-  const void* pa;  // first A key of the tile
-  const void* pb;  // first B key of the tile
-  int64_t a0;      // its index in A's key array
-  int64_t b0;
-  int32_t ca, cb;  // keys of A / B in the tile
+  const void* a_keys;
+  const void* b_keys;
+  int64_t a0, b0;
+  int64_t a1, b1;
 };
 
 // ---- tile plan --------------------------------------------------------------------------
+template <typename KeyT, typename Segs>
+struct LoadSegTiles {
+  Segs segs;
+  __device__ __forceinline__ int64_t operator()(int64_t s) const {
+    const KeyT *a, *b;
+    int64_t a_lo, a_hi, b_lo, b_hi;
+    segs.get(s, a, a_lo, a_hi, b, b_lo, b_hi);
+    const int64_t len = (a_hi - a_lo) + (b_hi - b_lo);
+    return (len + TileCfg<KeyT>::kTile - 1) / TileCfg<KeyT>::kTile;
+  }
+};
+
+// Which segment a tile belongs to, which of the segment's tiles it is and how many there are.
+struct TileOwner {
+  int32_t seg, q, n_tiles, pad;
+};
+
+// Scan epilogue: segment s with n_tiles tiles starting at tile `first` labels them.
+struct EmitTileOwners {
+  TileOwner* owner;
+  __device__ __forceinline__ void operator()(int64_t s, int64_t first, int64_t n_tiles) const {
+    for (int64_t q = 0; q < n_tiles; q++) owner[first + q] = TileOwner{int32_t(s), int32_t(q), int32_t(n_tiles), 0};
+  }
+};
+
+__global__ __launch_bounds__(256) void k_tile_owners(const int64_t* __restrict__ tile_base, int64_t n_segs,
+                                                      TileOwner* __restrict__ owner) {
+  const int64_t s = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (s >= n_segs) return;
+  EmitTileOwners{owner}(s, tile_base[s], tile_base[s + 1] - tile_base[s]);
+}
+
 template <typename KeyT, typename Segs>
 __global__ __launch_bounds__(256) void k_seg_tiles(Segs segs, int64_t n_segs,
                                                     int64_t* __restrict__ tiles_per_seg) {
   const int64_t s = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (s >= n_segs) return;
-  const KeyT *a, *b;
-  int64_t a_lo, a_hi, b_lo, b_hi;
-  segs.get(s, a, a_lo, a_hi, b, b_lo, b_hi);
-  const int64_t len = (a_hi - a_lo) + (b_hi - b_lo);
-  tiles_per_seg[s] = (len + TileCfg<KeyT>::kTile - 1) / TileCfg<KeyT>::kTile;
+  tiles_per_seg[s] = LoadSegTiles<KeyT, Segs>{segs}(s);
 }
 
 // Merge-path split of (a[0, na), b[0, nb)) at `diag` (A first on ties); a common key's
@@ -134,41 +163,39 @@ __device__ __forceinline__ void merge_path_split(const KeyT* __restrict__ a, int
   *j_out = j;
 }
 
-// One thread per tile: which segment, where the tile starts and ends in A and in B.
+// One thread per tile: which segment it belongs to and where it starts in A and in B.  The
+// segment's tiles share its keys evenly (each at most TileCfg::kTile): the merge kernel's
+// cost follows the keys in a tile, not the tile count.  A tile ends where the next tile of
+// its segment starts, so every boundary inside a segment is searched once, by the thread of
+// the tile that starts there, which also closes the tile before it; a segment's first tile
+// starts at the segment's start and its last tile ends at the segment's end without a search.
 template <typename KeyT, typename Segs>
 __global__ __launch_bounds__(256) void k_tile_split(Segs segs, int64_t n_segs,
                                                      const int64_t* __restrict__ tile_base,
+                                                     const TileOwner* __restrict__ owner,
                                                      TileDesc* __restrict__ desc) {
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const int64_t total = tile_base[n_segs];
   if (t >= total) return;
-  // last s with tile_base[s] <= t
-  int64_t lo = 0, hi = n_segs;
-  while (lo < hi) {
-    const int64_t mid = (lo + hi) >> 1;
-    if (tile_base[mid] <= t) lo = mid + 1; else hi = mid;
-  }
-  const int64_t s = lo - 1;
+  const TileOwner o = owner[t];
   const KeyT *a, *b;
   int64_t a_lo, a_hi, b_lo, b_hi;
-  segs.get(s, a, a_lo, a_hi, b, b_lo, b_hi);
+  segs.get(o.seg, a, a_lo, a_hi, b, b_lo, b_hi);
   const int64_t na = a_hi - a_lo, nb = b_hi - b_lo;
-  // the segment's tiles share its keys evenly (each at most TileCfg::kTile): the merge kernel's cost
-  // follows the keys in a tile, not the tile count
-  const int64_t q = t - tile_base[s], n_tiles = tile_base[s + 1] - tile_base[s];
-  const int64_t diag = q * (na + nb) / n_tiles;
-  const int64_t diag_end = (q + 1) * (na + nb) / n_tiles;
-  int64_t i0, j0, i1 = na, j1 = nb;
-  merge_path_split(a + a_lo, na, b + b_lo, nb, diag, &i0, &j0);
-  if (q + 1 < n_tiles) merge_path_split(a + a_lo, na, b + b_lo, nb, diag_end, &i1, &j1);
-  TileDesc d;
-  d.pa = a + a_lo + i0;
-  d.pb = b + b_lo + j0;
-  d.a0 = a_lo + i0;
-  d.b0 = b_lo + j0;
-  d.ca = int32_t(i1 - i0);
-  d.cb = int32_t(j1 - j0);
-  desc[t] = d;
+  int64_t i0 = 0, j0 = 0;
+  if (o.q > 0) {
+    merge_path_split(a + a_lo, na, b + b_lo, nb, int64_t(o.q) * (na + nb) / o.n_tiles, &i0, &j0);
+    desc[t - 1].a1 = a_lo + i0;
+    desc[t - 1].b1 = b_lo + j0;
+  }
+  desc[t].a_keys = a;
+  desc[t].b_keys = b;
+  desc[t].a0 = a_lo + i0;
+  desc[t].b0 = b_lo + j0;
+  if (o.q + 1 == o.n_tiles) {
+    desc[t].a1 = a_hi;
+    desc[t].b1 = b_hi;
+  }
 }
 
 // A tile's keys travel global -> registers -> LDS as whole 16-byte vectors, A's vectors
@@ -191,18 +218,23 @@ struct TileStage {
   uint32_t va, vb, b_vec0;     // vectors of A, of B; LDS vector index of B's first vector
   GlobalVecs ga, gb;
 
+  int ca, cb;                  // keys of A / B in the tile
+
   __device__ __forceinline__ void init(const TileDesc& d) {
-    const uintptr_t pa = reinterpret_cast<uintptr_t>(d.pa), pb = reinterpret_cast<uintptr_t>(d.pb);
+    ca = int(d.a1 - d.a0);
+    cb = int(d.b1 - d.b0);
+    const uintptr_t pa = reinterpret_cast<uintptr_t>(d.a_keys) + uintptr_t(d.a0) * sizeof(KeyT);
+    const uintptr_t pb = reinterpret_cast<uintptr_t>(d.b_keys) + uintptr_t(d.b0) * sizeof(KeyT);
     const int mis_a = int((pa / sizeof(KeyT)) & (kPer - 1)), mis_b = int((pb / sizeof(KeyT)) & (kPer - 1));
     ga = (GlobalVecs)(pa & ~uintptr_t(15));
     gb = (GlobalVecs)(pb & ~uintptr_t(15));
-    va = d.ca > 0 ? uint32_t(mis_a + d.ca + kPer - 1) / kPer : 0u;
-    vb = d.cb > 0 ? uint32_t(mis_b + d.cb + kPer - 1) / kPer : 0u;
+    va = ca > 0 ? uint32_t(mis_a + ca + kPer - 1) / kPer : 0u;
+    vb = cb > 0 ? uint32_t(mis_b + cb + kPer - 1) / kPer : 0u;
     a_lo = mis_a;
-    a_hi = a_lo + d.ca;
+    a_hi = a_lo + ca;
     b_vec0 = uint32_t(a_hi + kPer - 1) / kPer;
     b_lo = int(b_vec0) * kPer + mis_b;
-    b_hi = b_lo + d.cb;
+    b_hi = b_lo + cb;
   }
   // global -> LDS, one range after the other
   __device__ __forceinline__ void copy(KeyT* lds) const {
@@ -309,7 +341,7 @@ __global__ __launch_bounds__(kThreads) void k_tile_merge(
       return;
     }
 #endif
-    const int ca = d.ca, cb = d.cb;
+    const int ca = st.ca, cb = st.cb;
     const int a_lo = st.a_lo, a_hi = st.a_hi, b_lo = st.b_lo, b_hi = st.b_hi;
 
     const int n = ca + cb;
@@ -497,6 +529,7 @@ struct Plan {
   TileDesc* desc = nullptr;      // max_tiles
   int64_t* tile_ioff = nullptr;  // max_tiles (count, then exclusive prefix in place)
   int64_t* total_m = nullptr;    // 1
+  TileOwner* owner = nullptr;    // max_tiles
   uint16_t* split = nullptr;     // max_tiles * kSplitPerTile: every chain's merge-path split (count pass -> write pass)
 };
 
@@ -504,7 +537,8 @@ inline size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
 
 inline size_t plan_bytes(int64_t n_segs, int64_t max_tiles) {
   return align256(size_t(n_segs + 1) * 8) + align256(size_t(max_tiles) * sizeof(TileDesc)) +
-         align256(size_t(max_tiles) * 8) + 256 + align256(size_t(max_tiles) * kSplitPerTile * 2);
+         align256(size_t(max_tiles) * 8) + 256 + align256(size_t(max_tiles) * kSplitPerTile * 2) +
+         align256(size_t(max_tiles) * sizeof(TileOwner));
 }
 
 inline void plan_carve(char* base, int64_t n_segs, int64_t max_tiles, Plan* p) {
@@ -520,6 +554,8 @@ inline void plan_carve(char* base, int64_t n_segs, int64_t max_tiles, Plan* p) {
   p->total_m = reinterpret_cast<int64_t*>(at);
   at += 256;
   p->split = reinterpret_cast<uint16_t*>(at);
+  at += align256(size_t(max_tiles) * kSplitPerTile * 2);
+  p->owner = reinterpret_cast<TileOwner*>(at);
 }
 
 // Consecutive tiles handled by one wave of k_tile_merge: as many as still leave every wave
@@ -547,11 +583,32 @@ void launch_tile_merge(ksh_ctx* ctx, const Plan& p, int64_t* tile_m, const int64
 inline unsigned blocks_for(int64_t n, int per) { return unsigned(std::max<int64_t>(1, (n + per - 1) / per)); }
 
 // Tiles per segment -> tile_base (exclusive prefix, total at [n_segs]).
+// owner == nullptr: the caller does not know the tile count yet and labels the tiles later
+// (label_tiles).
 template <typename KeyT, typename Segs>
-int plan_tile_base(ksh_ctx* ctx, const Segs& segs, int64_t n_segs, int64_t* tile_base) {
-  hipLaunchKernelGGL((k_seg_tiles<KeyT, Segs>), dim3(blocks_for(n_segs, 256)), dim3(256), 0,
-                     ctx->stream, segs, n_segs, tile_base);
-  KSH_TRY(scan_exclusive_i64(ctx, tile_base, tile_base, n_segs, tile_base + n_segs));
+int plan_tile_base(ksh_ctx* ctx, const Segs& segs, int64_t n_segs, int64_t* tile_base, TileOwner* owner) {
+  // one launch when the chained scan takes it: the per-segment tile counts are computed
+  // while they are scanned, and every segment labels its tiles on the way out
+  const LoadSegTiles<KeyT, Segs> load{segs};
+  const bool chained = owner ? scan_exclusive_chained(ctx, load, tile_base, n_segs, tile_base + n_segs,
+                                                      EmitTileOwners{owner})
+                             : scan_exclusive_chained(ctx, load, tile_base, n_segs, tile_base + n_segs);
+  if (!chained) {
+    hipLaunchKernelGGL((k_seg_tiles<KeyT, Segs>), dim3(blocks_for(n_segs, 256)), dim3(256), 0,
+                       ctx->stream, segs, n_segs, tile_base);
+    KSH_TRY(scan_exclusive_i64(ctx, tile_base, tile_base, n_segs, tile_base + n_segs));
+    if (owner)
+      hipLaunchKernelGGL(k_tile_owners, dim3(blocks_for(n_segs, 256)), dim3(256), 0, ctx->stream, tile_base,
+                         n_segs, owner);
+  }
+  KSH_HIP(hipGetLastError());
+  return KSH_OK;
+}
+
+inline int label_tiles(ksh_ctx* ctx, const int64_t* tile_base, int64_t n_segs, TileOwner* owner) {
+  hipLaunchKernelGGL(k_tile_owners, dim3(blocks_for(n_segs, 256)), dim3(256), 0, ctx->stream, tile_base,
+                     n_segs, owner);
+  KSH_HIP(hipGetLastError());
   return KSH_OK;
 }
 
@@ -559,7 +616,7 @@ int plan_tile_base(ksh_ctx* ctx, const Segs& segs, int64_t n_segs, int64_t* tile
 template <typename KeyT, typename Segs>
 int plan_count(ksh_ctx* ctx, const Segs& segs, const Plan& p, int timer_kind, bool save_split) {
   hipLaunchKernelGGL((k_tile_split<KeyT, Segs>), dim3(blocks_for(p.max_tiles, 256)), dim3(256), 0,
-                     ctx->stream, segs, p.n_segs, p.tile_base, p.desc);
+                     ctx->stream, segs, p.n_segs, p.tile_base, p.owner, p.desc);
   {
     Timer timer(ctx, timer_kind);
     launch_tile_merge<KeyT, 0>(ctx, p, p.tile_ioff, nullptr, save_split ? p.split : nullptr,
@@ -594,7 +651,7 @@ int pair_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ks
   plan_carve(ctx->plan, nb, max_tiles, &p);
   BucketSegs<KeyT> segs{static_cast<const KeyT*>(a->d_keys), a->d_offsets,
                         static_cast<const KeyT*>(b->d_keys), b->d_offsets};
-  KSH_TRY((plan_tile_base<KeyT>(ctx, segs, nb, p.tile_base)));
+  KSH_TRY((plan_tile_base<KeyT>(ctx, segs, nb, p.tile_base, p.owner)));
   KSH_TRY((plan_count<KeyT>(ctx, segs, p, 1, true)));
   int64_t* d_totals = static_cast<int64_t*>(arena_alloc(ctx, 3 * sizeof(int64_t)));
   if (!d_totals) return fail(KSH_INTERNAL, "scratch arena too small");
@@ -653,7 +710,7 @@ int pair_algebra_enqueue(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a,
   plan_carve(base, nb, max_tiles, &p);
   BucketSegs<KeyT> segs{static_cast<const KeyT*>(a->d_keys), a->d_offsets,
                         static_cast<const KeyT*>(b->d_keys), b->d_offsets};
-  KSH_TRY((plan_tile_base<KeyT>(ctx, segs, nb, p.tile_base)));
+  KSH_TRY((plan_tile_base<KeyT>(ctx, segs, nb, p.tile_base, p.owner)));
   KSH_TRY((plan_count<KeyT>(ctx, segs, p, 1, true)));
   hipLaunchKernelGGL(k_result_offsets, dim3(blocks_for(nb + 1, 256)), dim3(256), 0, ctx->stream,
                      a->d_offsets, b->d_offsets, p.tile_base, p.tile_ioff, p.total_m, nb, d_off_i,
@@ -745,7 +802,7 @@ int union_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const k
   plan_carve(ctx->plan, nb, max_tiles, &p);
   BucketSegs<KeyT> segs{static_cast<const KeyT*>(a->d_keys), a->d_offsets,
                         static_cast<const KeyT*>(b->d_keys), b->d_offsets};
-  KSH_TRY((plan_tile_base<KeyT>(ctx, segs, nb, p.tile_base)));
+  KSH_TRY((plan_tile_base<KeyT>(ctx, segs, nb, p.tile_base, p.owner)));
   KSH_TRY((plan_count<KeyT>(ctx, segs, p, 1, true)));
   int64_t* d_total = static_cast<int64_t*>(arena_alloc(ctx, sizeof(int64_t)));
   if (!d_total) return fail(KSH_INTERNAL, "scratch arena too small");
@@ -791,7 +848,7 @@ int set_diff_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh
   plan_carve(base, nb, max_tiles, &p);
   BucketSegs<KeyT> segs{static_cast<const KeyT*>(a->d_keys), a->d_offsets,
                         static_cast<const KeyT*>(b->d_keys), b->d_offsets};
-  KSH_TRY((plan_tile_base<KeyT>(ctx, segs, nb, p.tile_base)));
+  KSH_TRY((plan_tile_base<KeyT>(ctx, segs, nb, p.tile_base, p.owner)));
   KSH_TRY((plan_count<KeyT>(ctx, segs, p, 1, false)));
   KSH_HIP(hipMemcpyAsync(ctx->h_pinned, p.total_m, sizeof(int64_t), hipMemcpyDeviceToHost,
                          ctx->stream));
@@ -827,7 +884,7 @@ int pair_weights_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sets, in
   KSH_HIP(hipMemcpyAsync(d_ids, bucket_ids, size_t(n_ids) * 4, hipMemcpyHostToDevice, ctx->stream));
   KSH_HIP(hipMemcpyAsync(d_pairs, pairs, size_t(n_pairs) * 8, hipMemcpyHostToDevice, ctx->stream));
   PairSegs<KeyT> segs{d_sets, d_ids, d_pairs, n_ids};
-  KSH_TRY((plan_tile_base<KeyT>(ctx, segs, n_segs, tile_base)));
+  KSH_TRY((plan_tile_base<KeyT>(ctx, segs, n_segs, tile_base, nullptr)));
   // exact tile count (the sampled slices are ~2 % of each set; no useful bound without it)
   KSH_HIP(hipMemcpyAsync(ctx->h_pinned, tile_base + n_segs, sizeof(int64_t), hipMemcpyDeviceToHost,
                          ctx->stream));
@@ -847,6 +904,7 @@ int pair_weights_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sets, in
   plan_carve(base, 0, n_tiles, &p);
   p.n_segs = n_segs;
   p.tile_base = tile_base;
+  KSH_TRY(label_tiles(ctx, tile_base, n_segs, p.owner));
   KSH_TRY((plan_count<KeyT>(ctx, segs, p, 2, false)));
   hipLaunchKernelGGL(k_pair_weight_gather, dim3(blocks_for(n_pairs, 256)), dim3(256), 0,
                      ctx->stream, p.tile_base, p.tile_ioff, p.total_m, n_segs, n_ids, n_pairs,

@@ -157,6 +157,30 @@ class DeviceSet:
         self.g, self.offsets, self.keys, self.n_keys = g, offsets, keys_bytes, int(n_keys)
 
     @classmethod
+    def carved(cls, g, off_rows, row, key_pool, byte_start, byte_len):
+        """A set whose offsets are row `row` of off_rows and whose keys are a byte range of
+        key_pool; the tensor slices are only made when somebody asks for them (a batch of pair
+        results carves dozens of these per call)."""
+        self = cls.__new__(cls)
+        self.g, self.n_keys = g, 0
+        self._carve = (off_rows, row, key_pool, byte_start, byte_len)
+        self._ptrs = (off_rows.data_ptr() + row * off_rows.shape[1] * 8, key_pool.data_ptr() + byte_start)
+        return self
+
+    def __getattr__(self, name):
+        # only reached for attributes that are not set: the lazily sliced tensors of carved()
+        if name in ("offsets", "keys") and "_carve" in self.__dict__:
+            off_rows, row, key_pool, byte_start, byte_len = self._carve
+            self.offsets = off_rows[row]
+            self.keys = key_pool[byte_start:byte_start + byte_len]
+            return self.__dict__[name]
+        raise AttributeError(name)
+
+    def pointers(self):
+        p = self.__dict__.get("_ptrs")
+        return p if p is not None else (self.offsets.data_ptr(), self.keys.data_ptr())
+
+    @classmethod
     def from_numpy(cls, g, offsets, keys, device):
         import torch
 
@@ -184,7 +208,8 @@ class DeviceSet:
         return cls(g, off, keys, n_keys)
 
     def view(self):
-        return SetView(self.offsets.data_ptr(), self.keys.data_ptr(), self.n_keys)
+        po, pk = self.pointers()
+        return SetView(po, pk, self.n_keys)
 
     def to_numpy(self):
         kdt = np.uint32 if self.g.key_bytes == 4 else np.uint64
@@ -403,20 +428,26 @@ class Context:
         import torch
 
         g = pairs[0][0].g
+        kb = g.key_bytes
         jobs = (PairJob * len(pairs))()
+        # one offsets block and one key pool for the whole batch, carved by pointer arithmetic
+        caps = [(min(a.n_keys, b.n_keys), a.n_keys, b.n_keys) for a, b in pairs]
+        starts, at = [], 0
+        for trio in caps:
+            for cap in trio:
+                starts.append(at)
+                at += (max(cap * kb, 16) + 255) & ~255
+        off_rows = torch.empty((3 * len(pairs), (1 << g.n_bucket_bits) + 1), dtype=torch.int64, device=self.device)
+        key_pool = torch.empty(at, dtype=torch.uint8, device=self.device)
         outs = []
         for idx, (a, b) in enumerate(pairs):
-            caps = (min(a.n_keys, b.n_keys), a.n_keys, b.n_keys)
-            trio = []
-            for cap in caps:
-                o = DeviceSet.empty_like_offsets(g, 0, self.device)
-                o.keys = torch.empty(max(cap * g.key_bytes, 16), dtype=torch.uint8, device=self.device)
-                trio.append(o)
+            trio = [DeviceSet.carved(g, off_rows, 3 * idx + r, key_pool, starts[3 * idx + r],
+                                     max(caps[idx][r] * kb, 16)) for r in range(3)]
             outs.append(trio)
             j = jobs[idx]
             j.a, j.b = a.view(), b.view()
-            j.d_off_i, j.d_off_amb, j.d_off_bma = (t.offsets.data_ptr() for t in trio)
-            j.d_keys_i, j.d_keys_amb, j.d_keys_bma = (t.keys.data_ptr() for t in trio)
+            (j.d_off_i, j.d_keys_i), (j.d_off_amb, j.d_keys_amb), (j.d_off_bma, j.d_keys_bma) = (
+                t.pointers() for t in trio)
         check(lib().ksh_pair_algebra_batch(self.h, C.byref(g), jobs, len(pairs)))
         for idx, trio in enumerate(outs):
             for o, n in zip(trio, jobs[idx].totals):

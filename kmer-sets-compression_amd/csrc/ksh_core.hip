@@ -458,7 +458,7 @@ int ksh_ctx_create(int device, void* stream, ksh_ctx** out) {
     delete ctx;
     return rc;
   }
-  const size_t state_bytes = size_t(kChainMaxBlocks) * sizeof(unsigned long long);
+  const size_t state_bytes = size_t(2 * kChainMaxBlocks) * sizeof(unsigned long long);
   if (hipMalloc(reinterpret_cast<void**>(&ctx->scan_state), state_bytes) != hipSuccess ||
       hipMemset(ctx->scan_state, 0, state_bytes) != hipSuccess) {
     ksh_ctx_destroy(ctx);

@@ -558,16 +558,15 @@ inline void plan_carve(char* base, int64_t n_segs, int64_t max_tiles, Plan* p) {
   p->owner = reinterpret_cast<TileOwner*>(at);
 }
 
-// Consecutive tiles handled by one wave of k_tile_merge: as many as still leave every wave
-// slot of the chip (256 CUs x 32) about two waves, at most 4.  The tile count is only known
-// on the device; the host bound max_tiles is close to it when buckets are evenly filled.
+// Consecutive tiles handled by one wave of k_tile_merge.
 inline int tiles_per_wave(int64_t max_tiles) {
-  static const int forced = [] {
-    const char* e = std::getenv("KSH_TILES_PER_WAVE");
-    return e ? std::atoi(e) : 0;
-  }();
-  if (forced > 0) return forced;
-  return int(std::min<int64_t>(4, std::max<int64_t>(1, max_tiles / (2 * 256 * 32))));
+  (void)max_tiles;
+  // Measured on config 2 (docs: DESIGN.md 3.1): more than one tile per wave is slower at every
+  // size tried, with or without register prefetch of the next tile -- many short waves keep
+  // more memory requests in flight than few long ones.  The knob stays for experiments.
+  const char* e = std::getenv("KSH_TILES_PER_WAVE");
+  const int forced = e ? std::atoi(e) : 0;
+  return forced > 0 ? forced : 1;
 }
 
 template <typename KeyT, int kMode>

@@ -5,10 +5,13 @@
 // Every workgroup scans its own 2048 values, publishes their sum in `state`, then adds up the
 // sums published by the workgroups before it and writes its values out.  A workgroup only
 // ever waits for workgroups with a smaller index, which were dispatched no later than it was
-// and wait only for still smaller ones, so the chain always makes progress.  The published
-// word carries the launch's epoch in its top 16 bits: words left by earlier launches never
-// match and the state array needs no clearing between launches.  XCD L2s are not coherent
-// with each other, so the word is stored and polled with agent-scope atomics.
+// and wait only for still smaller ones, so the chain always makes progress.  A sum is
+// published as two words (its low 48 bits and its high 16 bits), each carrying the launch's
+// epoch in its top 16 bits: a word is valid by itself, so the two need no ordering between
+// them, words left by earlier launches never match, and the state array needs no clearing
+// between launches.  XCD L2s are not coherent with each other, so the words are stored and
+// polled with agent-scope atomics.  Sums are full 64-bit values (callers scan packed
+// counters).
 //
 // The values come from a functor (index -> int64), which lets a caller fold the kernel that
 // would have produced the input array into the scan; a second functor sees every value with
@@ -24,7 +27,7 @@ constexpr int kChainThreads = 256;
 constexpr int kChainItems = 8;
 constexpr int kChainTile = kChainThreads * kChainItems;
 constexpr int64_t kChainMaxBlocks = 128;  // every workgroup reads all earlier sums: keep the chain short
-constexpr int kChainValueBits = 48;       // sums must stay below 2^48 (they are key counts)
+constexpr int kChainValueBits = 48;       // payload bits of a published word
 
 struct LoadArray {
   const int64_t* in;
@@ -69,21 +72,26 @@ __global__ __launch_bounds__(kChainThreads) void k_scan_chained(Load load, Emit 
     block_total += wave_sum[w];
   }
   constexpr unsigned long long kValueMask = (1ull << kChainValueBits) - 1;
-  if (threadIdx.x == 0)
-    __hip_atomic_store(&state[b], (epoch << kChainValueBits) | (static_cast<unsigned long long>(block_total) & kValueMask),
-                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const unsigned long long tag = epoch << kChainValueBits;
+  if (threadIdx.x < 2) {
+    const unsigned long long t = static_cast<unsigned long long>(block_total);
+    const unsigned long long part = threadIdx.x == 0 ? (t & kValueMask) : (t >> kChainValueBits);
+    __hip_atomic_store(&state[2 * b + threadIdx.x], tag | part, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
   if (wave == 0) {
-    int64_t sum = 0;
+    unsigned long long sum_u = 0;
     for (int64_t first = b - 1; first >= 0; first -= 64) {
       const int64_t idx = first - lane;
       if (idx >= 0) {
-        unsigned long long w;
+        unsigned long long w0, w1;
         do {
-          w = __hip_atomic_load(&state[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } while ((w >> kChainValueBits) != epoch);
-        sum += static_cast<int64_t>(w & kValueMask);
+          w0 = __hip_atomic_load(&state[2 * idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          w1 = __hip_atomic_load(&state[2 * idx + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while ((w0 >> kChainValueBits) != epoch || (w1 >> kChainValueBits) != epoch);
+        sum_u += (w0 & kValueMask) | (w1 << kChainValueBits);
       }
     }
+    int64_t sum = static_cast<int64_t>(sum_u);
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
     if (lane == 0) block_prefix = sum;
@@ -110,7 +118,7 @@ bool scan_exclusive_chained(ksh_ctx* ctx, const Load& load, int64_t* d_out, int6
   ctx->scan_epoch = (ctx->scan_epoch + 1) & 0xFFFF;
   if (ctx->scan_epoch == 0) {
     // epochs are about to repeat: forget every word published so far
-    (void)hipMemsetAsync(ctx->scan_state, 0, size_t(kChainMaxBlocks) * sizeof(unsigned long long), ctx->stream);
+    (void)hipMemsetAsync(ctx->scan_state, 0, size_t(2 * kChainMaxBlocks) * sizeof(unsigned long long), ctx->stream);
     ctx->scan_epoch = 1;
   }
   hipLaunchKernelGGL((k_scan_chained<Load, Emit>), dim3(unsigned(blocks)), dim3(kChainThreads), 0, ctx->stream,

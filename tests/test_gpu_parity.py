@@ -198,6 +198,51 @@ def test_config2_properties(ctx):
             assert np.array_equal(inter.kmers(), np.intersect1d(sets[i], sets[j]))
 
 
+@pytest.mark.parametrize("tiles_per_wave", ["1", "3"])
+def test_large_pair_properties(ctx, tiles_per_wave, monkeypatch):
+    """Two device-generated k=23 sets of 6.5e7 k-mers: more than 2^17 tiles, so the tile-count
+    prefix takes the chained scan with more than 64 workgroups and the multi-launch scan is
+    used for nothing; several tiles per bucket; optionally several tiles per wave.  Checked
+    through identities that need no host copy of the sets."""
+    import torch
+    from kmersets import synth_torch
+
+    monkeypatch.setenv("KSH_TILES_PER_WAVE", tiles_per_wave)
+    k, n = 23, 14
+    size = int(float(os.environ.get("KMERSETS_TEST_LARGE", "6.5e7")))
+    g = capi.geom(k, n)
+    ka, kb = synth_torch.phylogeny_sets(k, 2, size, seed=9, device=ctx.device)
+    a, b = synth_torch.device_set(g, ka), synth_torch.device_set(g, kb)
+    # expected sizes and hashes from torch on the sorted k-mer tensors
+    both = torch.cat([ka, kb]).sort().values
+    dup = both[1:] == both[:-1]
+    want_i = both[1:][dup]
+    xor = lambda t: int(np.bitwise_xor.reduce(t.cpu().numpy().astype(np.uint64))) if t.numel() else 0
+    h_a, h_b, h_i = xor(ka), xor(kb), xor(want_i)
+    del both, dup
+    assert ctx.set_hash(a) == h_a and ctx.set_hash(b) == h_b
+    inter, amb, bma = ctx.pair_algebra(a, b)
+    assert inter.n_keys == want_i.numel() and ctx.set_hash(inter) == h_i
+    assert inter.n_keys + amb.n_keys == a.n_keys and inter.n_keys + bma.n_keys == b.n_keys
+    assert ctx.set_hash(amb) == h_a ^ h_i and ctx.set_hash(bma) == h_b ^ h_i
+    assert ctx.set_diff(a, b) == amb.n_keys + bma.n_keys
+    i2 = ctx.pair_algebra_batch([(b, a)])[0]
+    assert ctx.set_diff(i2[0], inter) == 0 and ctx.set_diff(i2[1], bma) == 0 and ctx.set_diff(i2[2], amb) == 0
+    key_bits = 2 * k - n
+    for s_, want in ((inter, want_i), (amb, None), (bma, None)):
+        off = s_.offsets
+        assert int(off[0]) == 0 and int(off[-1]) == s_.n_keys and bool(torch.all(off[1:] >= off[:-1]))
+        keys = s_.keys[: s_.n_keys * 4].view(torch.int32).to(torch.int64) & 0xFFFFFFFF
+        bucket = torch.repeat_interleave(torch.arange(1 << n, device=keys.device), off[1:] - off[:-1])
+        km = (bucket << key_bits) | keys
+        assert bool(torch.all(km[1:] > km[:-1]))
+        if want is not None:
+            assert bool(torch.equal(km, want))
+    # union through the same tiles: |A u B| and its hash
+    u = ctx.set_union(a, b)
+    assert u.n_keys == a.n_keys + bma.n_keys and ctx.set_hash(u) == h_a ^ h_b ^ h_i
+
+
 def test_device_generator_matches_host(ctx):
     """bench.py builds its large inputs on the GPU; same sets as the numpy generator."""
     from kmersets import synth_torch

@@ -149,6 +149,18 @@ def test_encode_families(ctx, geom):
     check_encode(ctx, k, n, kb, np.setdiff1d(sets[2], sets[0]))
 
 
+def test_encode_many_unitigs(ctx):
+    """150 000 unrelated k-mers: about as many unitigs, nearly all of one kind, so the packed
+    two-counter prefix sums over the unitigs pass 2^48 on arrays of 10^5 elements (the
+    single-launch scan has to carry full 64-bit sums), and a mixed set on the same path."""
+    k, n, kb = 15, 14, 2
+    lone, other = synth.uniform_pair(k, 150000, 0.5, seed=77)
+    stats = check_encode(ctx, k, n, kb, lone)
+    assert stats["unitigs"] > 100000
+    reads = synth.random_read_kmers(k, 200000, seed=78, canonical=True)
+    check_encode(ctx, k, n, kb, np.union1d(reads, other[:80000]))
+
+
 def test_encode_roundtrip_large(ctx):
     """Size-independent properties at 2 x 10^6 k-mers (k = 23): every k-mer exactly once,
     decode(encode(S)) == S, weight = |S| + (K-1) * strings."""

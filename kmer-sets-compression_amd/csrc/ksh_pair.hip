@@ -31,7 +31,13 @@ namespace ksh {
 // tiles large enough to take such a bucket whole.  Single-wave workgroups need no cross-wave
 // scan and no barrier that waits for another wave.  The LDS footprint (6 KB) keeps 26
 // tiles in flight per CU; 8-byte keys use smaller tiles to stay at that occupancy.
-constexpr int kThreads = 64;
+constexpr int kThreads = 64;        // lanes per tile (one wavefront)
+// Wavefronts per workgroup of k_tile_merge.  The waves of a workgroup work on different tiles and
+// never talk to each other.  The dispatcher launches about 4.4 workgroups per ns whatever their
+// size (tools/launch_rate.hip: 32768 empty single-wave workgroups take 8 us), but packing four
+// waves into a workgroup measured the same kernel times on config 2 (dispatch overlaps the
+// waves already running), so workgroups stay single waves: their LDS is released wave by wave.
+constexpr int kGroupWaves = 1;
 
 template <typename KeyT>
 struct TileCfg {
@@ -236,16 +242,37 @@ struct TileStage {
     b_lo = int(b_vec0) * kPer + mis_b;
     b_hi = b_lo + cb;
   }
-  // global -> LDS, one range after the other
+  // global -> LDS: every load of both ranges is issued before the first one is waited for
+  // (a loop that loads and stores one vector per trip pays one memory round trip per trip).
   __device__ __forceinline__ void copy(KeyT* lds) const {
     Vec* l = reinterpret_cast<Vec*>(lds);
-    for (uint32_t v = threadIdx.x; v < va; v += kThreads) l[v] = ga[v];
-    for (uint32_t v = threadIdx.x; v < vb; v += kThreads) l[b_vec0 + v] = gb[v];
+    const uint32_t lane = threadIdx.x & (kThreads - 1);
+    Vec ra[Cfg::kVecs], rb[Cfg::kVecs];
+    // Straight-line, unconditional loads: lanes past a range's end re-read its last vector
+    // (one coalesced request), an empty range reads from the other one (a tile is never empty
+    // on both sides); only the stores are predicated.  Conditional loads would make the
+    // compiler wait at every join.
+    const GlobalVecs safe_a = va ? ga : gb, safe_b = vb ? gb : ga;
+    const uint32_t last_a = (va ? va : vb) - 1, last_b = (vb ? vb : va) - 1;
+#pragma unroll
+    for (int j = 0; j < Cfg::kVecs; j++) ra[j] = safe_a[min(lane + j * kThreads, last_a)];
+#pragma unroll
+    for (int j = 0; j < Cfg::kVecs; j++) rb[j] = safe_b[min(lane + j * kThreads, last_b)];
+#pragma unroll
+    for (int j = 0; j < Cfg::kVecs; j++) {
+      const uint32_t v = lane + j * kThreads;
+      if (uint32_t(j * kThreads) < va && v < va) l[v] = ra[j];
+    }
+#pragma unroll
+    for (int j = 0; j < Cfg::kVecs; j++) {
+      const uint32_t v = lane + j * kThreads;
+      if (uint32_t(j * kThreads) < vb && v < vb) l[b_vec0 + v] = rb[j];
+    }
   }
   __device__ __forceinline__ void load(Vec (&r)[Cfg::kVecs]) const {
 #pragma unroll
     for (int j = 0; j < Cfg::kVecs; j++) {
-      const uint32_t v = threadIdx.x + j * kThreads;
+      const uint32_t v = (threadIdx.x & (kThreads - 1)) + j * kThreads;
       if (v < va + vb) r[j] = *(v < va ? ga + v : gb + (v - va));
     }
   }
@@ -253,7 +280,7 @@ struct TileStage {
     Vec* l = reinterpret_cast<Vec*>(lds);
 #pragma unroll
     for (int j = 0; j < Cfg::kVecs; j++) {
-      const uint32_t v = threadIdx.x + j * kThreads;
+      const uint32_t v = (threadIdx.x & (kThreads - 1)) + j * kThreads;
       if (v < va + vb) l[v < va ? v : b_vec0 + (v - va)] = r[j];
     }
   }
@@ -271,7 +298,7 @@ __device__ __forceinline__ void copy_out(const KeyT* __restrict__ lds, uint32_t 
   const char* l = reinterpret_cast<const char*>(lds + lds_first);
   const uint32_t end = cnt * uint32_t(sizeof(KeyT));
 #pragma unroll 2
-  for (uint32_t x = threadIdx.x * uint32_t(sizeof(KeyT)); x < end; x += kThreads * uint32_t(sizeof(KeyT)))
+  for (uint32_t x = (threadIdx.x & (kThreads - 1)) * uint32_t(sizeof(KeyT)); x < end; x += kThreads * uint32_t(sizeof(KeyT)))
     *(GlobalKeys)(o + x) = *reinterpret_cast<const KeyT*>(l + x);
 }
 
@@ -290,6 +317,14 @@ __device__ __forceinline__ uint32_t wave_inclusive_scan_u32(uint32_t v) {
   return v;
 }
 
+// Orders the LDS accesses of one wave: a wave's LDS instructions execute in issue order, so a
+// read placed after this sees every write placed before it, whichever lane made it.
+__device__ __forceinline__ void wave_sync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // Build with -DKSH_TRACE to record s_memtime at the phases of every tile (debugging aid for
 // the latency breakdown in DESIGN.md; compiled out otherwise).
 #ifdef KSH_TRACE
@@ -297,7 +332,7 @@ __device__ unsigned long long* g_tile_trace = nullptr;
 __device__ int g_tile_stop_after = 0;  // 1: return once the tile's keys are in LDS
 #define KSH_MARK(k, tile)                                                                      \
   do {                                                                                   \
-    if (g_tile_trace && threadIdx.x == 0)                                                \
+    if (g_tile_trace && (threadIdx.x & 63) == 0)                                                \
       g_tile_trace[(int64_t(kMode != 0) * max_tiles + (tile)) * 8 + (k)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
 #else
@@ -305,7 +340,7 @@ __device__ int g_tile_stop_after = 0;  // 1: return once the tile's keys are in 
 #endif
 
 template <typename KeyT, int kMode>
-__global__ __launch_bounds__(kThreads) void k_tile_merge(
+__global__ __launch_bounds__(kThreads * kGroupWaves) void k_tile_merge(
     const TileDesc* __restrict__ desc, const int64_t* __restrict__ total_tiles, int64_t max_tiles,
     int tiles_per_wave, int64_t* __restrict__ tile_m, const int64_t* __restrict__ tile_ioff,
     uint16_t* __restrict__ split, KeyT* __restrict__ out_i, KeyT* __restrict__ out_amb,
@@ -314,13 +349,15 @@ __global__ __launch_bounds__(kThreads) void k_tile_merge(
   using Stage = TileStage<KeyT>;
   constexpr int kVT = Cfg::kVT;
   constexpr bool kWrite = kMode != 0;
-  __shared__ __attribute__((aligned(16))) KeyT lds[Cfg::kLds];
+  __shared__ __attribute__((aligned(16))) KeyT lds_all[kGroupWaves][Cfg::kLds];
 
-  // This wave owns tiles [t_first, t_end): consecutive tiles, so consecutive memory.  The
-  // keys of tile t + 1 are loaded into registers before tile t is merged: the wave's HBM
-  // latency overlaps its own compute instead of waiting for another wave to cover it.
-  const int lane = threadIdx.x;
-  const int64_t t_first = int64_t(blockIdx.x) * tiles_per_wave;
+  // This wave owns tiles [t_first, t_end), consecutive tiles (tiles_per_wave is 1 unless
+  // forced, see tiles_per_wave()), and one slice of the workgroup's LDS.  Nothing below
+  // synchronises across waves: wave_sync() orders this wave's own LDS traffic.
+  const int lane = threadIdx.x & (kThreads - 1);
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kThreads);  // uniform: stays scalar
+  KeyT* const lds = lds_all[wave];
+  const int64_t t_first = (int64_t(blockIdx.x) * kGroupWaves + wave) * tiles_per_wave;
   const int64_t n_tiles = *total_tiles;
   const int64_t t_end = min(t_first + tiles_per_wave, n_tiles);
   if (!kWrite) {
@@ -337,7 +374,7 @@ __global__ __launch_bounds__(kThreads) void k_tile_merge(
 #ifdef KSH_TRACE
     if (g_tile_stop_after == 1) {
       if (!kWrite && lane == 0) tile_m[t] = lds[st.a_lo] == lds[st.b_lo];
-      __syncthreads();
+      wave_sync();
       return;
     }
 #endif
@@ -426,12 +463,12 @@ __global__ __launch_bounds__(kThreads) void k_tile_merge(
     if constexpr (!kWrite) {
       if (lane == 0) tile_m[t] = tot_i;
       KSH_MARK(5, t);
-      __syncthreads();  // all reads of this tile's keys are done before the next tile lands
+      wave_sync();  // all reads of this tile's keys are done before the next tile lands
     } else {
       KSH_MARK(5, t);
       const uint32_t excl_i = excl & 0xFFFF, excl_a = excl >> 16;
       const uint32_t excl_b = uint32_t(d0) - 2 * excl_i - excl_a + uint32_t(straddle);
-      __syncthreads();  // every lane is done reading the inputs: reuse the LDS for compaction
+      wave_sync();  // every lane is done reading the inputs: reuse the LDS for compaction
       const int64_t ioff = tile_ioff[t];
       // A&B keys go to [0, tot_i), A\B keys to [tot_i, tot_i + tot_a), B\A keys after them
       // (union: every kept key, in merged order).  The three write positions travel in one
@@ -455,7 +492,7 @@ __global__ __launch_bounds__(kThreads) void k_tile_merge(
           }
         }
       }
-      __syncthreads();
+      wave_sync();
       KSH_MARK(6, t);
       if (kMode == 2) {
         copy_out(lds, 0, tot_i + tot_a + tot_b, out_i + (d.a0 + d.b0 - ioff));
@@ -465,7 +502,7 @@ __global__ __launch_bounds__(kThreads) void k_tile_merge(
         if (out_bma) copy_out(lds, tot_i + tot_a, tot_b, out_bma + (d.b0 - ioff));
       }
       KSH_MARK(7, t);
-      __syncthreads();  // the compacted keys are read out before the next tile lands
+      wave_sync();  // the compacted keys are read out before the next tile lands
     }
   };
 
@@ -478,7 +515,7 @@ __global__ __launch_bounds__(kThreads) void k_tile_merge(
     st.init(d);
     KSH_MARK(1, t);
     st.copy(lds);
-    __syncthreads();
+    wave_sync();
     process(d, st, t);
   }
 }
@@ -574,7 +611,8 @@ void launch_tile_merge(ksh_ctx* ctx, const Plan& p, int64_t* tile_m, const int64
                        uint16_t* split, KeyT* out_i, KeyT* out_amb, KeyT* out_bma) {
   const int tpw = tiles_per_wave(p.max_tiles);
   const int64_t waves = (p.max_tiles + tpw - 1) / tpw;
-  hipLaunchKernelGGL((k_tile_merge<KeyT, kMode>), dim3(unsigned(waves)), dim3(kThreads), 0, ctx->stream,
+  const int64_t groups = (waves + kGroupWaves - 1) / kGroupWaves;
+  hipLaunchKernelGGL((k_tile_merge<KeyT, kMode>), dim3(unsigned(groups)), dim3(kThreads * kGroupWaves), 0, ctx->stream,
                      p.desc, p.tile_base + p.n_segs, p.max_tiles, tpw, tile_m, tile_ioff, split, out_i,
                      out_amb, out_bma);
 }

@@ -108,8 +108,11 @@ def main():
     pairs = [(i, j) for i in range(n_sets) for j in range(i + 1, n_sets)]
     units_per_step = sum(sets[i].n_keys + sets[j].n_keys for i, j in pairs)
 
-    diff_local = torch.zeros(len(pairs), dtype=torch.int64, device=coll_dev)
-    gathered = [torch.zeros_like(diff_local) for _ in range(world)] if world > 1 else None
+    # two slots: the all-gather of step s travels while step s + 1 computes
+    diff_local = [torch.zeros(len(pairs), dtype=torch.int64, device=coll_dev) for _ in range(2)]
+    gathered = [[torch.zeros_like(diff_local[0]) for _ in range(world)] for _ in range(2)] if world > 1 else None
+    pending = [None]
+    step_no = [0]
     algo_bytes = [0.0]
 
     algebra = ctx.pair_algebra if args.two_pass else ctx.pair_algebra_onepass
@@ -127,12 +130,20 @@ def main():
                 union = sets[i].n_keys + bma.n_keys
                 algo_bytes[0] += (sets[i].n_keys + sets[j].n_keys + union) * g.key_bytes
         if world > 1:
-            diff_local.copy_(torch.tensor(diffs, dtype=torch.int64), non_blocking=False)
-            dist.all_gather(gathered, diff_local)
+            slot = step_no[0] & 1
+            step_no[0] += 1
+            diff_local[slot].copy_(torch.tensor(diffs, dtype=torch.int64), non_blocking=False)
+            work = dist.all_gather(gathered[slot], diff_local[slot], async_op=True)
+            if pending[0] is not None:
+                pending[0].wait()      # the previous step's exchange; this one overlaps the next step
+            pending[0] = work
         return diffs
 
     def fence():
         if world > 1:
+            if pending[0] is not None:
+                pending[0].wait()
+                pending[0] = None
             dist.barrier()
         torch.cuda.synchronize()
 

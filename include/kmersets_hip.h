@@ -177,6 +177,20 @@ int ksh_spss_decode_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s
 int ksh_spss_decode_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int canonical,
                           int64_t* d_offsets, void* d_keys, int64_t* n_keys);
 
+/* ---- Text form of an SPSS: the file format of KmerSetCompact::Dump / Load ------------------
+ * (lib/core/kmer_set_compact.h:62-87 over WriteLines / ReadLines, lib/core/io.h:20-126): one
+ * string over ACGT per line, every line closed by '\n'; the reference spells / parses it base
+ * by base on the host (ToStrings :290-336, the private constructor :206-266).
+ * to_text: d_text receives exactly n_bases + n_strings bytes.
+ * from_text: plan counts the lines and bases of n_bytes of text in device memory (a last line
+ * without '\n' counts); the caller allocates ceil(n_bases / 32) words and n_strings lengths;
+ * write fills them (ksh_spss_view layout).  A byte other than A, C, G, T, '\n' or a line
+ * shorter than K is KSH_INVALID_ARGUMENT (the reference asserts / underflows).  K >= 4. */
+int ksh_spss_to_text(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, char* d_text);
+int ksh_spss_from_text_plan(ksh_ctx* ctx, const ksh_geom* g, const char* d_text, int64_t n_bytes,
+                            int64_t* n_strings, int64_t* n_bases);
+int ksh_spss_from_text_write(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens);
+
 /* ---- StreamVByte "0124" pack of the string lengths ---------------------------------------
  * The in-memory form of KmerSetCompact::lengths_compressed_
  * (lib/core/kmer_set_compact.h:257-265 streamvbyte_encode_0124, :269-287 decode; format in

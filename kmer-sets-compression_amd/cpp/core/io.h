@@ -68,6 +68,55 @@ inline Status WriteLines(const std::string& file_name, const std::string& compre
   return OkStatus();
 }
 
+// The same files as whole byte buffers: the device spells and parses the lines
+// (ksh_spss_to_text / ksh_spss_from_text_*), the host only moves bytes.
+inline StatusOr<std::string> ReadBytes(const std::string& file_name, const std::string& decompressor) {
+  std::string s;
+  if (decompressor.empty()) {
+    std::ifstream file(file_name, std::ios::binary);
+    if (file.fail()) return InternalError("failed to open file");
+    file.seekg(0, std::ios::end);
+    const std::streamoff size = file.tellg();
+    file.seekg(0, std::ios::beg);
+    s.resize(static_cast<std::size_t>(size));
+    if (size > 0) file.read(&s[0], size);
+    if (file.fail()) return InternalError("failed to read file");
+    return s;
+  }
+  std::FILE* f = popen((decompressor + " < " + file_name).c_str(), "r");
+  if (f == NULL) return InternalError("failed to open a sub-process");
+  {
+    char buf[1 << 16];
+    std::size_t got;
+    while ((got = std::fread(buf, 1, sizeof(buf), f)) > 0) s.append(buf, got);
+  }
+  const int exit_status = pclose(f);
+  if (exit_status != 0)
+    return InternalError("process failed with non-zero exit code: " + std::to_string(exit_status));
+  return s;
+}
+
+inline Status WriteBytes(const std::string& file_name, const std::string& compressor, const char* data,
+                         std::size_t size) {
+  if (compressor.empty()) {
+    std::ofstream file(file_name, std::ios::binary);
+    if (file.fail()) return InternalError("failed to open file");
+    file.write(data, static_cast<std::streamsize>(size));
+    if (file.fail()) return InternalError("failed to write file");
+    return OkStatus();
+  }
+  std::FILE* f = popen((compressor + " > " + file_name).c_str(), "w");
+  if (f == NULL) return InternalError("failed to open a sub-process");
+  if (size > 0 && std::fwrite(data, 1, size, f) != size) {
+    pclose(f);
+    return InternalError("failed to write to the process");
+  }
+  const int exit_status = pclose(f);
+  if (exit_status != 0)
+    return InternalError("process failed with non-zero exit code: " + std::to_string(exit_status));
+  return OkStatus();
+}
+
 }  // namespace ksc
 
 #endif

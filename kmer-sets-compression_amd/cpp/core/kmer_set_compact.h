@@ -100,14 +100,46 @@ class KmerSetCompact {
     return Set::FromDevice(std::move(off), std::move(keys), n);
   }
 
-  ksc::Status Dump(const std::string& file_name, const std::string& compressor, int n_workers) const {
-    return ksc::WriteLines(file_name, compressor, ToStrings(n_workers));
+  // The lines are spelled on the device (ksh_spss_to_text); the host writes one buffer.
+  ksc::Status Dump(const std::string& file_name, const std::string& compressor, int /*n_workers*/) const {
+    const std::string text = ToText();
+    return ksc::WriteBytes(file_name, compressor, text.data(), text.size());
   }
 
+  // The file's bytes go to the device as they are and are parsed there
+  // (ksh_spss_from_text_plan / _write).
   static ksc::StatusOr<KmerSetCompact> Load(const std::string& file_name, const std::string& decompressor) {
-    ksc::StatusOr<std::vector<std::string>> lines = ksc::ReadLines(file_name, decompressor);
-    if (!lines.ok()) return lines.status();
-    return FromStrings(lines.value());
+    ksc::StatusOr<std::string> bytes = ksc::ReadBytes(file_name, decompressor);
+    if (!bytes.ok()) return bytes.status();
+    return FromText(bytes.value());
+  }
+
+  // "line\nline\n...": the text Dump writes.
+  std::string ToText() const {
+    std::string text(static_cast<std::size_t>(n_bases_ + n_), '\0');
+    if (text.empty()) return text;
+    const ksh_geom g = Set::Geom();
+    const ksh_spss_view v = View();
+    ksc::DeviceBuffer d_text(text.size());
+    ksc::Check(ksh_spss_to_text(ksc::Ctx(), &g, &v, static_cast<char*>(d_text.get())));
+    ksc::Check(ksh_ctx_sync(ksc::Ctx()));
+    ksc::Check(ksh_memcpy_d2h(ksc::DeviceIndex(), &text[0], d_text.get(), text.size()));
+    return text;
+  }
+
+  static KmerSetCompact FromText(const std::string& text) {
+    KmerSetCompact c;
+    if (text.empty()) return c;
+    const ksh_geom g = Set::Geom();
+    ksc::DeviceBuffer d_text(text.size());
+    ksc::Check(ksh_memcpy_h2d(ksc::DeviceIndex(), d_text.get(), text.data(), text.size()));
+    ksc::Check(ksh_spss_from_text_plan(ksc::Ctx(), &g, static_cast<const char*>(d_text.get()),
+                                       static_cast<std::int64_t>(text.size()), &c.n_, &c.n_bases_));
+    c.words_ = ksc::DeviceBuffer(std::size_t((c.n_bases_ + 31) / 32) * 8);
+    c.lens_ = ksc::DeviceBuffer(std::size_t(c.n_) * 4);
+    ksc::Check(ksh_spss_from_text_write(ksc::Ctx(), static_cast<std::uint64_t*>(c.words_.get()),
+                                        static_cast<std::uint32_t*>(c.lens_.get())));
+    return c;
   }
 
   std::int64_t Size(int /*n_workers*/) const {

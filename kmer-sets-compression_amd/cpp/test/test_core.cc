@@ -204,6 +204,23 @@ static void TestCompact() {
     EXPECT_TRUE(s.Equals(loaded.value().ToKmerSet(true, 4), 4));
   }
   EXPECT_TRUE((!KmerSetCompact<K, N, KeyType>::Load(file + ".missing", "").ok()));
+  {
+    // the dumped bytes are the strings, one per line (device-spelled == host-spelled), and a
+    // compressor pipe sees the same bytes
+    std::string want;
+    for (const std::string& line : c.ToStrings(4)) want += line + "\n";
+    EXPECT_TRUE(c.ToText() == want);
+    auto bytes = ksc::ReadBytes(file, "");
+    EXPECT_TRUE(bytes.ok());
+    EXPECT_TRUE(bytes.value() == want);
+    EXPECT_TRUE(c.Dump(file + ".piped", "cat", 4).ok());
+    auto piped = ksc::ReadBytes(file + ".piped", "cat");
+    EXPECT_TRUE(piped.ok());
+    EXPECT_TRUE(piped.value() == want);
+    const auto again = (KmerSetCompact<K, N, KeyType>::FromText(want));
+    EXPECT_TRUE(again.ToStrings(4) == c.ToStrings(4));
+    EXPECT_EQ((KmerSetCompact<K, N, KeyType>::FromText("")).StringCount(), 0);
+  }
   EXPECT_EQ(s.Size(), c.Size(4));
   EXPECT_TRUE(s.Equals(c.ToKmerSet(true, 4), 4));
   std::vector<int> ids;

@@ -477,8 +477,9 @@ int ksh_ctx_destroy(ksh_ctx* ctx) {
   if (ctx->arena) (void)hipFree(ctx->arena);
   if (ctx->scan_state) (void)hipFree(ctx->scan_state);
   if (ctx->plan) (void)hipFree(ctx->plan);
-  for (int i = 0; i < 2; i++)
+  for (int i = 0; i < 3; i++)
     if (ctx->slot[i]) (void)hipFree(ctx->slot[i]);
+  if (ctx->text_plan && ctx->text_plan_free) ctx->text_plan_free(ctx->text_plan);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
   for (hipEvent_t ev : ctx->ev_pool)

@@ -57,8 +57,8 @@ struct ksh_ctx {
 
   // persistent device buffers that must survive between two calls
   // (decode plan -> write, encode plan -> write)
-  char* slot[2] = {nullptr, nullptr};
-  size_t slot_bytes[2] = {0, 0};
+  char* slot[3] = {nullptr, nullptr, nullptr};
+  size_t slot_bytes[3] = {0, 0, 0};
 
   // decode plan state
   int64_t dec_words = 0, dec_groups = 0, dec_kmers = 0;
@@ -66,6 +66,10 @@ struct ksh_ctx {
 
   // encode plan state (ksh_encode.hip)
   void* enc_state = nullptr;
+
+  // text -> SPSS plan state (ksh_text.hip)
+  void* text_plan = nullptr;
+  void (*text_plan_free)(void*) = nullptr;
 
   // pair plan (ksh_pair_plan -> ksh_pair_write)
   char* plan = nullptr;
@@ -105,7 +109,7 @@ inline void arena_reset(ksh_ctx* ctx) { ctx->arena_used = 0; }
 // Returns nullptr when the arena is too small (callers reserve first).
 void* arena_alloc(ksh_ctx* ctx, size_t bytes);
 int plan_reserve(ksh_ctx* ctx, size_t bytes);
-enum { kSlotDecode = 0, kSlotEncode = 1 };
+enum { kSlotDecode = 0, kSlotEncode = 1, kSlotText = 2 };
 int slot_reserve(ksh_ctx* ctx, int which, size_t bytes);
 int pool_alloc(ksh_ctx* ctx, size_t bytes, void** out);
 void pool_free(ksh_ctx* ctx, void* p);

@@ -101,6 +101,9 @@ def lib():
         "ksh_spss_decode_plan": (C.c_int, [vp, GP, C.POINTER(SpssView), C.c_int, vp, C.POINTER(i64)]),
         "ksh_spss_decode_write": (C.c_int, [vp, GP, C.POINTER(SpssView), C.c_int, vp, vp,
                                             C.POINTER(i64)]),
+        "ksh_spss_to_text": (C.c_int, [vp, GP, C.POINTER(SpssView), vp]),
+        "ksh_spss_from_text_plan": (C.c_int, [vp, GP, vp, i64, C.POINTER(i64), C.POINTER(i64)]),
+        "ksh_spss_from_text_write": (C.c_int, [vp, vp, vp]),
         "ksh_spss_encode_plan": (C.c_int, [vp, GP, SP, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]),
         "ksh_spss_encode_write": (C.c_int, [vp, vp, vp]),
         "ksh_spss_encode_stats": (C.c_int, [vp, C.POINTER(i64)]),
@@ -357,6 +360,28 @@ class Context:
                                           out.offsets.data_ptr(), out.keys.data_ptr(), C.byref(n)))
         out.n_keys = n.value
         return out
+
+    # KmerSetCompact::Dump / Load text (one string per line) ------------------------------
+    def spss_to_text(self, sp):
+        """The bytes KmerSetCompact::Dump writes, as a uint8 tensor on the device."""
+        import torch
+
+        text = torch.empty(sp.n_bases + sp.n_strings, dtype=torch.uint8, device=self.device)
+        v = sp.view()
+        check(lib().ksh_spss_to_text(self.h, C.byref(sp.g), C.byref(v), text.data_ptr() if text.numel() else None))
+        return text
+
+    def spss_from_text(self, g, text):
+        """uint8 tensor (device) holding lines over ACGT -> DeviceSpss."""
+        import torch
+
+        n_strings, n_bases = C.c_int64(), C.c_int64()
+        check(lib().ksh_spss_from_text_plan(self.h, C.byref(g), text.data_ptr() if text.numel() else None,
+                                            text.numel(), C.byref(n_strings), C.byref(n_bases)))
+        words = torch.empty(max((n_bases.value + 31) // 32, 1), dtype=torch.int64, device=self.device)
+        lens = torch.empty(max(n_strings.value, 1), dtype=torch.int32, device=self.device)
+        check(lib().ksh_spss_from_text_write(self.h, words.data_ptr(), lens.data_ptr()))
+        return DeviceSpss(g, words, lens, n_strings.value, n_bases.value)
 
     # KmerSetCompact::FromKmerSet / GetUnitigsCanonical ---------------------------------------
     def spss_encode(self, s, mode=0, canonical=True):

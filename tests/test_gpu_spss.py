@@ -218,3 +218,72 @@ def test_decode_oversize_buckets(ctx, geom):
     # and the encoder on such a set (probes through big buckets)
     d = dev_set(ctx, k, n, oset.kmers())
     assert ctx.spss_encode(d, mode=0).to_strings() == oset.spss()
+
+
+# ------------------------------------------------------------------------------ text form
+def _text_of(strings):
+    return "".join(x + "\n" for x in strings).encode()
+
+
+def _roundtrip_text(ctx, g, strings):
+    import torch
+
+    sp = capi.DeviceSpss.from_strings(g, strings, ctx.device)
+    text = ctx.spss_to_text(sp)
+    want = _text_of(strings)
+    assert bytes(text.cpu().numpy().tobytes()) == want
+    for raw in (want, want[:-1] if want else want):          # with and without the final newline
+        t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(ctx.device) if raw else \
+            torch.zeros(0, dtype=torch.uint8, device=ctx.device)
+        back = ctx.spss_from_text(g, t)
+        assert back.n_strings == len(strings) and back.n_bases == sum(len(x) for x in strings)
+        assert back.to_strings() == strings
+        n_words = (back.n_bases + 31) // 32
+        assert bool(torch.equal(back.words[:n_words], sp.words[:n_words]))
+        assert bool(torch.equal(back.lens[: back.n_strings], sp.lens[: sp.n_strings]))
+
+
+def test_text_form_small(ctx):
+    """KmerSetCompact::Dump / Load text (kmer_set_compact.h:62-87): exact bytes both ways."""
+    g = capi.geom(5, 3)
+    _roundtrip_text(ctx, g, [])
+    _roundtrip_text(ctx, g, ["ACGTA"])
+    _roundtrip_text(ctx, g, ["ATGCTAACGGTT"])                                  # reference known answer
+    _roundtrip_text(ctx, g, ["ACGTA", "CCCCCC", "GATTACAGATTACAGATTACA", "TTTTT"])
+    rng = np.random.default_rng(5)
+    for n in (31, 32, 33, 63, 64, 65, 500):                                   # word / chunk edges
+        strings = ["".join("ACGT"[c] for c in rng.integers(0, 4, size=int(m)))
+                   for m in rng.integers(5, 40, size=n)]
+        _roundtrip_text(ctx, g, strings)
+    # one string longer than a workgroup's span, then many strings of exactly K bases
+    long_one = "".join("ACGT"[c] for c in rng.integers(0, 4, size=40000))
+    _roundtrip_text(ctx, g, ["ACGTA", long_one, "GGGGG"])
+    _roundtrip_text(ctx, g, ["".join("ACGT"[c] for c in rng.integers(0, 4, size=5)) for _ in range(9000)])
+
+
+def test_text_form_of_an_encoded_set(ctx):
+    """Dump text of a device-encoded SPSS == the oracle's strings joined by newlines, and the
+    text loads back to the same set."""
+    import torch
+
+    k, n, kb = 23, 14, 4
+    kmers = synth.phylogeny_sets(k, 1, 300000, seed=12)[0]
+    oset = ol.Set.from_kmers(k, n, kb, kmers)
+    d = dev_set(ctx, k, n, kmers)
+    sp = ctx.spss_encode(d, mode=0)
+    text = ctx.spss_to_text(sp)
+    assert bytes(text.cpu().numpy().tobytes()) == _text_of(oset.spss())
+    back = ctx.spss_from_text(sp.g, text)
+    assert back.n_strings == sp.n_strings and back.n_bases == sp.n_bases
+    assert ctx.set_diff(ctx.spss_decode(back), d) == 0
+
+
+def test_text_form_rejects_bad_input(ctx):
+    import torch
+
+    g = capi.geom(5, 3)
+    for raw in (b"ACGTN\n", b"ACGTA\r\n", b"ACG\n", b"ACGTA\n\nACGTA\n", b"acgta\n"):
+        t = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(ctx.device)
+        with pytest.raises(capi.KshError) as e:
+            ctx.spss_from_text(g, t)
+        assert e.value.code == 3

@@ -191,6 +191,27 @@ int ksh_spss_from_text_plan(ksh_ctx* ctx, const ksh_geom* g, const char* d_text,
                             int64_t* n_strings, int64_t* n_bases);
 int ksh_spss_from_text_write(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens);
 
+/* ---- KmerCounter: FASTA -> counted k-mers -> KmerSet (the step before the loop) ---------------
+ * lib/core/kmer_counter.h:136-206 FromFASTA (lines 0, 2, ... are headers starting with '>',
+ * lines 1, 3, ... reads over ACGTN), :64-133 FromReads (reads split at 'N', every K-long window
+ * is one k-mer, canonical or not), :209-243 ToKmerSet (k-mers seen at least `cutoff` times; the
+ * second result counts the distinct k-mers seen less often).
+ * ksh_fasta_plan / ksh_fasta_write turn n_bytes of FASTA text in device memory into the reads'
+ * ACGT fragments of length >= K as an SPSS-shaped 2-bit stream (ksh_spss_view layout; the
+ * caller allocates ceil(n_bases / 32) words and n_fragments lengths between the two calls).
+ * An odd number of lines, a header that is empty or does not start with '>', or a read byte
+ * outside ACGTN is KSH_FAILED_PRECONDITION with the reference's message.
+ * Counting is the decode pipeline with multiplicities: ksh_spss_decode_plan on the fragments
+ * (*n_keys = k-mer occurrences, the size of the key buffer), then ksh_kmer_count_write:
+ * offsets + sorted keys of the k-mers whose count >= cutoff, *n_keys of them, *n_cut distinct
+ * k-mers below the cutoff (cutoff in 0..255: uint8 counts saturate in the reference). */
+int ksh_fasta_plan(ksh_ctx* ctx, const ksh_geom* g, const char* d_text, int64_t n_bytes,
+                   int64_t* n_fragments, int64_t* n_bases);
+int ksh_fasta_write(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens);
+int ksh_kmer_count_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* reads, int canonical,
+                         int32_t cutoff, int64_t* d_offsets, void* d_keys, int64_t* n_keys,
+                         int64_t* n_cut);
+
 /* ---- StreamVByte "0124" pack of the string lengths ---------------------------------------
  * The in-memory form of KmerSetCompact::lengths_compressed_
  * (lib/core/kmer_set_compact.h:257-265 streamvbyte_encode_0124, :269-287 decode; format in

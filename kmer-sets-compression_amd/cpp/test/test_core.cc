@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "core/kmer.h"
+#include "core/kmer_counter.h"
 #include "core/kmer_set.h"
 #include "core/kmer_set_compact.h"
 #include "core/kmer_set_set.h"
@@ -185,6 +186,62 @@ static void TestSpss() {
   }
 }
 
+// ---- test/kmer_counter.cc ----------------------------------------------------------------------
+static void TestCounter() {
+  const int K = 5, N = 3;
+  using KeyType = std::uint8_t;
+  using Counter = KmerCounter<K, N, KeyType, std::uint8_t>;
+  {  // AddAndGet
+    Counter c;
+    c.Add(Kmer<K>("AAAAA"), 1);
+    c.Add(Kmer<K>("CCCCC"), 2);
+    c.Add(Kmer<K>("TTTTT"), 3);
+    c.Add(Kmer<K>("AAAAA"), 1);
+    EXPECT_EQ(int(c.Get(Kmer<K>("AAAAA"))), 2);
+    EXPECT_EQ(int(c.Get(Kmer<K>("CCCCC"))), 2);
+    EXPECT_EQ(int(c.Get(Kmer<K>("TTTTT"))), 3);
+    EXPECT_EQ(int(c.Get(Kmer<K>("GGGGG"))), 0);
+    EXPECT_EQ(c.Size(), 3);
+  }
+  {  // ToKmerSet
+    Counter c;
+    c.Add(Kmer<K>("AAAAA"), 3);
+    c.Add(Kmer<K>("CCCCC"), 1);
+    c.Add(Kmer<K>("GGGGG"), 2);
+    c.Add(Kmer<K>("TTTTT"), 4);
+    auto r = c.ToKmerSet(3, 1);
+    EXPECT_EQ(r.second, 2);
+    EXPECT_EQ(r.first.Size(), 2);
+    EXPECT_TRUE(r.first.Contains(Kmer<K>("AAAAA")));
+    EXPECT_TRUE(r.first.Contains(Kmer<K>("TTTTT")));
+  }
+  {  // FromReads
+    const Counter c = Counter::FromReads({"AACCGTT", "AACCGTA"}, false, 1);
+    EXPECT_EQ(int(c.Get(Kmer<K>("AACCG"))), 2);
+    EXPECT_EQ(int(c.Get(Kmer<K>("ACCGT"))), 2);
+    EXPECT_EQ(int(c.Get(Kmer<K>("CCGTT"))), 1);
+    EXPECT_EQ(int(c.Get(Kmer<K>("CCGTA"))), 1);
+  }
+  {  // FromFASTA: a file, the same through a pipe, and the reference's two failure modes
+    const std::string file = (std::filesystem::temp_directory_path() / "ksc_test_reads.fa").string();
+    const std::string text = ">r1\nAACCGTTNNAACCGTA\n>r2\nACGTNACGTACGT\n";
+    EXPECT_TRUE(ksc::WriteBytes(file, "", text.data(), text.size()).ok());
+    auto c = Counter::FromFASTA(file, "", false, 4);
+    EXPECT_TRUE(c.ok());
+    EXPECT_EQ(int(c.value().Get(Kmer<K>("AACCG"))), 2);
+    EXPECT_EQ(int(c.value().Get(Kmer<K>("GTTAA"))), 0);
+    auto piped = Counter::FromFASTA(file, "cat", true, 4);
+    EXPECT_TRUE(piped.ok());
+    EXPECT_TRUE(piped.value().Size() <= c.value().Size());
+    auto odd = Counter::FromFASTA(std::vector<std::string>{">r1", "ACGTA", ">r2"}, true, 1);
+    EXPECT_TRUE(!odd.ok());
+    EXPECT_TRUE(odd.status().message() == "FASTA files should have an even number of lines");
+    auto bad = Counter::FromFASTA(std::vector<std::string>{"r1", "ACGTA"}, true, 1);
+    EXPECT_TRUE(!bad.ok());
+    EXPECT_TRUE(bad.status().message() == "invalid FASTA file");
+  }
+}
+
 // ---- test/kmer_set_compact.cc -----------------------------------------------------------------------
 static void TestCompact() {
   const int K = 9, N = 10;
@@ -274,6 +331,7 @@ int main() {
     TestKmerSet();
     TestSpss();
     TestCompact();
+    TestCounter();
     TestSetSet<15, 14, std::uint16_t>(8, 20000);
     TestSetSet<23, 14, std::uint32_t>(6, 30000);
     TestSetSet<31, 14, std::uint64_t>(4, 20000);

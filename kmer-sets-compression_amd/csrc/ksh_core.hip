@@ -480,6 +480,7 @@ int ksh_ctx_destroy(ksh_ctx* ctx) {
   for (int i = 0; i < 3; i++)
     if (ctx->slot[i]) (void)hipFree(ctx->slot[i]);
   if (ctx->text_plan && ctx->text_plan_free) ctx->text_plan_free(ctx->text_plan);
+  if (ctx->fasta_plan && ctx->fasta_plan_free) ctx->fasta_plan_free(ctx->fasta_plan);
   if (ctx->h_pinned) (void)hipHostFree(ctx->h_pinned);
   if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
   for (hipEvent_t ev : ctx->ev_pool)

@@ -141,6 +141,7 @@ __global__ __launch_bounds__(256) void k_hist_columns(uint32_t* __restrict__ his
 struct SortLds {
   uint32_t sub_cnt[(1 << kMaxSubBits) + 1];
   int wave_cnt[4];
+  int wave_below[4];
   int overflow;
   int kept;
 };
@@ -245,29 +246,58 @@ __device__ void block_sort_into_lds(const KeyT* __restrict__ src, int cnt, int e
   }
 }
 
-// Writes the distinct keys of the sorted lds[0, cnt) to dst; returns how many (block-uniform).
+// Writes the distinct keys of the sorted lds[0, cnt) that occur at least `cutoff` times to dst
+// and returns how many (block-uniform); *below (thread 0 adds to it) counts the distinct keys
+// that occur less often.  cutoff == 1 is plain duplicate removal (KmerSet semantics); larger
+// cutoffs are KmerCounter::ToKmerSet (lib/core/kmer_counter.h:209-243; its saturating uint8
+// counts compare like the exact ones for every cutoff a uint8 can hold).
 template <typename KeyT>
 __device__ int block_unique_write(const KeyT* __restrict__ lds, int cnt, KeyT* __restrict__ dst,
-                                  SortLds* __restrict__ sh) {
+                                  SortLds* __restrict__ sh, int cutoff, int64_t* below) {
   const int per = (cnt + 255) / 256;
   const int c0 = min(int(threadIdx.x) * per, cnt), c1 = min(c0 + per, cnt);
-  int mine = 0;
-  for (int i = c0; i < c1; i++) mine += (i == 0 || lds[i] != lds[i - 1]);
+  int mine = 0, mine_below = 0;
+  for (int i = c0; i < c1; i++) {
+    if (i == 0 || lds[i] != lds[i - 1]) {
+      bool keep = true;
+      if (cutoff > 1) {
+        int run = 1;
+        while (run < cutoff && i + run < cnt && lds[i + run] == lds[i]) run++;
+        keep = run >= cutoff;
+      }
+      mine += keep;
+      mine_below += !keep;
+    }
+  }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int inc = mine;
+  int inc = mine, inc_below = mine_below;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     const int o = __shfl_up(inc, d, 64);
     if (lane >= d) inc += o;
   }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) inc_below += __shfl_xor(inc_below, d, 64);
   __syncthreads();  // wave_cnt may still be read by the scan of a previous call
   if (lane == 63) sh->wave_cnt[wave] = inc;
+  if (lane == 0) sh->wave_below[wave] = inc_below;
   __syncthreads();
   int at = inc - mine;
   for (int w = 0; w < wave; w++) at += sh->wave_cnt[w];
   const int total = sh->wave_cnt[0] + sh->wave_cnt[1] + sh->wave_cnt[2] + sh->wave_cnt[3];
-  for (int i = c0; i < c1; i++)
-    if (i == 0 || lds[i] != lds[i - 1]) dst[at++] = lds[i];
+  if (threadIdx.x == 0 && below)
+    *below += sh->wave_below[0] + sh->wave_below[1] + sh->wave_below[2] + sh->wave_below[3];
+  for (int i = c0; i < c1; i++) {
+    if (i == 0 || lds[i] != lds[i - 1]) {
+      bool keep = true;
+      if (cutoff > 1) {
+        int run = 1;
+        while (run < cutoff && i + run < cnt && lds[i + run] == lds[i]) run++;
+        keep = run >= cutoff;
+      }
+      if (keep) dst[at++] = lds[i];
+    }
+  }
   __syncthreads();
   return total;
 }
@@ -280,7 +310,8 @@ template <typename KeyT>
 __global__ __launch_bounds__(256) void k_bucket_sort(const int64_t* __restrict__ offsets,
                                                       KeyT* __restrict__ keys,
                                                       KeyT* __restrict__ scratch,
-                                                      int64_t* __restrict__ uniq, int key_bits) {
+                                                      int64_t* __restrict__ uniq, int key_bits,
+                                                      int cutoff, int64_t* __restrict__ below) {
   extern __shared__ unsigned char lds_raw[];
   __shared__ SortLds sh;
   __shared__ uint32_t part_end[(1 << kMaxSubBits) + 1];
@@ -290,14 +321,21 @@ __global__ __launch_bounds__(256) void k_bucket_sort(const int64_t* __restrict__
   const int64_t lo = offsets[b], hi = offsets[b + 1];
   const int64_t cnt64 = hi - lo;
   if (cnt64 == 0) {
-    if (threadIdx.x == 0) uniq[b] = 0;
+    if (threadIdx.x == 0) {
+      uniq[b] = 0;
+      if (below) below[b] = 0;
+    }
     return;
   }
   KeyT* g = keys + lo;
+  int64_t n_below = 0;  // thread 0's copy is the bucket's count
   if (cnt64 <= kCap) {
     block_sort_into_lds(g, int(cnt64), key_bits, lds, &sh);
-    const int kept = block_unique_write(lds, int(cnt64), g, &sh);
-    if (threadIdx.x == 0) uniq[b] = kept;
+    const int kept = block_unique_write(lds, int(cnt64), g, &sh, cutoff, &n_below);
+    if (threadIdx.x == 0) {
+      uniq[b] = kept;
+      if (below) below[b] = n_below;
+    }
     return;
   }
   // ---- oversize bucket: partition by the top `bits` key bits so that a part holds about
@@ -336,7 +374,7 @@ __global__ __launch_bounds__(256) void k_bucket_sort(const int64_t* __restrict__
     if (pc == 0) continue;
     if (pc <= kCap) {
       block_sort_into_lds(tmp + s0, int(pc), shift, lds, &sh);
-      out += block_unique_write(lds, int(pc), g + out, &sh);
+      out += block_unique_write(lds, int(pc), g + out, &sh, cutoff, &n_below);
     } else {
       // a part that still does not fit (heavily skewed keys): bitonic network in global memory
       KeyT* buf = tmp + s0;
@@ -373,8 +411,13 @@ __global__ __launch_bounds__(256) void k_bucket_sort(const int64_t* __restrict__
       }
       if (threadIdx.x == 0) {
         int64_t at = out;
-        for (int64_t i = 0; i < pc; i++)
-          if (i == 0 || buf[i] != buf[i - 1]) g[at++] = buf[i];
+        for (int64_t i = 0; i < pc;) {
+          int64_t run = 1;
+          while (i + run < pc && buf[i + run] == buf[i]) run++;
+          if (run >= cutoff) g[at++] = buf[i];
+          else n_below++;
+          i += run;
+        }
         sh.kept = int(at - out);
       }
       __syncthreads();
@@ -382,7 +425,10 @@ __global__ __launch_bounds__(256) void k_bucket_sort(const int64_t* __restrict__
       __syncthreads();
     }
   }
-  if (threadIdx.x == 0) uniq[b] = out;
+  if (threadIdx.x == 0) {
+    uniq[b] = out;
+    if (below) below[b] = n_below;
+  }
 }
 
 template <typename KeyT>
@@ -491,10 +537,11 @@ int decode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int c
 
 template <typename KeyT>
 int decode_write_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int canonical_flag,
-                   int64_t* d_offsets, void* d_keys, int64_t* n_keys) {
+                   int64_t* d_offsets, void* d_keys, int64_t* n_keys, int cutoff, int64_t* n_below) {
   const int64_t nb = n_buckets(g);
   if (ctx->dec_src != s->d_words)
     return fail(KSH_FAILED_PRECONDITION, "ksh_spss_decode_write without a matching decode_plan");
+  if (n_below) *n_below = 0;
   if (ctx->dec_kmers == 0) {
     *n_keys = 0;
     return KSH_OK;
@@ -525,18 +572,23 @@ int decode_write_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int 
       scratch = static_cast<KeyT*>(ptr);
     }
   }
+  arena_reset(ctx);
+  KSH_TRY(arena_reserve(ctx, 2 * a256(size_t(nb + 1) * 8) + (1u << 16)));
+  int64_t* new_off = static_cast<int64_t*>(arena_alloc(ctx, size_t(nb + 1) * 8));
+  int64_t* below = static_cast<int64_t*>(arena_alloc(ctx, size_t(nb + 1) * 8));
+  if (!new_off || !below) return fail(KSH_INTERNAL, "scratch arena too small");
   hipLaunchKernelGGL((k_bucket_sort<KeyT>), dim3(unsigned(nb)), dim3(256), kSortLdsBytes, ctx->stream,
-                     d_offsets, keys, scratch, st.totals, key_bits(g));
+                     d_offsets, keys, scratch, st.totals, key_bits(g), cutoff, n_below ? below : nullptr);
   if (scratch) pool_free(ctx, scratch);
   KSH_HIP(hipGetLastError());
-  arena_reset(ctx);
-  KSH_TRY(arena_reserve(ctx, a256(size_t(nb + 1) * 8) + (1u << 16)));
-  int64_t* new_off = static_cast<int64_t*>(arena_alloc(ctx, size_t(nb + 1) * 8));
-  if (!new_off) return fail(KSH_INTERNAL, "scratch arena too small");
   KSH_TRY(scan_exclusive_i64(ctx, st.totals, new_off, nb, new_off + nb));
+  if (n_below) KSH_TRY(scan_exclusive_i64(ctx, below, below, nb, below + nb));
   KSH_HIP(hipMemcpyAsync(ctx->h_pinned, new_off + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+  if (n_below)
+    KSH_HIP(hipMemcpyAsync(ctx->h_pinned + 1, below + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
   KSH_HIP(hipStreamSynchronize(ctx->stream));
   const int64_t kept = ctx->h_pinned[0];
+  if (n_below) *n_below = ctx->h_pinned[1];
   if (kept != ctx->dec_kmers) {
     // repeated k-mers in the input: close the gaps (rare; through a temporary copy)
     void* tmp = nullptr;
@@ -602,8 +654,27 @@ int ksh_spss_decode_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* 
   if (ctx->dec_kmers > 0 && !d_keys) return fail(KSH_INVALID_ARGUMENT, "d_keys is NULL");
   KSH_HIP(hipSetDevice(ctx->device));
   return g->key_bytes == 4
-             ? decode_write_t<uint32_t>(ctx, g, s, canonical_flag, d_offsets, d_keys, n_keys)
-             : decode_write_t<uint64_t>(ctx, g, s, canonical_flag, d_offsets, d_keys, n_keys);
+             ? decode_write_t<uint32_t>(ctx, g, s, canonical_flag, d_offsets, d_keys, n_keys, 1, nullptr)
+             : decode_write_t<uint64_t>(ctx, g, s, canonical_flag, d_offsets, d_keys, n_keys, 1, nullptr);
+}
+
+/* KmerCounter::FromReads + ToKmerSet (lib/core/kmer_counter.h:64-133,209-243): the k-mers of
+ * the strings of `reads` counted with multiplicity, those seen at least `cutoff` times kept.
+ * Same two calls as the decode (ksh_spss_decode_plan sizes the key buffer: one slot per k-mer
+ * occurrence). */
+int ksh_kmer_count_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* reads, int canonical_flag,
+                         int32_t cutoff, int64_t* d_offsets, void* d_keys, int64_t* n_keys,
+                         int64_t* n_cut) {
+  if (!ctx || !d_offsets || !n_keys || !n_cut) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  KSH_TRY(check_geom(g));
+  KSH_TRY(check_spss(reads));
+  if (cutoff < 0 || cutoff > 255) return fail(KSH_INVALID_ARGUMENT, "cutoff must be in 0..255 (uint8 counts)");
+  if (cutoff < 1) cutoff = 1;  // "count < 0" never holds: a cutoff of 0 keeps every k-mer, like 1
+  if (ctx->dec_kmers > 0 && !d_keys) return fail(KSH_INVALID_ARGUMENT, "d_keys is NULL");
+  KSH_HIP(hipSetDevice(ctx->device));
+  return g->key_bytes == 4
+             ? decode_write_t<uint32_t>(ctx, g, reads, canonical_flag, d_offsets, d_keys, n_keys, cutoff, n_cut)
+             : decode_write_t<uint64_t>(ctx, g, reads, canonical_flag, d_offsets, d_keys, n_keys, cutoff, n_cut);
 }
 
 }  // extern "C"

@@ -67,9 +67,13 @@ struct ksh_ctx {
   // encode plan state (ksh_encode.hip)
   void* enc_state = nullptr;
 
-  // text -> SPSS plan state (ksh_text.hip)
+  // text -> SPSS plan state (ksh_text.hip), FASTA -> fragments plan state (ksh_fasta.hip);
+  // both use slot kSlotText, so a plan of one kind invalidates a pending plan of the other
   void* text_plan = nullptr;
   void (*text_plan_free)(void*) = nullptr;
+  void* fasta_plan = nullptr;
+  void (*fasta_plan_free)(void*) = nullptr;
+  int text_slot_owner = 0;  // 1: the text plan's arrays are in the slot, 2: the FASTA plan's
 
   // pair plan (ksh_pair_plan -> ksh_pair_write)
   char* plan = nullptr;

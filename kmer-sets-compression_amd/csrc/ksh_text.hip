@@ -264,6 +264,7 @@ int ksh_spss_from_text_plan(ksh_ctx* ctx, const ksh_geom* g, const char* d_text,
   hipStream_t st = ctx->stream;
   // nl_before lives in the text slot: it is needed again by ksh_spss_from_text_write
   KSH_TRY(slot_reserve(ctx, kSlotText, a256(size_t(n_chunks + 1) * 8)));
+  ctx->text_slot_owner = 1;
   p->nl_before = reinterpret_cast<int64_t*>(ctx->slot[kSlotText]);
   KSH_HIP(hipMemsetAsync(flags, 0, sizeof(int), st));
   hipLaunchKernelGGL(k_text_count_nl, dim3(blocks_of(n_chunks, 256)), dim3(256), 0, st, p->text, n_bytes,
@@ -287,7 +288,7 @@ int ksh_spss_from_text_plan(ksh_ctx* ctx, const ksh_geom* g, const char* d_text,
 int ksh_spss_from_text_write(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens) {
   if (!ctx) return fail(KSH_INVALID_ARGUMENT, "ctx is NULL");
   TextPlan* p = static_cast<TextPlan*>(ctx->text_plan);
-  if (!p || (p->n_bytes > 0 && !p->nl_before))
+  if (!p || (p->n_bytes > 0 && (!p->nl_before || ctx->text_slot_owner != 1)))
     return fail(KSH_FAILED_PRECONDITION, "ksh_spss_from_text_write without ksh_spss_from_text_plan");
   if (p->n_lines == 0) return KSH_OK;
   if (!d_words || !d_lens) return fail(KSH_INVALID_ARGUMENT, "NULL output buffer");

@@ -101,6 +101,10 @@ def lib():
         "ksh_spss_decode_plan": (C.c_int, [vp, GP, C.POINTER(SpssView), C.c_int, vp, C.POINTER(i64)]),
         "ksh_spss_decode_write": (C.c_int, [vp, GP, C.POINTER(SpssView), C.c_int, vp, vp,
                                             C.POINTER(i64)]),
+        "ksh_fasta_plan": (C.c_int, [vp, GP, vp, i64, C.POINTER(i64), C.POINTER(i64)]),
+        "ksh_fasta_write": (C.c_int, [vp, vp, vp]),
+        "ksh_kmer_count_write": (C.c_int, [vp, GP, C.POINTER(SpssView), C.c_int, i32, vp, vp, C.POINTER(i64),
+                                           C.POINTER(i64)]),
         "ksh_spss_to_text": (C.c_int, [vp, GP, C.POINTER(SpssView), vp]),
         "ksh_spss_from_text_plan": (C.c_int, [vp, GP, vp, i64, C.POINTER(i64), C.POINTER(i64)]),
         "ksh_spss_from_text_write": (C.c_int, [vp, vp, vp]),
@@ -360,6 +364,38 @@ class Context:
                                           out.offsets.data_ptr(), out.keys.data_ptr(), C.byref(n)))
         out.n_keys = n.value
         return out
+
+    # KmerCounter::FromFASTA / FromReads / ToKmerSet -------------------------------------------
+    def fasta_fragments(self, g, text):
+        """uint8 tensor (device) holding FASTA text -> DeviceSpss of the reads' ACGT fragments
+        of length >= K (what the counter counts k-mers of)."""
+        import torch
+
+        n_frag, n_bases = C.c_int64(), C.c_int64()
+        check(lib().ksh_fasta_plan(self.h, C.byref(g), text.data_ptr() if text.numel() else None,
+                                   text.numel(), C.byref(n_frag), C.byref(n_bases)))
+        words = torch.zeros(max((n_bases.value + 31) // 32, 1), dtype=torch.int64, device=self.device)
+        lens = torch.zeros(max(n_frag.value, 1), dtype=torch.int32, device=self.device)
+        check(lib().ksh_fasta_write(self.h, words.data_ptr(), lens.data_ptr()))
+        return DeviceSpss(g, words, lens, n_frag.value, n_bases.value)
+
+    def kmer_count(self, reads, cutoff, canonical=True):
+        """(KmerSet of the k-mers seen >= cutoff times in the fragments, number of distinct
+        k-mers below the cutoff)."""
+        import torch
+
+        g = reads.g
+        out = DeviceSet.empty_like_offsets(g, 0, self.device)
+        n, n_cut = C.c_int64(), C.c_int64()
+        v = reads.view()
+        check(lib().ksh_spss_decode_plan(self.h, C.byref(g), C.byref(v), int(canonical),
+                                         out.offsets.data_ptr(), C.byref(n)))
+        out.keys = torch.empty(max(n.value * g.key_bytes, 16), dtype=torch.uint8, device=self.device)
+        check(lib().ksh_kmer_count_write(self.h, C.byref(g), C.byref(v), int(canonical), int(cutoff),
+                                         out.offsets.data_ptr(), out.keys.data_ptr(), C.byref(n),
+                                         C.byref(n_cut)))
+        out.n_keys = n.value
+        return out, n_cut.value
 
     # KmerSetCompact::Dump / Load text (one string per line) ------------------------------
     def spss_to_text(self, sp):

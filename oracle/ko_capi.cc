@@ -14,6 +14,7 @@
 #include "ko_compact.h"
 #include "ko_dsu.h"
 #include "ko_kmer.h"
+#include "ko_kmer_counter.h"
 #include "ko_kmer_set.h"
 #include "ko_kmer_set_set.h"
 #include "ko_spss.h"
@@ -453,6 +454,37 @@ void* ko_kss_load(const char* dir, const char* ext, int k, int n, int key_bytes,
     return nullptr;
   }
   return h;
+}
+
+
+// ---- k-mer counter (lib/core/kmer_counter.h) ---------------------------------------------------
+void* ko_counter_new(int k, int n, int key_bytes) { return new ko::KmerCounter(ko::Geom{k, n, key_bytes}); }
+void ko_counter_free(void* c) { delete static_cast<ko::KmerCounter*>(c); }
+void ko_counter_add(void* c, std::uint64_t kmer, int v) {
+  static_cast<ko::KmerCounter*>(c)->add(kmer, static_cast<std::uint8_t>(v));
+}
+int ko_counter_get(void* c, std::uint64_t kmer) { return static_cast<ko::KmerCounter*>(c)->get(kmer); }
+std::int64_t ko_counter_size(void* c) { return static_cast<ko::KmerCounter*>(c)->size(); }
+// FromFASTA on a whole file's bytes: 0 ok, 1 odd number of lines, 2 invalid FASTA file.
+int ko_counter_from_fasta(void* c, const char* text, std::int64_t n, int canonical) {
+  const std::vector<std::string> lines = ko::split_lines(std::string(text, static_cast<std::size_t>(n)));
+  return static_cast<ko::KmerCounter*>(c)->from_fasta_lines(lines, canonical != 0);
+}
+// FromReads on '\n'-separated reads.
+void ko_counter_from_reads(void* c, const char* text, std::int64_t n, int canonical) {
+  static_cast<ko::KmerCounter*>(c)->from_reads(ko::split_lines(std::string(text, static_cast<std::size_t>(n))),
+                                               canonical != 0);
+}
+void* ko_counter_to_set(void* c, int key_bytes, int cutoff, std::int64_t* cutoff_count) {
+  ko::KmerCounter* k = static_cast<ko::KmerCounter*>(c);
+  if (key_bytes > 4) {
+    auto r = k->to_kmer_set<std::uint64_t>(cutoff);
+    *cutoff_count = r.second;
+    return wrap_set(std::move(r.first));
+  }
+  auto r = k->to_kmer_set<std::uint32_t>(cutoff);
+  *cutoff_count = r.second;
+  return wrap_set(std::move(r.first));
 }
 
 }  // extern "C"

@@ -101,6 +101,14 @@ def lib():
         "ko_compact_sampled": (None, [vp, i32p, i, i, i64p, C.c_void_p]),
         "ko_compact_dump": (i, [vp, C.c_char_p]),
         "ko_compact_load": (vp, [C.c_char_p, i, i, i]),
+        "ko_counter_new": (vp, [i, i, i]),
+        "ko_counter_free": (None, [vp]),
+        "ko_counter_add": (None, [vp, u64, i]),
+        "ko_counter_get": (i, [vp, u64]),
+        "ko_counter_size": (i64, [vp]),
+        "ko_counter_from_fasta": (i, [vp, C.c_char_p, i64, i]),
+        "ko_counter_from_reads": (None, [vp, C.c_char_p, i64, i]),
+        "ko_counter_to_set": (vp, [vp, i, i, C.POINTER(i64)]),
         "ko_kss_build": (vp, [C.POINTER(vp), i, i32p, i, i, i]),
         "ko_kss_free": (None, [vp]),
         "ko_kss_size": (i, [vp]),
@@ -242,6 +250,43 @@ class Set:
     def __del__(self):
         if getattr(self, "h", None):
             lib().ko_set_free(self.h)
+            self.h = None
+
+
+class Counter:
+    """KmerCounter<K, N, KeyType, uint8_t> (lib/core/kmer_counter.h)."""
+
+    def __init__(self, k, n, key_bytes):
+        self.k, self.n, self.key_bytes = k, n, key_bytes
+        self.h = lib().ko_counter_new(k, n, key_bytes)
+
+    def add(self, kmer_bits, v):
+        lib().ko_counter_add(self.h, int(kmer_bits), int(v))
+
+    def get(self, kmer_bits):
+        return lib().ko_counter_get(self.h, int(kmer_bits))
+
+    def size(self):
+        return lib().ko_counter_size(self.h)
+
+    def from_fasta(self, text, canonical=True):
+        """0 ok, 1 = odd number of lines, 2 = invalid FASTA file."""
+        return lib().ko_counter_from_fasta(self.h, text, len(text), int(canonical))
+
+    def from_reads(self, reads, canonical=True):
+        text = "\n".join(reads).encode()
+        if reads:
+            text += b"\n"
+        lib().ko_counter_from_reads(self.h, text, len(text), int(canonical))
+
+    def to_set(self, cutoff):
+        cut = C.c_int64()
+        s = Set(self.k, self.n, self.key_bytes, lib().ko_counter_to_set(self.h, self.key_bytes, int(cutoff), C.byref(cut)))
+        return s, cut.value
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib().ko_counter_free(self.h)
             self.h = None
 
 

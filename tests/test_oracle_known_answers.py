@@ -350,3 +350,48 @@ def test_range_split_exhaustive():
                 assert np.array_equal(b[1:], e[:-1])
                 sizes = e - b
                 assert sizes.max() - sizes.min() <= 1 and np.all(np.diff(sizes) >= 0)
+
+
+# ---- k-mer counter (the step before the loop): test/kmer_counter.cc ------------------------------
+def test_kmer_counter_known_answers():
+    g = json.load(open(GOLDEN))["kmer_counter"]
+    k, n, kb = 5, 3, 1
+    c = ol.Counter(k, n, kb)
+    c.add(ol.kmer("AAAAA"), g["add_with_max"]["x"])
+    c.add(ol.kmer("AAAAA"), g["add_with_max"]["y"])
+    assert c.get(ol.kmer("AAAAA")) == g["add_with_max"]["want"]
+    c = ol.Counter(k, n, kb)
+    for s, v in g["add_and_get"]["adds"]:
+        c.add(ol.kmer(s), v)
+    for s, want in g["add_and_get"]["want"].items():
+        assert c.get(ol.kmer(s)) == want
+    c = ol.Counter(k, n, kb)
+    for s, v in g["to_kmer_set"]["adds"]:
+        c.add(ol.kmer(s), v)
+    s_, cut = c.to_set(g["to_kmer_set"]["cutoff"])
+    assert cut == g["to_kmer_set"]["want_cutoff_count"]
+    assert sorted(ol.kmer_str(x, k) for x in s_.kmers()) == sorted(g["to_kmer_set"]["want_set"])
+    c = ol.Counter(k, n, kb)
+    c.from_reads(g["from_reads"]["reads"], canonical=g["from_reads"]["canonical"])
+    for s, want in g["from_reads"]["want"].items():
+        assert c.get(ol.kmer(s)) == want
+    assert c.size() == len(g["from_reads"]["want"])
+
+
+def test_kmer_counter_fasta_rules():
+    """FromFASTA's checks (kmer_counter.h:157-190) and the 'N' split (:79)."""
+    k, n, kb = 5, 3, 1
+    ok = b">r1\nAACCGTTNNAACCGTA\n>r2 some text\nACGTNACGTACGT\n"
+    c = ol.Counter(k, n, kb)
+    assert c.from_fasta(ok, canonical=False) == 0
+    assert c.get(ol.kmer("AACCG")) == 2 and c.get(ol.kmer("CCGTA")) == 1
+    assert c.get(ol.kmer("ACGTA")) == 1 and c.get(ol.kmer("ACGTN".replace("N", "A"))) == 1
+    assert c.get(ol.kmer("GTTAA")) == 0                      # windows never cross an N
+    assert ol.Counter(k, n, kb).from_fasta(ok[:-1], canonical=True) == 0      # no final newline
+    assert ol.Counter(k, n, kb).from_fasta(b"", canonical=True) == 0          # no lines at all
+    assert ol.Counter(k, n, kb).from_fasta(b">r1\nACGTA\n>r2\n", canonical=True) == 1
+    assert ol.Counter(k, n, kb).from_fasta(b"r1\nACGTA\n", canonical=True) == 2
+    assert ol.Counter(k, n, kb).from_fasta(b"\nACGTA\n", canonical=True) == 2
+    assert ol.Counter(k, n, kb).from_fasta(b">r1\nACGTa\n", canonical=True) == 2
+    assert ol.Counter(k, n, kb).from_fasta(b">r1\nACGTA\r\n", canonical=True) == 2
+    assert ol.Counter(k, n, kb).from_fasta(b">r1\n\n", canonical=True) == 0   # an empty read is fine

@@ -235,7 +235,8 @@ def main():
 
     if rank == 0:
         # algo_bytes covers every launch of the timed region, write_ms the sampled ones
-        all_launches = args.steps * len(pairs)
+        # one write-pass launch per pair, or one for the whole batch of a step
+        all_launches = args.steps * (len(pairs) if (args.per_pair_sync or args.two_pass) else 1)
         bytes_per_launch = algo_bytes[0] / max(all_launches, 1)
         avg_launch_ms = write_ms / max(write_launches, 1)
         achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if write_ms > 0 else 0.0
@@ -264,6 +265,7 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": "k_tile_merge<KeyT, 1> (write pass)",
+                "pairs_per_launch": 1 if (args.per_pair_sync or args.two_pass) else len(pairs),
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -101,6 +101,36 @@ struct PairSegs {
   }
 };
 
+// One pair of a batch (ksh_pair_algebra_batch): its two sets, where its three results go, and
+// the common-key prefix at its first tile (filled in on the device once the counts are scanned).
+struct BatchPair {
+  const void* a_keys;
+  const int64_t* a_off;
+  const void* b_keys;
+  const int64_t* b_off;
+  int64_t *off_i, *off_amb, *off_bma;
+  void *out_i, *out_amb, *out_bma;
+  int64_t ioff_base;
+};
+
+// One segment per (pair p of the batch, bucket b): s = p * 2^bucket_bits + b.
+template <typename KeyT>
+struct BatchSegs {
+  const BatchPair* pairs;
+  int bucket_bits;
+  __device__ void get(int64_t s, const KeyT*& a, int64_t& a_lo, int64_t& a_hi, const KeyT*& b,
+                      int64_t& b_lo, int64_t& b_hi) const {
+    const BatchPair& p = pairs[s >> bucket_bits];
+    const int64_t bucket = s & ((int64_t(1) << bucket_bits) - 1);
+    a = static_cast<const KeyT*>(p.a_keys);
+    b = static_cast<const KeyT*>(p.b_keys);
+    a_lo = p.a_off[bucket];
+    a_hi = p.a_off[bucket + 1];
+    b_lo = p.b_off[bucket];
+    b_hi = p.b_off[bucket + 1];
+  }
+};
+
 // Everything a tile needs, in one 48-byte record (one dependent load in the merge kernel):
 // the two key arrays and the tile's index ranges [a0, a1) and [b0, b1) in them.
 struct TileDesc {
@@ -344,7 +374,8 @@ __global__ __launch_bounds__(kThreads * kGroupWaves) void k_tile_merge(
     const TileDesc* __restrict__ desc, const int64_t* __restrict__ total_tiles, int64_t max_tiles,
     int tiles_per_wave, int64_t* __restrict__ tile_m, const int64_t* __restrict__ tile_ioff,
     uint16_t* __restrict__ split, KeyT* __restrict__ out_i, KeyT* __restrict__ out_amb,
-    KeyT* __restrict__ out_bma) {
+    KeyT* __restrict__ out_bma, const BatchPair* __restrict__ batch, const TileOwner* __restrict__ owner,
+    int batch_bucket_bits) {
   using Cfg = TileCfg<KeyT>;
   using Stage = TileStage<KeyT>;
   constexpr int kVT = Cfg::kVT;
@@ -469,7 +500,14 @@ __global__ __launch_bounds__(kThreads * kGroupWaves) void k_tile_merge(
       const uint32_t excl_i = excl & 0xFFFF, excl_a = excl >> 16;
       const uint32_t excl_b = uint32_t(d0) - 2 * excl_i - excl_a + uint32_t(straddle);
       wave_sync();  // every lane is done reading the inputs: reuse the LDS for compaction
-      const int64_t ioff = tile_ioff[t];
+      int64_t ioff = tile_ioff[t];
+      if (batch) {  // a batch launch: this tile's pair says where its results go
+        const BatchPair bp = batch[owner[t].seg >> batch_bucket_bits];
+        out_i = static_cast<KeyT*>(bp.out_i);
+        out_amb = static_cast<KeyT*>(bp.out_amb);
+        out_bma = static_cast<KeyT*>(bp.out_bma);
+        ioff -= bp.ioff_base;
+      }
       // A&B keys go to [0, tot_i), A\B keys to [tot_i, tot_i + tot_a), B\A keys after them
       // (union: every kept key, in merged order).  The three write positions travel in one
       // register, 10 bits each.
@@ -556,6 +594,36 @@ __global__ __launch_bounds__(256) void k_pair_weight_gather(
   weights[p] = m1 - m0;
 }
 
+// The same for every pair of a batch: pair p owns segments [p * nb, (p + 1) * nb]; its prefixes
+// are taken relative to the prefix at its first tile, which is also left in pairs[p].ioff_base
+// for the write pass.  totals3[3 p ..] = |A&B|, |A\\B|, |B\\A|.
+__global__ __launch_bounds__(256) void k_batch_offsets(BatchPair* __restrict__ pairs, int32_t n_pairs,
+                                                        const int64_t* __restrict__ tile_base,
+                                                        const int64_t* __restrict__ tile_ioff,
+                                                        const int64_t* __restrict__ total_m, int64_t n_buckets,
+                                                        int64_t n_segs, int64_t* __restrict__ totals3) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t per = n_buckets + 1;
+  if (i >= per * n_pairs) return;
+  const int32_t p = int32_t(i / per);
+  const int64_t s = i - int64_t(p) * per;
+  const int64_t total_tiles = tile_base[n_segs];
+  const int64_t first_of_pair = tile_base[int64_t(p) * n_buckets];
+  const int64_t first = tile_base[int64_t(p) * n_buckets + s];
+  const int64_t base = first_of_pair < total_tiles ? tile_ioff[first_of_pair] : *total_m;
+  const int64_t m = (first < total_tiles ? tile_ioff[first] : *total_m) - base;
+  const BatchPair bp = pairs[p];
+  bp.off_i[s] = m;
+  bp.off_amb[s] = bp.a_off[s] - m;
+  bp.off_bma[s] = bp.b_off[s] - m;
+  if (s == 0) pairs[p].ioff_base = base;
+  if (s == n_buckets) {
+    totals3[3 * p + 0] = m;
+    totals3[3 * p + 1] = bp.a_off[s] - m;
+    totals3[3 * p + 2] = bp.b_off[s] - m;
+  }
+}
+
 // ---- host-side plan ------------------------------------------------------------------------------
 constexpr int kSplitPerTile = kThreads;
 
@@ -608,13 +676,14 @@ inline int tiles_per_wave(int64_t max_tiles) {
 
 template <typename KeyT, int kMode>
 void launch_tile_merge(ksh_ctx* ctx, const Plan& p, int64_t* tile_m, const int64_t* tile_ioff,
-                       uint16_t* split, KeyT* out_i, KeyT* out_amb, KeyT* out_bma) {
+                       uint16_t* split, KeyT* out_i, KeyT* out_amb, KeyT* out_bma,
+                       const BatchPair* batch = nullptr, int batch_bucket_bits = 0) {
   const int tpw = tiles_per_wave(p.max_tiles);
   const int64_t waves = (p.max_tiles + tpw - 1) / tpw;
   const int64_t groups = (waves + kGroupWaves - 1) / kGroupWaves;
   hipLaunchKernelGGL((k_tile_merge<KeyT, kMode>), dim3(unsigned(groups)), dim3(kThreads * kGroupWaves), 0, ctx->stream,
                      p.desc, p.tile_base + p.n_segs, p.max_tiles, tpw, tile_m, tile_ioff, split, out_i,
-                     out_amb, out_bma);
+                     out_amb, out_bma, batch, p.owner, batch_bucket_bits);
 }
 
 inline unsigned blocks_for(int64_t n, int per) { return unsigned(std::max<int64_t>(1, (n + per - 1) / per)); }
@@ -767,22 +836,45 @@ int pair_algebra_enqueue(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a,
 template <typename KeyT>
 int pair_algebra_batch_t(ksh_ctx* ctx, const ksh_geom* g, ksh_pair_job* jobs, int32_t n_jobs) {
   const int64_t nb = n_buckets(g);
-  size_t need = 0;
+  // One plan, one count launch and one write launch for the whole batch: the segments of all
+  // pairs are tiled together, so the launches are n_jobs times longer and their ramp-up, tail
+  // and launch gaps are paid once.
+  int64_t max_tiles = 0;
+  for (int32_t i = 0; i < n_jobs; i++)
+    max_tiles += nb + (jobs[i].a.n_keys + jobs[i].b.n_keys) / TileCfg<KeyT>::kTile + 1;
+  const int64_t n_segs = int64_t(n_jobs) * nb;
+  if (max_tiles > int64_t(0x7FFFFFF0) || n_segs > int64_t(0x7FFFFFF0))
+    return fail(KSH_INVALID_ARGUMENT, "batch too large for one launch");
+  const size_t pairs_bytes = align256(size_t(n_jobs) * sizeof(BatchPair));
+  KSH_TRY(arena_reserve(ctx, pairs_bytes + align256(size_t(n_jobs) * 24) + plan_bytes(n_segs, max_tiles) +
+                                 size_t(std::max(max_tiles, n_segs) / 256 + 4096) * 8 + (1u << 16)));
+  arena_reset(ctx);
+  BatchPair* d_pairs = static_cast<BatchPair*>(arena_alloc(ctx, size_t(n_jobs) * sizeof(BatchPair)));
+  int64_t* d_totals = static_cast<int64_t*>(arena_alloc(ctx, size_t(n_jobs) * 24));
+  char* base = static_cast<char*>(arena_alloc(ctx, plan_bytes(n_segs, max_tiles)));
+  if (!d_pairs || !d_totals || !base) return fail(KSH_INTERNAL, "scratch arena too small");
+  std::vector<BatchPair> h_pairs(static_cast<size_t>(n_jobs));
   for (int32_t i = 0; i < n_jobs; i++) {
-    const int64_t max_tiles = nb + (jobs[i].a.n_keys + jobs[i].b.n_keys) / TileCfg<KeyT>::kTile + 1;
-    if (max_tiles > int64_t(0x7FFFFFF0)) return fail(KSH_INVALID_ARGUMENT, "pair too large for one launch");
-    need = std::max(need, pair_scratch_bytes(nb, max_tiles));
+    const ksh_pair_job& j = jobs[i];
+    h_pairs[i] = BatchPair{j.a.d_keys, j.a.d_offsets, j.b.d_keys, j.b.d_offsets, j.d_off_i, j.d_off_amb,
+                           j.d_off_bma, j.d_keys_i, j.d_keys_amb, j.d_keys_bma, 0};
   }
-  KSH_TRY(arena_reserve(ctx, need));
-  void* tot = nullptr;
-  KSH_TRY(pool_alloc(ctx, size_t(n_jobs) * 3 * sizeof(int64_t), &tot));
-  int64_t* d_totals = static_cast<int64_t*>(tot);
-  int rc = KSH_OK;
-  for (int32_t i = 0; i < n_jobs && rc == KSH_OK; i++) {
-    ksh_pair_job& j = jobs[i];
-    rc = pair_algebra_enqueue<KeyT>(ctx, g, &j.a, &j.b, j.d_off_i, j.d_off_amb, j.d_off_bma, j.d_keys_i,
-                                    j.d_keys_amb, j.d_keys_bma, d_totals + 3 * i);
+  KSH_HIP(hipMemcpyAsync(d_pairs, h_pairs.data(), size_t(n_jobs) * sizeof(BatchPair), hipMemcpyHostToDevice,
+                         ctx->stream));
+  Plan p;
+  plan_carve(base, n_segs, max_tiles, &p);
+  const BatchSegs<KeyT> segs{d_pairs, g->n_bucket_bits};
+  KSH_TRY((plan_tile_base<KeyT>(ctx, segs, n_segs, p.tile_base, p.owner)));
+  KSH_TRY((plan_count<KeyT>(ctx, segs, p, 1, true)));
+  hipLaunchKernelGGL(k_batch_offsets, dim3(blocks_for((nb + 1) * n_jobs, 256)), dim3(256), 0, ctx->stream,
+                     d_pairs, n_jobs, p.tile_base, p.tile_ioff, p.total_m, nb, n_segs, d_totals);
+  {
+    Timer timer(ctx, 0);
+    launch_tile_merge<KeyT, 1>(ctx, p, nullptr, p.tile_ioff, p.split, static_cast<KeyT*>(nullptr),
+                               static_cast<KeyT*>(nullptr), static_cast<KeyT*>(nullptr), d_pairs,
+                               g->n_bucket_bits);
   }
+  KSH_HIP(hipGetLastError());
   const size_t n_vals = static_cast<size_t>(n_jobs) * 3;
   int64_t* h = ctx->h_pinned;  // 64 values
   if (n_vals > 64) {
@@ -790,22 +882,14 @@ int pair_algebra_batch_t(ksh_ctx* ctx, const ksh_geom* g, ksh_pair_job* jobs, in
       if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
       ctx->h_batch = nullptr;
       ctx->h_batch_count = 0;
-      if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_batch), n_vals * 2 * sizeof(int64_t)) != hipSuccess) {
-        pool_free(ctx, tot);
+      if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_batch), n_vals * 2 * sizeof(int64_t)) != hipSuccess)
         return fail(KSH_INTERNAL, "hipHostMalloc failed");
-      }
       ctx->h_batch_count = n_vals * 2;
     }
     h = ctx->h_batch;
   }
-  if (rc == KSH_OK) {
-    hipError_t e = hipMemcpyAsync(h, d_totals, n_vals * sizeof(int64_t), hipMemcpyDeviceToHost,
-                                  ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    if (e != hipSuccess) rc = fail(KSH_INTERNAL, "totals read-back failed: %s", hipGetErrorString(e));
-  }
-  pool_free(ctx, tot);
-  if (rc != KSH_OK) return rc;
+  KSH_HIP(hipMemcpyAsync(h, d_totals, n_vals * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
+  KSH_HIP(hipStreamSynchronize(ctx->stream));  // also keeps h_pairs alive long enough
   for (int32_t i = 0; i < n_jobs; i++)
     for (int q = 0; q < 3; q++) jobs[i].totals[q] = h[size_t(3 * i + q)];
   return KSH_OK;

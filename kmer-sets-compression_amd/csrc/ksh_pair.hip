@@ -509,24 +509,44 @@ __global__ __launch_bounds__(kThreads * kGroupWaves) void k_tile_merge(
         ioff -= bp.ioff_base;
       }
       // A&B keys go to [0, tot_i), A\B keys to [tot_i, tot_i + tot_a), B\A keys after them
-      // (union: every kept key, in merged order).  The three write positions travel in one
-      // register, 10 bits each.
-      static_assert(Cfg::kCap < 1024, "packed 10-bit positions");
-      uint32_t pos3 = kMode == 2 ? excl_i + excl_a + excl_b
-                                 : excl_i + ((tot_i + excl_a) << 10) + ((tot_i + tot_a + excl_b) << 20);
+      // (union: every kept key, in merged order).  While a tile holds fewer than 1024 keys the
+      // three write positions travel in one register, 10 bits each.
+      if constexpr (kMode == 2) {
+        uint32_t p_u = excl_i + excl_a + excl_b;
 #pragma unroll
-      for (int step = 0; step < kVT; step++) {
-        if (step < n_steps) {
-          const uint32_t bit = 1u << (kVT - 1 - step);
-          const bool from_a = (m_a & bit) != 0, x = (m_x & bit) != 0;
-          const bool keep = from_a | !x;
-          if (kMode == 2) {
-            if (keep) lds[pos3] = vals[step];
-            pos3 += uint32_t(keep);
-          } else {
+        for (int step = 0; step < kVT; step++) {
+          if (step < n_steps) {
+            const uint32_t bit = 1u << (kVT - 1 - step);
+            const bool keep = ((m_a & bit) != 0) | ((m_x & bit) == 0);
+            if (keep) lds[p_u] = vals[step];
+            p_u += uint32_t(keep);
+          }
+        }
+      } else if constexpr (Cfg::kCap < 1024) {
+        uint32_t pos3 = excl_i + ((tot_i + excl_a) << 10) + ((tot_i + tot_a + excl_b) << 20);
+#pragma unroll
+        for (int step = 0; step < kVT; step++) {
+          if (step < n_steps) {
+            const uint32_t bit = 1u << (kVT - 1 - step);
+            const bool from_a = (m_a & bit) != 0, x = (m_x & bit) != 0;
+            const bool keep = from_a | !x;
             const uint32_t sh = from_a ? (x ? 10u : 0u) : 20u;
             if (keep) lds[(pos3 >> sh) & 1023] = vals[step];
             pos3 += keep ? (1u << sh) : 0u;
+          }
+        }
+      } else {
+        uint32_t p_i = excl_i, p_a = tot_i + excl_a, p_b = tot_i + tot_a + excl_b;
+#pragma unroll
+        for (int step = 0; step < kVT; step++) {
+          if (step < n_steps) {
+            const uint32_t bit = 1u << (kVT - 1 - step);
+            const bool from_a = (m_a & bit) != 0, x = (m_x & bit) != 0;
+            const uint32_t pos = from_a ? (x ? p_a : p_i) : p_b;
+            if (from_a | !x) lds[pos] = vals[step];
+            p_i += uint32_t(from_a & !x);
+            p_a += uint32_t(from_a & x);
+            p_b += uint32_t(!from_a & !x);
           }
         }
       }

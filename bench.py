@@ -231,7 +231,11 @@ def main():
         pmc = json.load(open(pmc_file))
         if pmc.get("kernel") == "k_tile_merge<KeyT, 1>" and pmc.get("kmers_per_set") == size \
                 and pmc.get("k") == k and pmc.get("sets") == n_sets:
-            traffic, traffic_src = pmc["bytes_per_launch"], "profiles/pmc_traffic.json"
+            # the counters were collected on batched launches; a per-pair launch moves a
+            # proportional share
+            per_launch_pairs = 1 if (args.per_pair_sync or args.two_pass) else len(pairs)
+            traffic = pmc["bytes_per_launch"] * per_launch_pairs / pmc.get("pairs_per_launch", 1)
+            traffic_src = "profiles/pmc_traffic.json"
 
     if rank == 0:
         # algo_bytes covers every launch of the timed region, write_ms the sampled ones

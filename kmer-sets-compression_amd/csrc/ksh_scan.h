@@ -3,9 +3,11 @@
 // gfx950 only.
 //
 // Every workgroup scans its own 2048 values, publishes their sum in `state`, then adds up the
-// sums published by the workgroups before it and writes its values out.  A workgroup only
-// ever waits for workgroups with a smaller index, which were dispatched no later than it was
-// and wait only for still smaller ones, so the chain always makes progress.  A sum is
+// sums published by the workgroups before it and writes its values out.  A launch has at most
+// kChainMaxBlocks (128) workgroups of 256 threads, far fewer than the chip holds at once, so
+// every workgroup of it becomes resident whatever the dispatch order, and a workgroup only ever
+// waits for lower-numbered ones, which wait only for still lower ones: the chain always makes
+// progress (and every poll loop is bounded all the same).  A sum is
 // published as two words (its low 48 bits and its high 16 bits), each carrying the launch's
 // epoch in its top 16 bits: a word is valid by itself, so the two need no ordering between
 // them, words left by earlier launches never match, and the state array needs no clearing
@@ -84,9 +86,13 @@ __global__ __launch_bounds__(kChainThreads) void k_scan_chained(Load load, Emit 
       const int64_t idx = first - lane;
       if (idx >= 0) {
         unsigned long long w0, w1;
+        unsigned polls = 0;
         do {
           w0 = __hip_atomic_load(&state[2 * idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           w1 = __hip_atomic_load(&state[2 * idx + 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          // every spin is bounded: a launch of at most kChainMaxBlocks workgroups is resident as a
+          // whole, so a wait of seconds can only mean a broken launch; abort it rather than hang
+          if (++polls == (1u << 28)) __builtin_trap();
         } while ((w0 >> kChainValueBits) != epoch || (w1 >> kChainValueBits) != epoch);
         sum_u += (w0 & kValueMask) | (w1 << kChainValueBits);
       }

@@ -31,6 +31,10 @@ def main():
     ap.add_argument("--cpu-iterations", type=int, default=0,
                     help="also time the oracle on the first I iterations (0 = skip)")
     ap.add_argument("--cpu-size", type=float, default=0, help="set size for the CPU leg (default: --size)")
+    ap.add_argument("--gpus", type=int, default=1,
+                    help="strong scaling of the loop: N processes (python -m torch.distributed.run "
+                         "--nproc-per-node N bench_loop.py --gpus N ...), every rank runs the loop on "
+                         "replicated sets and the SPSS encodes are dealt out (ksh_kss_build_sharded)")
     args = ap.parse_args()
 
     import numpy as np
@@ -38,9 +42,29 @@ def main():
 
     from kmersets import capi, synth, synth_torch
 
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("WORLD_SIZE=%d does not match --gpus %d (launch with torch.distributed.run)" % (world, args.gpus))
+    dist, coll_dev = None, "cpu"
+    backend = os.environ.get("KSH_BENCH_BACKEND", "nccl")   # gloo: rehearsal, every rank on cuda:0
+    if backend != "nccl":
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            coll_dev = torch.device("cuda", local_rank)
+        else:
+            dist.init_process_group(backend)
+
     k, nbits, n_sets, size = args.k, args.bucket_bits, args.sets, int(args.size)
     g = capi.geom(k, nbits)
-    ctx = capi.Context(0)
+    ctx = capi.Context(local_rank)
     dev = ctx.device
     t0 = time.perf_counter()
     kmers = synth_torch.phylogeny_sets(k, n_sets, size, args.seed, dev)
@@ -54,12 +78,30 @@ def main():
     ids = synth.sample_bucket_ids(nbits, seed=args.seed + 1)
 
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     t0 = time.perf_counter()
-    kss = capi.DeviceKmerSetSet(ctx, compacts, ids, max_iterations=args.max_iterations)
+    kss = capi.DeviceKmerSetSet(ctx, compacts, ids, max_iterations=args.max_iterations, dist=dist,
+                                dist_device=coll_dev)
     torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
     wall = time.perf_counter() - t0
     st = kss.stats()
     it, cp, imp = kss.trace()
+    encodes = [st["n_encodes"]]
+    if world > 1:
+        t = torch.tensor([wall], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        wall = float(t.item())
+        # the StreamVByte sizes of a node's lengths are known where the node's SPSS is held
+        lb = torch.tensor([st["length_bytes"]], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(lb)
+        st["length_bytes"] = int(lb.item())
+        ne = torch.tensor([st["n_encodes"]], dtype=torch.int64, device=coll_dev)
+        parts = [torch.zeros_like(ne) for _ in range(world)]
+        dist.all_gather(parts, ne)
+        encodes = [int(x.item()) for x in parts]
     out = {
         "metric": "Mk-mers/s processed in kmerset-multiple-compress (KmerSetSet constructor)",
         "value": st["n_processed"] / wall / 1e6,
@@ -72,10 +114,16 @@ def main():
         "chars_per_kmer_before": st["initial_spss_weight"] / sum(sizes),
         "chars_per_kmer_after": st["final_spss_weight"] / sum(sizes),
         "bytes_per_kmer_after_spss": (st["packed_bytes"] + st["length_bytes"]) / sum(sizes),
+        "n_gpus": world,
+        "scaling": "strong",
+        "encodes_per_rank": encodes,
         "config": {"workload": "%d canonical k=%d sets of %d k-mers, full KmerSetSet loop" % (n_sets, k, size),
-                   "input_build_s": t_inputs},
+                   "input_build_s": t_inputs,
+                   "parallelism": "1 GPU" if world == 1 else
+                                  "1 process per GPU, sets replicated, SPSS encodes dealt out by node, "
+                                  "all-gather of (n_strings, n_bases) at the convergence checks"},
     }
-    if args.cpu_iterations > 0:
+    if args.cpu_iterations > 0 and rank == 0:
         import oracle_lib as ol
 
         csize = int(args.cpu_size) if args.cpu_size else size
@@ -88,9 +136,13 @@ def main():
                                "kind": "port",
                                "sample": "oracle KmerSetSet, %d sets of %d k-mers, first %d iterations, %.1f s"
                                          % (n_sets, csize, args.cpu_iterations, cw)}
-    print(json.dumps(out))
+    if rank == 0:
+        print(json.dumps(out))
     kss.close()
     ctx.close()
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":

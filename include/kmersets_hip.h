@@ -253,6 +253,25 @@ typedef struct ksh_kss ksh_kss;
 int ksh_kss_build(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* inputs, int32_t n_inputs,
                   const int32_t* bucket_ids, int32_t n_ids, int canonical, int32_t max_iterations,
                   ksh_kss** out);
+/* Multi-GPU build, one process per GPU.  Every rank calls this with the same inputs and runs the
+ * same (deterministic) loop on its own resident copies of the sets; the SPSS encodes, ~85 % of
+ * the loop's time, are dealt out node by node (node i -> rank i % world), and at every point
+ * where the loop reads the SPSS weights (kmer_set_set.h:287 and the end) the ranks exchange
+ * (n_strings, n_bases) of the freshly encoded nodes through `gather`: an all-gather of `count`
+ * int64 per rank into recv[world * count], rank-major, returning 0 on success (RCCL or any other
+ * transport; KB-scale, a few times per build).  Trace, checkpoints, DAG and every node's set
+ * are identical on all ranks and equal to the single-GPU build; a node's SPSS is held by one
+ * rank (ksh_kss_node_holder; -1 = every rank, the inputs), and ksh_kss_node answers
+ * KSH_FAILED_PRECONDITION for the SPSS of a node held elsewhere. */
+typedef int (*ksh_allgather_i64)(void* user, const int64_t* send, int64_t count, int64_t* recv);
+int ksh_kss_build_sharded(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* inputs, int32_t n_inputs,
+                          const int32_t* bucket_ids, int32_t n_ids, int canonical,
+                          int32_t max_iterations, int32_t rank, int32_t world, ksh_allgather_i64 gather,
+                          void* gather_user, ksh_kss** out);
+int ksh_kss_node_holder(const ksh_kss* k, int32_t i, int32_t* rank);
+/* SPSS encodes this process ran for the build, and the k-mers they covered (the sharded build's
+ * balance; in a single-GPU build: how many encodes the deferral left). */
+int ksh_kss_encode_counts(const ksh_kss* k, int64_t* n_encodes, int64_t* n_encoded_kmers);
 int ksh_kss_destroy(ksh_kss* k);
 /* KmerSetSet::Size (:430): number of nodes. */
 int ksh_kss_size(const ksh_kss* k, int32_t* n_nodes);

@@ -73,22 +73,42 @@ class KmerSetSet {
       : KmerSetSet(std::move(kmer_sets_compact), canonical, n_workers,
                    ksc::SampleBucketIds(N, ksc::BucketSeedFromEnv())) {}
 
+  // One process per GPU: every rank constructs the same KmerSetSet with its own rank, and the
+  // SPSS encodes are dealt out (ksh_kss_build_sharded).  `gather` is the all-gather the build
+  // needs a few times (ksh_allgather_i64: RCCL ncclAllGather on a staging buffer, MPI, ...).
+  // Nodes held by another rank stay empty here (Holder(i) says which); Dump writes the files
+  // of the nodes this rank holds, so the ranks together write the directory.
+  struct Shard {
+    int rank = 0, world = 1;
+    ksh_allgather_i64 gather = nullptr;
+    void* user = nullptr;
+  };
+
   KmerSetSet(std::vector<Compact> kmer_sets_compact, bool canonical, int /*n_workers*/,
-             const std::vector<int>& bucket_ids, int max_iterations = -1) {
+             const std::vector<int>& bucket_ids, int max_iterations = -1, Shard shard = Shard()) {
     const ksh_geom g = Set::Geom();
     std::vector<ksh_spss_view> views;
     for (const Compact& c : kmer_sets_compact) views.push_back(c.View());
     std::vector<std::int32_t> ids(bucket_ids.begin(), bucket_ids.end());
     ksh_kss* kss = nullptr;
-    ksc::Check(ksh_kss_build(ksc::Ctx(), &g, views.data(), static_cast<std::int32_t>(views.size()),
-                             ids.data(), static_cast<std::int32_t>(ids.size()), canonical ? 1 : 0,
-                             max_iterations, &kss));
+    if (shard.world > 1)
+      ksc::Check(ksh_kss_build_sharded(ksc::Ctx(), &g, views.data(), static_cast<std::int32_t>(views.size()),
+                                       ids.data(), static_cast<std::int32_t>(ids.size()), canonical ? 1 : 0,
+                                       max_iterations, shard.rank, shard.world, shard.gather, shard.user, &kss));
+    else
+      ksc::Check(ksh_kss_build(ksc::Ctx(), &g, views.data(), static_cast<std::int32_t>(views.size()),
+                               ids.data(), static_cast<std::int32_t>(ids.size()), canonical ? 1 : 0,
+                               max_iterations, &kss));
     std::int32_t n_nodes = 0;
     ksc::Check(ksh_kss_size(kss, &n_nodes));
     const int dev = ksc::DeviceIndex();
     for (std::int32_t i = 0; i < n_nodes; i++) {
-      ksh_spss_view v;
-      ksc::Check(ksh_kss_node(kss, i, &v, nullptr, nullptr));
+      ksh_spss_view v{nullptr, nullptr, 0, 0};
+      std::int32_t holder = -1;
+      ksc::Check(ksh_kss_node_holder(kss, i, &holder));
+      holders_.push_back(holder);
+      my_rank_ = shard.rank;
+      if (holder < 0 || holder == shard.rank) ksc::Check(ksh_kss_node(kss, i, &v, nullptr, nullptr));
       ksc::DeviceBuffer words(std::size_t((v.n_bases + 31) / 32) * 8), lens(std::size_t(v.n_strings) * 4);
       if (v.n_bases) ksc::Check(ksh_memcpy_d2d(dev, words.get(), v.d_words, std::size_t((v.n_bases + 31) / 32) * 8));
       if (v.n_strings) ksc::Check(ksh_memcpy_d2d(dev, lens.get(), v.d_lens, std::size_t(v.n_strings) * 4));
@@ -108,6 +128,10 @@ class KmerSetSet {
   }
 
   int Size() const { return static_cast<int>(kmer_sets_compact_.size()); }
+
+  // Rank holding node i's SPSS after a sharded construction; -1: every rank (and always after
+  // a single-process construction or Load).
+  int Holder(int i) const { return i < static_cast<int>(holders_.size()) ? holders_[i] : -1; }
 
   // Reconstructs the ith k-mer set: union over the nodes reachable from i.
   Set Get(int i, bool canonical, int n_workers) const {
@@ -133,7 +157,7 @@ class KmerSetSet {
       return ksc::InternalError("failed to create a directory");
     }
     const std::filesystem::path dir(directory_name);
-    {
+    if (my_rank_ == 0) {
       std::vector<std::string> v;
       v.push_back(internal::SerializeAdjacencyList(children_));
       v.push_back(std::to_string(kmer_sets_compact_.size()));
@@ -142,6 +166,10 @@ class KmerSetSet {
     }
     int fail_count = 0;
     for (std::size_t i = 0; i < kmer_sets_compact_.size(); i++) {
+      // after a sharded construction a node's file is written by the rank that holds it (the
+      // inputs, held everywhere, by rank 0)
+      const int holder = Holder(static_cast<int>(i));
+      if (holder >= 0 ? holder != my_rank_ : my_rank_ != 0) continue;
       const ksc::Status status = kmer_sets_compact_[i].Dump(
           (dir / (std::to_string(i) + "." + extension)).string(), compressor, n_workers);
       if (!status.ok()) fail_count += 1;
@@ -192,6 +220,8 @@ class KmerSetSet {
  private:
   internal::AdjacencyList children_;
   std::vector<Compact> kmer_sets_compact_;
+  std::vector<int> holders_;  // sharded construction: the rank holding each node's SPSS (-1: all)
+  int my_rank_ = 0;
   std::vector<Iteration> iterations_;
   std::int64_t stats_[8] = {};
 };

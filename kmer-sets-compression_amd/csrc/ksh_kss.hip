@@ -32,6 +32,7 @@ struct KssCompact {
   int64_t n_strings = 0, n_bases = 0, size = 0;
   bool owned = false;
   bool valid = true;  // false: the node's set changed and its SPSS has not been re-encoded yet
+  int holder = -1;    // sharded build: the rank that holds the SPSS (-1: every rank does)
 };
 
 struct ksh_kss {
@@ -49,6 +50,11 @@ struct ksh_kss {
   int64_t final_spss_weight = 0;
   int64_t n_encodes = 0, n_encoded_kmers = 0;
   std::string meta;
+  // sharded build (ksh_kss_build_sharded): every rank runs the same loop on resident copies of
+  // the sets; the SPSS encodes, the dominant cost, are dealt out node by node
+  int rank = 0, world = 1;
+  ksh_allgather_i64 gather = nullptr;
+  void* gather_user = nullptr;
 };
 
 namespace ksh {
@@ -113,13 +119,51 @@ static int encode_set(ksh_ctx* ctx, const ksh_geom* g, const KssSet& s, KssCompa
 // node that is merged again before the next check never needs its intermediate SPSS, so the
 // encode is deferred to the points where the reference looks: same values, fewer encodes.
 static int ensure_compacts(ksh_kss* k) {
-  for (size_t i = 0; i < k->compacts.size(); i++) {
-    if (k->compacts[i].valid) continue;
+  if (k->world <= 1) {
+    for (size_t i = 0; i < k->compacts.size(); i++) {
+      if (k->compacts[i].valid) continue;
+      KssCompact c;
+      KSH_TRY(encode_set(k->ctx, &k->g, k->sets[i], &c));
+      k->compacts[i] = c;
+      k->n_encodes++;
+      k->n_encoded_kmers += k->sets[i].n;
+    }
+    return KSH_OK;
+  }
+  // Sharded: the stale nodes (the same list on every rank, the loop being deterministic) are
+  // dealt out round robin; a rank encodes its share and all ranks exchange what the loop reads,
+  // (n_strings, n_bases) per node.
+  std::vector<size_t> stale;
+  for (size_t i = 0; i < k->compacts.size(); i++)
+    if (!k->compacts[i].valid) stale.push_back(i);
+  if (stale.empty()) return KSH_OK;
+  std::vector<int64_t> send(2 * stale.size(), -1), recv(2 * stale.size() * size_t(k->world), -1);
+  for (size_t q = 0; q < stale.size(); q++) {
+    const size_t i = stale[q];
+    const int holder = int(i % size_t(k->world));
     KssCompact c;
-    KSH_TRY(encode_set(k->ctx, &k->g, k->sets[i], &c));
+    if (holder == k->rank) {
+      KSH_TRY(encode_set(k->ctx, &k->g, k->sets[i], &c));
+      k->n_encodes++;
+      k->n_encoded_kmers += k->sets[i].n;
+      send[2 * q] = c.n_strings;
+      send[2 * q + 1] = c.n_bases;
+    } else {
+      c.size = k->sets[i].n;
+    }
+    c.holder = holder;
     k->compacts[i] = c;
-    k->n_encodes++;
-    k->n_encoded_kmers += k->sets[i].n;
+  }
+  if (k->gather(k->gather_user, send.data(), int64_t(send.size()), recv.data()) != 0)
+    return fail(KSH_INTERNAL, "the all-gather callback of the sharded build failed");
+  for (size_t q = 0; q < stale.size(); q++) {
+    KssCompact& c = k->compacts[stale[q]];
+    const int64_t* from = recv.data() + size_t(c.holder) * send.size() + 2 * q;
+    if (from[0] < 0 || from[1] < 0)
+      return fail(KSH_INTERNAL, "rank %d did not report node %zu", c.holder, stale[q]);
+    c.n_strings = from[0];
+    c.n_bases = from[1];
+    c.valid = true;
   }
   return KSH_OK;
 }
@@ -312,6 +356,51 @@ int ksh_kss_build(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* inputs, 
   return KSH_OK;
 }
 
+int ksh_kss_build_sharded(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* inputs, int32_t n_inputs,
+                          const int32_t* bucket_ids, int32_t n_ids, int canonical_flag,
+                          int32_t max_iterations, int32_t rank, int32_t world, ksh_allgather_i64 gather,
+                          void* gather_user, ksh_kss** out) {
+  if (!ctx || !out || (n_inputs > 0 && !inputs)) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  *out = nullptr;
+  KSH_TRY(check_geom(g));
+  if (n_inputs < 0 || n_ids < 0) return fail(KSH_INVALID_ARGUMENT, "negative count");
+  if (!canonical_flag) return fail(KSH_INVALID_ARGUMENT, "only canonical k-mer sets are supported");
+  if (world < 1 || rank < 0 || rank >= world) return fail(KSH_INVALID_ARGUMENT, "bad rank / world");
+  if (world > 1 && !gather) return fail(KSH_INVALID_ARGUMENT, "a sharded build needs the all-gather callback");
+  KSH_HIP(hipSetDevice(ctx->device));
+  ksh_kss* k = new ksh_kss;
+  k->ctx = ctx;
+  k->g = *g;
+  k->canonical = canonical_flag;
+  k->rank = rank;
+  k->world = world;
+  k->gather = gather;
+  k->gather_user = gather_user;
+  std::vector<int32_t> ids(bucket_ids, bucket_ids + n_ids);
+  int rc = KSH_OK;
+  if (n_inputs > 0) rc = build(k, inputs, n_inputs, ids, max_iterations);
+  if (rc != KSH_OK) {
+    ksh_kss_destroy(k);
+    return rc;
+  }
+  *out = k;
+  return KSH_OK;
+}
+
+int ksh_kss_encode_counts(const ksh_kss* k, int64_t* n_encodes, int64_t* n_encoded_kmers) {
+  if (!k || !n_encodes || !n_encoded_kmers) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  *n_encodes = k->n_encodes;
+  *n_encoded_kmers = k->n_encoded_kmers;
+  return KSH_OK;
+}
+
+int ksh_kss_node_holder(const ksh_kss* k, int32_t i, int32_t* rank) {
+  if (!k || !rank) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  if (i < 0 || size_t(i) >= k->compacts.size()) return fail(KSH_INVALID_ARGUMENT, "no node %d", i);
+  *rank = k->compacts[i].holder;
+  return KSH_OK;
+}
+
 int ksh_kss_destroy(ksh_kss* k) {
   if (!k) return KSH_OK;
   (void)hipSetDevice(k->ctx->device);
@@ -332,7 +421,12 @@ int ksh_kss_node(const ksh_kss* k, int32_t i, ksh_spss_view* compact, ksh_set_vi
                  int64_t* size) {
   if (!k) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
   if (i < 0 || size_t(i) >= k->compacts.size()) return fail(KSH_INVALID_ARGUMENT, "no node %d", i);
-  if (compact) *compact = view_of(k->compacts[i]);
+  if (compact) {
+    const KssCompact& c = k->compacts[i];
+    if (c.holder >= 0 && c.holder != k->rank)
+      return fail(KSH_FAILED_PRECONDITION, "the SPSS of node %d is held by rank %d", i, c.holder);
+    *compact = view_of(c);
+  }
   if (set) *set = view_of(k->sets[i]);
   if (size) *size = k->compacts[i].size;
   return KSH_OK;
@@ -383,6 +477,7 @@ int ksh_kss_stats(const ksh_kss* k, int64_t stats[8]) {
   int64_t bytes = 0, len_bytes = 0;
   for (const KssCompact& c : k->compacts) {
     bytes += (2 * c.n_bases + 7) / 8;
+    if (c.holder >= 0 && c.holder != k->rank) continue;  // sharded build: lengths live on the holder
     int64_t b = 0;
     KSH_TRY(ksh_svb_encode_0124(k->ctx, c.lens, c.n_strings, nullptr, &b));
     len_bytes += b;

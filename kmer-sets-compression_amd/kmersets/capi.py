@@ -39,6 +39,9 @@ class SpssView(C.Structure):
                 ("n_bases", C.c_int64)]
 
 
+GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int64))
+
+
 class PairJob(C.Structure):
     _fields_ = [("a", SetView), ("b", SetView), ("d_off_i", C.c_void_p), ("d_off_amb", C.c_void_p),
                 ("d_off_bma", C.c_void_p), ("d_keys_i", C.c_void_p), ("d_keys_amb", C.c_void_p),
@@ -118,6 +121,10 @@ def lib():
         "ksh_svb_decode_0124": (C.c_int, [vp, vp, i64, vp, C.POINTER(i64)]),
         "ksh_kss_build": (C.c_int, [vp, GP, C.POINTER(SpssView), i32, C.POINTER(i32), i32, C.c_int,
                                     i32, C.POINTER(vp)]),
+        "ksh_kss_build_sharded": (C.c_int, [vp, GP, C.POINTER(SpssView), i32, C.POINTER(i32), i32, C.c_int,
+                                            i32, i32, i32, GATHER_FN, vp, C.POINTER(vp)]),
+        "ksh_kss_node_holder": (C.c_int, [vp, i32, C.POINTER(i32)]),
+        "ksh_kss_encode_counts": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
         "ksh_kss_destroy": (C.c_int, [vp]),
         "ksh_kss_size": (C.c_int, [vp, C.POINTER(i32)]),
         "ksh_kss_node": (C.c_int, [vp, i32, C.POINTER(SpssView), SP, C.POINTER(i64)]),
@@ -555,15 +562,51 @@ class Context:
 class DeviceKmerSetSet:
     """ksh_kss: KmerSetSet built on device (lib/core/kmer_set_set.h:109-427)."""
 
-    def __init__(self, ctx, compacts, bucket_ids, canonical=True, max_iterations=-1):
+    def __init__(self, ctx, compacts, bucket_ids, canonical=True, max_iterations=-1, dist=None,
+                 dist_device="cpu"):
+        """dist: an initialised torch.distributed module (one process per GPU) for the sharded
+        build (ksh_kss_build_sharded): every rank passes the same inputs; the SPSS of a node
+        lives on one rank (node_holder)."""
         self.ctx, self.g, self.inputs = ctx, compacts[0].g, list(compacts)
         views = (SpssView * len(compacts))(*[c.view() for c in compacts])
         ids = np.ascontiguousarray(bucket_ids, dtype=np.int32)
         h = C.c_void_p()
-        check(lib().ksh_kss_build(ctx.h, C.byref(self.g), views, len(compacts),
-                                  ids.ctypes.data_as(C.POINTER(C.c_int32)), ids.size, int(canonical),
-                                  max_iterations, C.byref(h)))
+        if dist is None:
+            check(lib().ksh_kss_build(ctx.h, C.byref(self.g), views, len(compacts),
+                                      ids.ctypes.data_as(C.POINTER(C.c_int32)), ids.size, int(canonical),
+                                      max_iterations, C.byref(h)))
+        else:
+            import torch
+
+            world, rank = dist.get_world_size(), dist.get_rank()
+
+            def gather(_user, send, count, recv):
+                try:
+                    mine = torch.from_numpy(np.ctypeslib.as_array(send, shape=(count,)).copy()).to(dist_device)
+                    parts = [torch.empty_like(mine) for _ in range(world)]
+                    dist.all_gather(parts, mine)
+                    out = np.ctypeslib.as_array(recv, shape=(world * count,))
+                    for r, part in enumerate(parts):
+                        out[r * count:(r + 1) * count] = part.cpu().numpy()
+                    return 0
+                except Exception:  # a Python exception must not unwind through the C frames
+                    import traceback
+
+                    traceback.print_exc()
+                    return 1
+
+            self._gather = GATHER_FN(gather)  # keep the callback object alive
+            check(lib().ksh_kss_build_sharded(ctx.h, C.byref(self.g), views, len(compacts),
+                                              ids.ctypes.data_as(C.POINTER(C.c_int32)), ids.size,
+                                              int(canonical), max_iterations, rank, world, self._gather, None,
+                                              C.byref(h)))
         self.h = h
+
+    def node_holder(self, i):
+        """Rank holding node i's SPSS in a sharded build; -1: every rank does."""
+        r = C.c_int32()
+        check(lib().ksh_kss_node_holder(self.h, i, C.byref(r)))
+        return r.value
 
     def close(self):
         if getattr(self, "h", None):
@@ -647,7 +690,11 @@ class DeviceKmerSetSet:
         check(lib().ksh_kss_stats(self.h, st))
         keys = ["initial_total_size", "final_total_size", "initial_spss_weight", "n_processed",
                 "final_spss_weight", "packed_bytes", "length_bytes", "nodes"]
-        return dict(zip(keys, [int(x) for x in st]))
+        out = dict(zip(keys, [int(x) for x in st]))
+        ne, nk = C.c_int64(), C.c_int64()
+        check(lib().ksh_kss_encode_counts(self.h, C.byref(ne), C.byref(nk)))
+        out["n_encodes"], out["n_encoded_kmers"] = ne.value, nk.value
+        return out
 
     def get_kmers(self, i):
         """KmerSetSet::Get(i) as a sorted uint64 array (downloaded)."""

@@ -1,0 +1,79 @@
+"""Worker of tests/test_gpu_kmer_set_set.py::test_sharded_build: one of N ranks (all on GPU 0, gloo
+for the exchange) building the same KmerSetSet with ksh_kss_build_sharded.  Every rank checks
+the replicated state against the oracle; the SPSS strings are checked by the rank that holds
+them, and every node must be held by exactly the rank the deal says."""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "..", "kmer-sets-compression_amd"))
+import oracle_lib as ol  # noqa: E402
+from kmersets import capi, synth  # noqa: E402
+
+
+def main():
+    k, n, kb, n_sets, size, seed = (int(x) for x in sys.argv[1:7])
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    torch.cuda.set_device(0)
+    ctx = capi.Context(0)
+    sets = synth.phylogeny_sets(k, n_sets, size, seed=seed)
+    osets = [ol.Set.from_kmers(k, n, kb, s) for s in sets]
+    ocompacts = [s.compact() for s in osets]
+    ids = synth.sample_bucket_ids(n, seed=seed + 1)
+    okss = ol.KmerSetSet(ocompacts, ids)
+    g = capi.geom(k, n)
+    dcompacts = [capi.DeviceSpss.from_strings(g, c.strings(), ctx.device) for c in ocompacts]
+    dkss = capi.DeviceKmerSetSet(ctx, dcompacts, ids, dist=dist)
+
+    it, cp, imp = dkss.trace()
+    assert np.array_equal(it, okss.iterations())
+    ocp, oimp = okss.checkpoints()
+    assert np.array_equal(cp, ocp) and np.array_equal(imp, oimp)
+    assert dkss.size() == okss.size() and dkss.meta() == okss.meta()
+    st = dkss.stats()
+    assert st["initial_spss_weight"] == okss.stat(2) and st["n_processed"] == okss.stat(3)
+    assert st["final_spss_weight"] == sum(okss.node(i).weight() for i in range(okss.size()))
+    held = []
+    for i in range(okss.size()):
+        node = okss.node(i)
+        assert dkss.node_size(i) == node.size()
+        assert np.array_equal(dkss.node_kmers(i), node.to_set().kmers())     # sets are replicated
+        holder = dkss.node_holder(i)
+        if holder in (-1, rank):
+            assert dkss.node_strings(i) == node.strings(), "node %d" % i
+            held.append(i)
+        else:
+            assert holder == i % world
+            try:
+                dkss.node_strings(i)
+                raise AssertionError("node %d should be held by rank %d only" % (i, holder))
+            except capi.KshError as e:
+                assert e.code == 9
+    for i in range(n_sets):
+        assert np.array_equal(dkss.get_kmers(i), sets[i])
+    # every node is held somewhere: gather the held lists
+    mine = torch.zeros(okss.size(), dtype=torch.int64)
+    mine[held] = 1
+    dist.all_reduce(mine)
+    assert int(mine.min()) >= 1
+    n_enc = torch.tensor([dkss.stats()["n_encodes"]], dtype=torch.int64)
+    all_enc = [torch.zeros_like(n_enc) for _ in range(world)]
+    dist.all_gather(all_enc, n_enc)
+    if rank == 0:
+        print(json.dumps({"ok": True, "iterations": int(len(it)), "nodes": okss.size(),
+                          "encodes_per_rank": [int(x) for x in all_enc]}))
+    dkss.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -94,3 +94,26 @@ def test_set_union(ctx):
     e = capi.DeviceSet.from_kmers(g, np.zeros(0, dtype=np.uint64), ctx.device)
     assert np.array_equal(ctx.set_union(e, a).kmers(), sets[0])
     assert np.array_equal(ctx.set_union(a, a).kmers(), sets[0])
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_build(gpu, world):
+    """ksh_kss_build_sharded with `world` processes (all on this GPU, gloo for the exchange): every
+    rank reproduces the oracle's trace, checkpoints, DAG and sets; each node's SPSS is held by,
+    and equal to the oracle's on, exactly one rank (tests/dist_kss_worker.py does the checks)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29541 + world),
+           os.path.join(here, "dist_kss_worker.py"), "15", "14", "2", "8", "20000", "3"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [x for x in r.stdout.splitlines() if x.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["ok"] and res["iterations"] > 0
+    assert sum(res["encodes_per_rank"]) > 0 and min(res["encodes_per_rank"]) > 0   # the encodes were shared

@@ -255,7 +255,7 @@ int ksh_kss_build(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* inputs, 
                   ksh_kss** out);
 /* Multi-GPU build, one process per GPU.  Every rank calls this with the same inputs and runs the
  * same (deterministic) loop on its own resident copies of the sets; the SPSS encodes, ~85 % of
- * the loop's time, are dealt out node by node (node i -> rank i % world), and at every point
+ * the loop's time, are dealt out node by node (largest set first, to the least loaded rank), and at every point
  * where the loop reads the SPSS weights (kmer_set_set.h:287 and the end) the ranks exchange
  * (n_strings, n_bases) of the freshly encoded nodes through `gather`: an all-gather of `count`
  * int64 per rank into recv[world * count], rank-major, returning 0 on success (RCCL or any other

@@ -17,6 +17,7 @@
 #include <cstring>
 #include <map>
 #include <queue>
+#include <algorithm>
 #include <utility>
 #include <vector>
 
@@ -131,16 +132,31 @@ static int ensure_compacts(ksh_kss* k) {
     return KSH_OK;
   }
   // Sharded: the stale nodes (the same list on every rank, the loop being deterministic) are
-  // dealt out round robin; a rank encodes its share and all ranks exchange what the loop reads,
+  // dealt out; a rank encodes its share and all ranks exchange what the loop reads,
   // (n_strings, n_bases) per node.
   std::vector<size_t> stale;
   for (size_t i = 0; i < k->compacts.size(); i++)
     if (!k->compacts[i].valid) stale.push_back(i);
   if (stale.empty()) return KSH_OK;
   std::vector<int64_t> send(2 * stale.size(), -1), recv(2 * stale.size() * size_t(k->world), -1);
+  // longest-processing-time deal: the largest set first, each to the rank with the least k-mers
+  // so far (ties: the lower rank); encode cost follows the set size.  Same answer on every rank.
+  std::vector<size_t> order(stale.size());
+  for (size_t q = 0; q < order.size(); q++) order[q] = q;
+  std::stable_sort(order.begin(), order.end(),
+                   [&](size_t a, size_t b) { return k->sets[stale[a]].n > k->sets[stale[b]].n; });
+  std::vector<int64_t> load(size_t(k->world), 0);
+  std::vector<int> holder_of(stale.size(), 0);
+  for (size_t q : order) {
+    int best = 0;
+    for (int r = 1; r < k->world; r++)
+      if (load[size_t(r)] < load[size_t(best)]) best = r;
+    holder_of[q] = best;
+    load[size_t(best)] += k->sets[stale[q]].n + 1;
+  }
   for (size_t q = 0; q < stale.size(); q++) {
     const size_t i = stale[q];
-    const int holder = int(i % size_t(k->world));
+    const int holder = holder_of[q];
     KssCompact c;
     if (holder == k->rank) {
       KSH_TRY(encode_set(k->ctx, &k->g, k->sets[i], &c));

@@ -51,7 +51,7 @@ def main():
             assert dkss.node_strings(i) == node.strings(), "node %d" % i
             held.append(i)
         else:
-            assert holder == i % world
+            assert 0 <= holder < world
             try:
                 dkss.node_strings(i)
                 raise AssertionError("node %d should be held by rank %d only" % (i, holder))

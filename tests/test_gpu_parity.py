@@ -129,6 +129,21 @@ def test_pair_algebra_edge_cases(ctx, geom):
     top = (np.uint64(1) << np.uint64(2 * k)) - np.uint64(1)
     hi = top - np.arange(0, 3000, dtype=np.uint64)[::-1]
     check_algebra(ctx, k, n, kb, hi, hi[::3].copy(), use_oracle=False)
+    # the batch form (all pairs tiled together, one count and one write launch) on a mix of
+    # empty, identical, heavy-bucket and ordinary pairs, against the pair-at-a-time form
+    other = synth.phylogeny_sets(k, 2, 5000, seed=1)[1]
+    members = [empty, some, other, dense[:30000], dense[10000:], hi]
+    d = [dev_set(ctx, k, n, x) for x in members]
+    pairs = [(0, 0), (0, 1), (1, 0), (1, 1), (1, 2), (3, 4), (4, 3), (5, 1), (2, 5)]
+    got = ctx.pair_algebra_batch([(d[i], d[j]) for i, j in pairs])
+    for (i, j), trio in zip(pairs, got):
+        want = (np.intersect1d(members[i], members[j]), np.setdiff1d(members[i], members[j]),
+                np.setdiff1d(members[j], members[i]))
+        for s_, w in zip(trio, want):
+            assert s_.n_keys == w.size
+            off, keys = s_.to_numpy()
+            w_off, w_keys = synth.to_bucketed(w, k, n, s_.g.key_bytes)
+            assert np.array_equal(off, w_off) and np.array_equal(keys, w_keys)
 
 
 def test_pair_weights_vs_oracle(ctx):

@@ -124,10 +124,14 @@ def main():
             results = [algebra(sets[i], sets[j]) for (i, j) in pairs]
         else:
             results = ctx.pair_algebra_batch([(sets[i], sets[j]) for (i, j) in pairs])
-        for (i, j), (inter, amb, bma) in zip(pairs, results):
-            diffs.append(amb.n_keys + bma.n_keys)
+        if hasattr(results, "totals"):      # the batch result: sizes without touching the sets
+            sizes = [(int(t[1]), int(t[2])) for t in results.totals]
+        else:
+            sizes = [(amb.n_keys, bma.n_keys) for (_inter, amb, bma) in results]
+        for (i, j), (n_amb, n_bma) in zip(pairs, sizes):
+            diffs.append(n_amb + n_bma)
             if record:
-                union = sets[i].n_keys + bma.n_keys
+                union = sets[i].n_keys + n_bma
                 algo_bytes[0] += (sets[i].n_keys + sets[j].n_keys + union) * g.key_bytes
         if world > 1:
             slot = step_no[0] & 1

@@ -873,13 +873,28 @@ int pair_algebra_batch_t(ksh_ctx* ctx, const ksh_geom* g, ksh_pair_job* jobs, in
   int64_t* d_totals = static_cast<int64_t*>(arena_alloc(ctx, size_t(n_jobs) * 24));
   char* base = static_cast<char*>(arena_alloc(ctx, plan_bytes(n_segs, max_tiles)));
   if (!d_pairs || !d_totals || !base) return fail(KSH_INTERNAL, "scratch arena too small");
-  std::vector<BatchPair> h_pairs(static_cast<size_t>(n_jobs));
+  // the pair records and, later, the totals travel through one pinned buffer (a pageable source
+  // would be staged by the runtime first); the stream is synchronised before this call returns,
+  // so the buffer is free again by then
+  const size_t n_vals = static_cast<size_t>(n_jobs) * 3;
+  static_assert(sizeof(BatchPair) % 8 == 0, "pair records are whole int64 words");
+  const size_t pair_words = size_t(n_jobs) * sizeof(BatchPair) / 8;
+  const size_t pinned_words = pair_words + n_vals;  // records, then totals
+  if (ctx->h_batch_count < pinned_words) {
+    if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
+    ctx->h_batch = nullptr;
+    ctx->h_batch_count = 0;
+    if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_batch), pinned_words * 2 * sizeof(int64_t)) != hipSuccess)
+      return fail(KSH_INTERNAL, "hipHostMalloc failed");
+    ctx->h_batch_count = pinned_words * 2;
+  }
+  BatchPair* h_pairs = reinterpret_cast<BatchPair*>(ctx->h_batch);
   for (int32_t i = 0; i < n_jobs; i++) {
     const ksh_pair_job& j = jobs[i];
     h_pairs[i] = BatchPair{j.a.d_keys, j.a.d_offsets, j.b.d_keys, j.b.d_offsets, j.d_off_i, j.d_off_amb,
                            j.d_off_bma, j.d_keys_i, j.d_keys_amb, j.d_keys_bma, 0};
   }
-  KSH_HIP(hipMemcpyAsync(d_pairs, h_pairs.data(), size_t(n_jobs) * sizeof(BatchPair), hipMemcpyHostToDevice,
+  KSH_HIP(hipMemcpyAsync(d_pairs, h_pairs, size_t(n_jobs) * sizeof(BatchPair), hipMemcpyHostToDevice,
                          ctx->stream));
   Plan p;
   plan_carve(base, n_segs, max_tiles, &p);
@@ -895,21 +910,11 @@ int pair_algebra_batch_t(ksh_ctx* ctx, const ksh_geom* g, ksh_pair_job* jobs, in
                                g->n_bucket_bits);
   }
   KSH_HIP(hipGetLastError());
-  const size_t n_vals = static_cast<size_t>(n_jobs) * 3;
-  int64_t* h = ctx->h_pinned;  // 64 values
-  if (n_vals > 64) {
-    if (ctx->h_batch_count < n_vals) {
-      if (ctx->h_batch) (void)hipHostFree(ctx->h_batch);
-      ctx->h_batch = nullptr;
-      ctx->h_batch_count = 0;
-      if (hipHostMalloc(reinterpret_cast<void**>(&ctx->h_batch), n_vals * 2 * sizeof(int64_t)) != hipSuccess)
-        return fail(KSH_INTERNAL, "hipHostMalloc failed");
-      ctx->h_batch_count = n_vals * 2;
-    }
-    h = ctx->h_batch;
-  }
+  // the totals land behind the pair records (still being read by the copy above until the
+  // stream gets there: stream order keeps the two apart)
+  int64_t* h = ctx->h_batch + pair_words;
   KSH_HIP(hipMemcpyAsync(h, d_totals, n_vals * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream));
-  KSH_HIP(hipStreamSynchronize(ctx->stream));  // also keeps h_pairs alive long enough
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
   for (int32_t i = 0; i < n_jobs; i++)
     for (int q = 0; q < 3; q++) jobs[i].totals[q] = h[size_t(3 * i + q)];
   return KSH_OK;

@@ -273,6 +273,35 @@ class DeviceSpss:
         return self.n_bases
 
 
+class BatchResult:
+    """Results of Context.pair_algebra_batch: indexable / iterable as [(A & B, A \\ B, B \\ A), ...];
+    the DeviceSet objects (slices of the two batch-wide allocations) are made on first access."""
+
+    def __init__(self, g, off_rows, key_pool, starts, byte_caps, totals):
+        self.g, self.off_rows, self.key_pool, self.starts, self.byte_caps = g, off_rows, key_pool, starts, byte_caps
+        self.totals = totals
+        self._made = {}
+
+    def __len__(self):
+        return self.totals.shape[0]
+
+    def __getitem__(self, idx):
+        if idx < 0:
+            idx += len(self)
+        if idx not in self._made:
+            trio = []
+            for r in range(3):
+                s_ = DeviceSet.carved(self.g, self.off_rows, 3 * idx + r, self.key_pool,
+                                      int(self.starts[3 * idx + r]), int(self.byte_caps[idx, r]))
+                s_.n_keys = int(self.totals[idx, r])
+                trio.append(s_)
+            self._made[idx] = trio
+        return self._made[idx]
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
 class Context:
     """ksh_ctx on one GPU; its stream becomes torch's current stream on that device."""
 
@@ -491,36 +520,35 @@ class Context:
         return d_out[:n].cpu().numpy().view(np.uint32), used.value
 
     def pair_algebra_batch(self, pairs):
-        """[(A, B), ...] -> [(A & B, A \\ B, B \\ A), ...]: all pairs enqueued back to back, one
-        stream synchronisation for every pair's sizes (ksh_pair_algebra_batch)."""
+        """[(A, B), ...] -> [(A & B, A \\ B, B \\ A), ...]: every pair of the batch tiled together, one
+        count launch, one write launch and one stream synchronisation for all sizes
+        (ksh_pair_algebra_batch).  The result behaves like that list; `.totals` is the int64
+        array [pair][|A&B|, |A\\B|, |B\\A|] for callers that only need the sizes."""
         import torch
 
         g = pairs[0][0].g
         kb = g.key_bytes
-        jobs = (PairJob * len(pairs))()
-        # one offsets block and one key pool for the whole batch, carved by pointer arithmetic
-        caps = [(min(a.n_keys, b.n_keys), a.n_keys, b.n_keys) for a, b in pairs]
-        starts, at = [], 0
-        for trio in caps:
-            for cap in trio:
-                starts.append(at)
-                at += (max(cap * kb, 16) + 255) & ~255
-        off_rows = torch.empty((3 * len(pairs), (1 << g.n_bucket_bits) + 1), dtype=torch.int64, device=self.device)
-        key_pool = torch.empty(at, dtype=torch.uint8, device=self.device)
-        outs = []
+        n = len(pairs)
+        # the job records as one int64 table with PairJob's layout (15 eight-byte fields):
+        # a.{offsets, keys, n}, b.{offsets, keys, n}, 3 offset pointers, 3 key pointers, 3 totals
+        assert C.sizeof(PairJob) == 15 * 8
+        jobs = np.zeros((n, 15), dtype=np.int64)
         for idx, (a, b) in enumerate(pairs):
-            trio = [DeviceSet.carved(g, off_rows, 3 * idx + r, key_pool, starts[3 * idx + r],
-                                     max(caps[idx][r] * kb, 16)) for r in range(3)]
-            outs.append(trio)
-            j = jobs[idx]
-            j.a, j.b = a.view(), b.view()
-            (j.d_off_i, j.d_keys_i), (j.d_off_amb, j.d_keys_amb), (j.d_off_bma, j.d_keys_bma) = (
-                t.pointers() for t in trio)
-        check(lib().ksh_pair_algebra_batch(self.h, C.byref(g), jobs, len(pairs)))
-        for idx, trio in enumerate(outs):
-            for o, n in zip(trio, jobs[idx].totals):
-                o.n_keys = int(n)
-        return outs
+            jobs[idx, 0:2] = a.pointers()
+            jobs[idx, 2] = a.n_keys
+            jobs[idx, 3:5] = b.pointers()
+            jobs[idx, 5] = b.n_keys
+        caps = np.stack([np.minimum(jobs[:, 2], jobs[:, 5]), jobs[:, 2], jobs[:, 5]], axis=1)
+        sizes = (np.maximum(caps * kb, 16) + 255) & ~255          # bytes reserved per result
+        starts = np.concatenate(([0], np.cumsum(sizes.reshape(-1))))
+        # one offsets block and one key pool for the whole batch, carved by pointer arithmetic
+        nb1 = (1 << g.n_bucket_bits) + 1
+        off_rows = torch.empty((3 * n, nb1), dtype=torch.int64, device=self.device)
+        key_pool = torch.empty(int(starts[-1]), dtype=torch.uint8, device=self.device)
+        jobs[:, 6:9] = off_rows.data_ptr() + 8 * nb1 * np.arange(3 * n, dtype=np.int64).reshape(n, 3)
+        jobs[:, 9:12] = key_pool.data_ptr() + starts[:-1].reshape(n, 3)
+        check(lib().ksh_pair_algebra_batch(self.h, C.byref(g), C.cast(jobs.ctypes.data, C.POINTER(PairJob)), n))
+        return BatchResult(g, off_rows, key_pool, starts, np.maximum(caps * kb, 16), jobs[:, 12:15].copy())
 
     def set_union(self, a, b):
         """KmerSet::Add: A | B as a new DeviceSet."""

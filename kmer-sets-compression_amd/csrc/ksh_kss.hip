@@ -188,14 +188,36 @@ static int pair_weights(ksh_kss* k, const std::vector<int32_t>& ids,
                         const std::vector<std::pair<int, int>>& pairs, std::vector<int64_t>* out) {
   std::vector<ksh_set_view> views;
   for (const KssSet& s : k->sets) views.push_back(view_of(s));
-  std::vector<int32_t> flat;
-  for (const auto& p : pairs) {
-    flat.push_back(p.first);
-    flat.push_back(p.second);
-  }
   out->assign(pairs.size(), 0);
-  return ksh_pair_weights(k->ctx, &k->g, views.data(), int32_t(views.size()), ids.data(),
-                          int32_t(ids.size()), flat.data(), int32_t(pairs.size()), out->data());
+  // Sharded build: the pairs are independent (kmer_set_set.h:205-216), so every rank weighs a
+  // contiguous share of the list and one all-gather of int64 puts the table on all of them.
+  // Small lists are not worth the exchange.
+  size_t lo = 0, hi = pairs.size();
+  const bool shard = k->world > 1 && pairs.size() >= size_t(4 * k->world);
+  const size_t per = (pairs.size() + size_t(k->world) - 1) / size_t(k->world);
+  if (shard) {
+    lo = std::min(pairs.size(), per * size_t(k->rank));
+    hi = std::min(pairs.size(), lo + per);
+  }
+  std::vector<int32_t> flat;
+  for (size_t q = lo; q < hi; q++) {
+    flat.push_back(pairs[q].first);
+    flat.push_back(pairs[q].second);
+  }
+  if (hi > lo)
+    KSH_TRY(ksh_pair_weights(k->ctx, &k->g, views.data(), int32_t(views.size()), ids.data(),
+                             int32_t(ids.size()), flat.data(), int32_t(hi - lo), out->data() + lo));
+  if (!shard) return KSH_OK;
+  std::vector<int64_t> send(per, -1), recv(per * size_t(k->world), -1);
+  for (size_t q = lo; q < hi; q++) send[q - lo] = (*out)[q];
+  if (k->gather(k->gather_user, send.data(), int64_t(per), recv.data()) != 0)
+    return fail(KSH_INTERNAL, "the all-gather callback of the sharded build failed");
+  for (size_t q = 0; q < pairs.size(); q++) {
+    const int64_t w = recv[(q / per) * per + q % per];
+    if (w < 0) return fail(KSH_INTERNAL, "rank %zu did not report the weight of pair %zu", q / per, q);
+    (*out)[q] = w;
+  }
+  return KSH_OK;
 }
 
 // SerializeAdjacencyList (kmer_set_set.h:45-56), keys ascending.

@@ -117,6 +117,7 @@ def main():
         "n_gpus": world,
         "scaling": "strong",
         "encodes_per_rank": encodes,
+        "phase_seconds": st["phase_seconds"],
         "config": {"workload": "%d canonical k=%d sets of %d k-mers, full KmerSetSet loop" % (n_sets, k, size),
                    "input_build_s": t_inputs,
                    "parallelism": "1 GPU" if world == 1 else

@@ -272,6 +272,9 @@ int ksh_kss_node_holder(const ksh_kss* k, int32_t i, int32_t* rank);
 /* SPSS encodes this process ran for the build, and the k-mers they covered (the sharded build's
  * balance; in a single-GPU build: how many encodes the deferral left). */
 int ksh_kss_encode_counts(const ksh_kss* k, int64_t* n_encodes, int64_t* n_encoded_kmers);
+/* Wall seconds the build spent in: [0] decode of the inputs, [1] weight computations,
+ * [2] merges (pair plan + write), [3] SPSS encodes (with, in a sharded build, the exchanges). */
+int ksh_kss_phase_seconds(const ksh_kss* k, double seconds[4]);
 int ksh_kss_destroy(ksh_kss* k);
 /* KmerSetSet::Size (:430): number of nodes. */
 int ksh_kss_size(const ksh_kss* k, int32_t* n_nodes);

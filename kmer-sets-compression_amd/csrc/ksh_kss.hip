@@ -18,6 +18,7 @@
 #include <map>
 #include <queue>
 #include <algorithm>
+#include <chrono>
 #include <utility>
 #include <vector>
 
@@ -50,6 +51,7 @@ struct ksh_kss {
   int64_t initial_total_size = 0, final_total_size = 0, initial_spss_weight = 0, n_processed = 0;
   int64_t final_spss_weight = 0;
   int64_t n_encodes = 0, n_encoded_kmers = 0;
+  double phase_seconds[4] = {0, 0, 0, 0};  // decode of the inputs, weights, merges, encodes
   std::string meta;
   // sharded build (ksh_kss_build_sharded): every rank runs the same loop on resident copies of
   // the sets; the SPSS encodes, the dominant cost, are dealt out node by node
@@ -59,6 +61,20 @@ struct ksh_kss {
 };
 
 namespace ksh {
+
+// Wall time per phase of the build (decode of the inputs, weights, merges, encodes), for the
+// shares quoted in DESIGN.md.  Every phase is closed by a stream synchronisation, which the
+// loop needs at those points anyway (each ends in a read-back), so the timers cost nothing.
+struct PhaseTimer {
+  ksh_kss* k;
+  int kind;
+  std::chrono::steady_clock::time_point t0;
+  PhaseTimer(ksh_kss* kss, int which) : k(kss), kind(which), t0(std::chrono::steady_clock::now()) {}
+  ~PhaseTimer() {
+    (void)hipStreamSynchronize(k->ctx->stream);
+    k->phase_seconds[kind] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+};
 
 static void free_set(ksh_ctx* ctx, KssSet* s) {
   pool_free(ctx, s->off);
@@ -246,7 +262,10 @@ static int build(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs,
     KSH_TRY(ksh_spss_size(ctx, g, &inputs[i], &c.size));
     k->compacts.push_back(c);
     k->sets.emplace_back();
-    KSH_TRY(decode_to_set(ctx, g, &inputs[i], k->canonical, &k->sets.back()));
+    {
+      PhaseTimer pt(k, 0);
+      KSH_TRY(decode_to_set(ctx, g, &inputs[i], k->canonical, &k->sets.back()));
+    }
   }
 
   std::map<std::pair<int, int>, int64_t> weights;
@@ -255,7 +274,10 @@ static int build(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs,
     for (int i = 0; i < n_inputs; i++)
       for (int j = i + 1; j < n_inputs; j++) pairs.emplace_back(i, j);
     std::vector<int64_t> w;
-    KSH_TRY(pair_weights(k, ids, pairs, &w));
+    {
+      PhaseTimer pt(k, 1);
+      KSH_TRY(pair_weights(k, ids, pairs, &w));
+    }
     for (size_t i = 0; i < pairs.size(); i++) weights[pairs[i]] = w[i];
     k->initial_weights = w;
   }
@@ -266,6 +288,7 @@ static int build(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs,
   k->n_processed = total_size;
 
   const auto total_spss_weight_now = [&](int64_t* total) {
+    PhaseTimer pt(k, 3);
     KSH_TRY(ensure_compacts(k));
     *total = 0;
     for (const KssCompact& c : k->compacts) *total += c.n_bases;
@@ -310,11 +333,14 @@ static int build(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs,
       KSH_TRY(alloc_offsets(ctx, g, &sj));
       KSH_TRY(alloc_offsets(ctx, g, &sk));
       int64_t totals[3];
-      KSH_TRY(ksh_pair_plan(ctx, g, &vj, &vk, sn.off, sj.off, sk.off, totals));
-      KSH_TRY(alloc_keys(ctx, g, totals[0], &sn));
-      KSH_TRY(alloc_keys(ctx, g, totals[1], &sj));
-      KSH_TRY(alloc_keys(ctx, g, totals[2], &sk));
-      KSH_TRY(ksh_pair_write(ctx, g, &vj, &vk, sn.keys, sj.keys, sk.keys));
+      {
+        PhaseTimer pt(k, 2);
+        KSH_TRY(ksh_pair_plan(ctx, g, &vj, &vk, sn.off, sj.off, sk.off, totals));
+        KSH_TRY(alloc_keys(ctx, g, totals[0], &sn));
+        KSH_TRY(alloc_keys(ctx, g, totals[1], &sj));
+        KSH_TRY(alloc_keys(ctx, g, totals[2], &sk));
+        KSH_TRY(ksh_pair_write(ctx, g, &vj, &vk, sn.keys, sj.keys, sk.keys));
+      }
 
       KssCompact cn, cj, ck;  // encoded lazily (ensure_compacts)
       cn.valid = cj.valid = ck.valid = false;
@@ -353,7 +379,10 @@ static int build(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs,
       }
       for (int l = 0; l < n; l++) pairs.emplace_back(l, n);
       std::vector<int64_t> w;
-      KSH_TRY(pair_weights(k, ids, pairs, &w));
+      {
+        PhaseTimer pt(k, 1);
+        KSH_TRY(pair_weights(k, ids, pairs, &w));
+      }
       for (size_t q = 0; q < pairs.size(); q++) weights[pairs[q]] = w[q];
     }
   }
@@ -429,6 +458,12 @@ int ksh_kss_encode_counts(const ksh_kss* k, int64_t* n_encodes, int64_t* n_encod
   if (!k || !n_encodes || !n_encoded_kmers) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
   *n_encodes = k->n_encodes;
   *n_encoded_kmers = k->n_encoded_kmers;
+  return KSH_OK;
+}
+
+int ksh_kss_phase_seconds(const ksh_kss* k, double seconds[4]) {
+  if (!k || !seconds) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  for (int i = 0; i < 4; i++) seconds[i] = k->phase_seconds[i];
   return KSH_OK;
 }
 

@@ -125,6 +125,7 @@ def lib():
                                             i32, i32, i32, GATHER_FN, vp, C.POINTER(vp)]),
         "ksh_kss_node_holder": (C.c_int, [vp, i32, C.POINTER(i32)]),
         "ksh_kss_encode_counts": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
+        "ksh_kss_phase_seconds": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "ksh_kss_destroy": (C.c_int, [vp]),
         "ksh_kss_size": (C.c_int, [vp, C.POINTER(i32)]),
         "ksh_kss_node": (C.c_int, [vp, i32, C.POINTER(SpssView), SP, C.POINTER(i64)]),
@@ -722,6 +723,9 @@ class DeviceKmerSetSet:
         ne, nk = C.c_int64(), C.c_int64()
         check(lib().ksh_kss_encode_counts(self.h, C.byref(ne), C.byref(nk)))
         out["n_encodes"], out["n_encoded_kmers"] = ne.value, nk.value
+        ph = (C.c_double * 4)()
+        check(lib().ksh_kss_phase_seconds(self.h, ph))
+        out["phase_seconds"] = dict(zip(["decode_inputs", "weights", "merges", "encodes"], [float(x) for x in ph]))
         return out
 
     def get_kmers(self, i):

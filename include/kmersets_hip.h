@@ -51,7 +51,10 @@ typedef struct ksh_geom {
   int32_t reserved;
 } ksh_geom;
 
-/* One k-mer set resident in HBM. */
+/* One k-mer set resident in HBM.  d_keys is 16-byte aligned and its allocation runs to a
+ * multiple of 16 bytes (ksh_malloc, hipMalloc and torch all round up further): the merge
+ * kernels read whole 16-byte vectors, so the last vector of a key array may reach up to 12
+ * bytes past its last key (never into another allocation's bytes they would use). */
 typedef struct ksh_set_view {
   const int64_t* d_offsets; /* int64[2^N + 1]                */
   const void* d_keys;       /* key_bytes * n_keys bytes      */

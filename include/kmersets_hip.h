@@ -121,8 +121,9 @@ int ksh_pair_algebra(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, con
                      void* d_keys_amb, void* d_keys_bma, int64_t totals[3]);
 
 /* Many independent pairs (a pairwise diff matrix, the reference's pooled loops over pairs,
- * lib/core/kmer_set_set.h:205-216): every pair's two passes are enqueued back to back and one
- * stream synchronisation returns all totals.  Buffers as for ksh_pair_algebra. */
+ * lib/core/kmer_set_set.h:205-216): the buckets of all pairs are tiled together, so the batch is
+ * one plan, one count launch and one write launch, and one stream synchronisation returns all
+ * totals.  Buffers as for ksh_pair_algebra. */
 typedef struct ksh_pair_job {
   ksh_set_view a, b;
   int64_t *d_off_i, *d_off_amb, *d_off_bma; /* int64[2^N + 1] each                         */

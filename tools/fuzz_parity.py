@@ -1,0 +1,151 @@
+"""Randomised differential testing of the HIP path against numpy / the oracle: many seeds,
+geometries, sizes and key distributions (uniform, clustered, dense runs, near-identical sets),
+through every form of the pair algebra (plan + write, one call, batch), the union, the sampled
+weights, SPSS encode / decode / text round trips and k-mer counting.  Not part of the pytest
+suites (it runs for minutes); prints one summary line.
+
+    python tools/fuzz_parity.py --seconds 300 --seed 1
+"""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+sys.path.insert(0, os.path.join(ROOT, "kmer-sets-compression_amd"))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import oracle_lib as ol  # noqa: E402
+from kmersets import capi, synth  # noqa: E402
+
+GEOMS = [(5, 3, 1), (9, 10, 1), (15, 14, 2), (19, 10, 4), (23, 14, 4), (31, 14, 8)]
+
+
+def random_set(rng, k, n_bits, size, kind):
+    space = 4 ** k
+    size = int(min(size, space // 3))
+    if kind == "uniform":
+        x = rng.integers(0, space, size=size, dtype=np.uint64)
+    elif kind == "clustered":     # a few buckets hold almost everything, long runs of neighbours
+        centres = rng.integers(0, space, size=max(1, size // 2000), dtype=np.uint64)
+        x = (centres[rng.integers(0, centres.size, size=size)] + rng.integers(0, 5000, size=size).astype(np.uint64)) % np.uint64(space)
+    elif kind == "dense":         # consecutive values: every tile boundary falls inside runs
+        start = rng.integers(0, max(1, space - 3 * size), dtype=np.uint64)
+        x = start + np.arange(size, dtype=np.uint64) * np.uint64(rng.integers(1, 3))
+    else:                         # canonical k-mers of a random genome
+        x = synth.phylogeny_sets(k, 1, size, seed=int(rng.integers(0, 1 << 30)))[0]
+    return np.unique(x.astype(np.uint64))
+
+
+def related(rng, a, k, frac_keep, frac_new):
+    keep = a[rng.random(a.size) < frac_keep]
+    new = rng.integers(0, 4 ** k, size=int(a.size * frac_new), dtype=np.uint64)
+    return np.unique(np.concatenate([keep, new]))
+
+
+def expect_sets(got_trio, want_trio, k, n):
+    for s_, w in zip(got_trio, want_trio):
+        assert s_.n_keys == w.size, (s_.n_keys, w.size)
+        off, keys = s_.to_numpy()
+        w_off, w_keys = synth.to_bucketed(w, k, n, s_.g.key_bytes)
+        assert np.array_equal(off, w_off) and np.array_equal(keys, w_keys)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=120)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    ctx = capi.Context(0)
+    t_end = time.time() + args.seconds
+    n_cases = {"algebra": 0, "spss": 0, "count": 0}
+    while time.time() < t_end:
+        k, n, kb = GEOMS[int(rng.integers(0, len(GEOMS)))]
+        g = capi.geom(k, n)
+        kind = ["uniform", "clustered", "dense", "genome"][int(rng.integers(0, 4))]
+        size = int(10 ** rng.uniform(1.5, 5.7))
+        a = random_set(rng, k, n, size, kind)
+        members = [a, related(rng, a, k, rng.uniform(0, 1), rng.uniform(0, 0.5)),
+                   related(rng, a, k, 1.0, 0.0), np.zeros(0, dtype=np.uint64)]
+        if rng.random() < 0.5:
+            members.append(random_set(rng, k, n, int(10 ** rng.uniform(1, 5)), "uniform"))
+        d = [capi.DeviceSet.from_kmers(g, m, ctx.device) for m in members]
+        pairs = [(int(i), int(j)) for i, j in rng.integers(0, len(members), size=(6, 2))]
+        want = {p: (np.intersect1d(members[p[0]], members[p[1]]), np.setdiff1d(members[p[0]], members[p[1]]),
+                    np.setdiff1d(members[p[1]], members[p[0]])) for p in pairs}
+        for p, trio in zip(pairs, ctx.pair_algebra_batch([(d[i], d[j]) for i, j in pairs])):
+            expect_sets(trio, want[p], k, n)
+        i, j = pairs[0]
+        expect_sets(ctx.pair_algebra(d[i], d[j]), want[(i, j)], k, n)
+        expect_sets(ctx.pair_algebra_onepass(d[i], d[j]), want[(i, j)], k, n)
+        u = ctx.set_union(d[i], d[j])
+        assert np.array_equal(u.kmers(), np.union1d(members[i], members[j]))
+        assert ctx.set_diff(d[i], d[j]) == want[(i, j)][1].size + want[(i, j)][2].size
+        assert ctx.set_hash(d[i]) == (int(np.bitwise_xor.reduce(members[i])) if members[i].size else 0)
+        ids = synth.sample_bucket_ids(n, seed=int(rng.integers(0, 1 << 20)))
+        w = ctx.pair_weights(d, ids, pairs)
+        for (pi, pj), got in zip(pairs, w):
+            inter = want[(pi, pj)][0]
+            assert got == int(np.isin(inter >> np.uint64(2 * k - n), np.asarray(ids, dtype=np.uint64)).sum())
+        n_cases["algebra"] += 1
+
+        # SPSS: encode == oracle, decode and text round trips (sizes the oracle handles quickly)
+        if a.size <= 60000 and k >= 5:
+            km = synth.phylogeny_sets(k, 1, min(size, 40000), seed=int(rng.integers(0, 1 << 30)))[0] if kind != "genome" else a
+            if rng.random() < 0.5:   # a fragmented set: many short unitigs, tips and bubbles
+                km = km[rng.random(km.size) < rng.uniform(0.3, 0.95)]
+            oset = ol.Set.from_kmers(k, n, kb, km)
+            ds = capi.DeviceSet.from_kmers(g, km, ctx.device)
+            sp = ctx.spss_encode(ds, mode=0)
+            strings = oset.spss()
+            assert sp.to_strings() == strings
+            assert ctx.spss_encode(ds, mode=1).to_strings() == oset.unitigs()
+            back = ctx.spss_decode(sp)
+            assert back.n_keys == ds.n_keys and ctx.set_diff(back, ds) == 0
+            if k >= 5 and strings:
+                text = ctx.spss_to_text(sp)
+                assert bytes(text.cpu().numpy().tobytes()) == "".join(x + "\n" for x in strings).encode()
+                again = ctx.spss_from_text(g, text)
+                assert again.to_strings() == strings
+            n_cases["spss"] += 1
+
+        # counting: random reads with N's against the oracle
+        if k >= 5 and rng.random() < 0.5:
+            genome = rng.integers(0, 4, size=int(rng.integers(k + 1, 3000)))
+            reads = []
+            for _ in range(int(rng.integers(1, 120))):
+                p0 = int(rng.integers(0, genome.size))
+                seq = np.array(list("ACGT"))[genome[p0:p0 + int(rng.integers(0, 200))]].copy()
+                if seq.size and rng.random() < 0.4:
+                    seq[int(rng.integers(0, seq.size))] = "N"
+                reads.append("".join(seq))
+            text = "".join(">%d\n%s\n" % (q, r) for q, r in enumerate(reads)).encode()
+            if rng.random() < 0.3:
+                text = text[:-1]
+            canonical = bool(rng.integers(0, 2))
+            t = torch.frombuffer(bytearray(text), dtype=torch.uint8).to(ctx.device)
+            status = ol.Counter(k, n, kb).from_fasta(text, canonical=canonical)
+            if status != 0:      # e.g. an empty last read whose newline was cut: an odd number of lines
+                try:
+                    ctx.fasta_fragments(g, t)
+                    raise AssertionError("the oracle rejects this FASTA text (%d), the device accepted it" % status)
+                except capi.KshError as e:
+                    assert e.code == 9
+                n_cases["count"] += 1
+                continue
+            frags = ctx.fasta_fragments(g, t)
+            for cutoff in (1, int(rng.integers(2, 6))):
+                oc = ol.Counter(k, n, kb)
+                assert oc.from_fasta(text, canonical=canonical) == 0
+                want_set, want_cut = oc.to_set(cutoff)
+                got, n_cut = ctx.kmer_count(frags, cutoff, canonical=canonical)
+                assert n_cut == want_cut and np.array_equal(got.kmers(), want_set.kmers())
+            n_cases["count"] += 1
+    print("fuzz ok: seed %d, %.0f s, cases %s" % (args.seed, args.seconds, n_cases))
+
+
+if __name__ == "__main__":
+    main()

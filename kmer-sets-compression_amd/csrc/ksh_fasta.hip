@@ -13,6 +13,7 @@
 //   fragment [start, end) positions       -> length, kept?, scans (output string index / base)
 //   kept bases per chunk -> scan          -> pack through LDS
 // gfx950 only.
+#include "ksh_bytes.h"
 #include "ksh_internal.h"
 
 #include <algorithm>
@@ -32,13 +33,12 @@ __device__ __forceinline__ bool is_acgt(unsigned char ch) { return ch == 'A' || 
 
 __global__ __launch_bounds__(256) void k_fa_newlines(const unsigned char* __restrict__ text, int64_t n,
                                                       int64_t* __restrict__ counts) {
+  __shared__ unsigned char lds[kChunkLds];
+  const Chunk ch = stage_chunk(text, n, lds);
+  if (ch.n == 0) return;
   const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  const int64_t n_chunks = (n + kFaChunk - 1) / kFaChunk;
-  if (c >= n_chunks) return;
-  const int64_t b0 = c * kFaChunk;
-  const int n_here = int(std::min<int64_t>(kFaChunk, n - b0));
   int nl = 0;
-  for (int i = 0; i < n_here; i++) nl += text[b0 + i] == '\n';
+  for (int i = 0; i < ch.n; i++) nl += ch.at(i) == '\n';
   counts[c] = nl;
 }
 
@@ -49,23 +49,22 @@ __global__ __launch_bounds__(256) void k_fa_newlines(const unsigned char* __rest
 __global__ __launch_bounds__(256) void k_fa_starts(const unsigned char* __restrict__ text, int64_t n,
                                                     const int64_t* __restrict__ nl_before,
                                                     int64_t* __restrict__ starts, int* __restrict__ flags) {
+  __shared__ unsigned char lds[kChunkLds];
+  const Chunk ch = stage_chunk(text, n, lds);
+  if (ch.n == 0) return;
   const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  const int64_t n_chunks = (n + kFaChunk - 1) / kFaChunk;
-  if (c >= n_chunks) return;
-  const int64_t b0 = c * kFaChunk;
-  const int n_here = int(std::min<int64_t>(kFaChunk, n - b0));
   int64_t line = nl_before[c];
-  unsigned char prev = b0 > 0 ? text[b0 - 1] : '\n';
+  unsigned char prev = ch.prev;
   int n_start = 0;
   bool bad = false;
-  for (int i = 0; i < n_here; i++) {
-    const unsigned char ch = text[b0 + i];
+  for (int i = 0; i < ch.n; i++) {
+    const unsigned char b = ch.at(i);
     const bool read_line = line & 1;
-    if (prev == '\n' && !read_line && ch != '>') bad = true;  // also catches an empty header line
-    if (read_line && !(is_acgt(ch) || ch == 'N' || ch == '\n')) bad = true;
-    if (read_line && is_acgt(ch) && !is_acgt(prev)) n_start++;  // prev is on the same line or '\n'
-    line += ch == '\n';
-    prev = ch;
+    if (prev == '\n' && !read_line && b != '>') bad = true;  // also catches an empty header line
+    if (read_line && !(is_acgt(b) || b == 'N' || b == '\n')) bad = true;
+    if (read_line && is_acgt(b) && !is_acgt(prev)) n_start++;  // prev is on the same line or '\n'
+    line += b == '\n';
+    prev = b;
   }
   starts[c] = n_start;
   if (bad) atomicOr(flags, 1);
@@ -79,23 +78,23 @@ __global__ __launch_bounds__(256) void k_fa_ranges(const unsigned char* __restri
                                                     const int64_t* __restrict__ starts_before,
                                                     int64_t* __restrict__ frag_start,
                                                     int64_t* __restrict__ frag_end) {
+  __shared__ unsigned char lds[kChunkLds];
+  const Chunk ch = stage_chunk(text, n, lds);
+  if (ch.n == 0) return;
   const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  const int64_t n_chunks = (n + kFaChunk - 1) / kFaChunk;
-  if (c >= n_chunks) return;
   const int64_t b0 = c * kFaChunk;
-  const int n_here = int(std::min<int64_t>(kFaChunk, n - b0));
   int64_t line = nl_before[c];
-  unsigned char prev = b0 > 0 ? text[b0 - 1] : '\n';
+  unsigned char prev = ch.prev;
   int64_t r = starts_before[c];  // index of the next fragment to start
-  for (int i = 0; i < n_here; i++) {
-    const unsigned char ch = text[b0 + i];
+  for (int i = 0; i < ch.n; i++) {
+    const unsigned char b = ch.at(i);
     const bool read_line = line & 1;
-    const bool base = read_line && is_acgt(ch);
+    const bool base = read_line && is_acgt(b);
     if (base && !is_acgt(prev)) frag_start[r++] = b0 + i;
-    const unsigned char next = b0 + i + 1 < n ? text[b0 + i + 1] : '\n';
+    const unsigned char next = i + 1 < ch.n ? ch.at(i + 1) : ch.next;
     if (base && !is_acgt(next)) frag_end[r - 1] = b0 + i + 1;  // r - 1: the fragment holding byte i
-    line += ch == '\n';
-    prev = ch;
+    line += b == '\n';
+    prev = b;
   }
 }
 
@@ -116,27 +115,27 @@ __global__ __launch_bounds__(256) void k_fa_kept_bases(const unsigned char* __re
                                                         const int64_t* __restrict__ frag_start,
                                                         const int64_t* __restrict__ frag_end, int k,
                                                         int64_t* __restrict__ kept) {
+  __shared__ unsigned char lds[kChunkLds];
+  const Chunk ch = stage_chunk(text, n, lds);
+  if (ch.n == 0) return;
   const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  const int64_t n_chunks = (n + kFaChunk - 1) / kFaChunk;
-  if (c >= n_chunks) return;
   const int64_t b0 = c * kFaChunk;
-  const int n_here = int(std::min<int64_t>(kFaChunk, n - b0));
   int64_t line = nl_before[c];
-  unsigned char prev = b0 > 0 ? text[b0 - 1] : '\n';
+  unsigned char prev = ch.prev;
   int64_t r = starts_before[c];
   bool keep = false;
   if (b0 > 0 && r > 0) keep = frag_end[r - 1] > b0 && frag_end[r - 1] - frag_start[r - 1] >= k;  // open fragment
   int cnt = 0;
-  for (int i = 0; i < n_here; i++) {
-    const unsigned char ch = text[b0 + i];
-    const bool base = (line & 1) && is_acgt(ch);
+  for (int i = 0; i < ch.n; i++) {
+    const unsigned char b = ch.at(i);
+    const bool base = (line & 1) && is_acgt(b);
     if (base && !is_acgt(prev)) {
       keep = frag_end[r] - frag_start[r] >= k;
       r++;
     }
     cnt += base && keep;
-    line += ch == '\n';
-    prev = ch;
+    line += b == '\n';
+    prev = b;
   }
   kept[c] = cnt;
 }
@@ -162,6 +161,8 @@ __global__ __launch_bounds__(kFaThreads) void k_fa_pack(const unsigned char* __r
                                                          const int64_t* __restrict__ kept_before, int k,
                                                          unsigned long long* __restrict__ words) {
   __shared__ unsigned char codes[kFaSpan + 32];
+  __shared__ unsigned char lds[kChunkLds];
+  const Chunk ch = stage_chunk(text, n, lds);
   const int64_t n_chunks = (n + kFaChunk - 1) / kFaChunk;
   const int64_t first_chunk = int64_t(blockIdx.x) * kFaThreads;
   const int64_t last_chunk = std::min<int64_t>(first_chunk + kFaThreads, n_chunks);  // exclusive
@@ -169,25 +170,24 @@ __global__ __launch_bounds__(kFaThreads) void k_fa_pack(const unsigned char* __r
   const int lead = int(base0 & 31);
   for (int i = threadIdx.x; i < lead; i += kFaThreads) codes[i] = 0;
   const int64_t c = first_chunk + threadIdx.x;
-  if (c < n_chunks) {
+  if (ch.n > 0) {
     const int64_t b0 = c * kFaChunk;
-    const int n_here = int(std::min<int64_t>(kFaChunk, n - b0));
     int64_t line = nl_before[c];
-    unsigned char prev = b0 > 0 ? text[b0 - 1] : '\n';
+    unsigned char prev = ch.prev;
     int64_t r = starts_before[c];
     bool keep = false;
     if (b0 > 0 && r > 0) keep = frag_end[r - 1] > b0 && frag_end[r - 1] - frag_start[r - 1] >= k;
     int at = lead + int(kept_before[c] - base0);
-    for (int i = 0; i < n_here; i++) {
-      const unsigned char ch = text[b0 + i];
-      const bool base = (line & 1) && is_acgt(ch);
+    for (int i = 0; i < ch.n; i++) {
+      const unsigned char b = ch.at(i);
+      const bool base = (line & 1) && is_acgt(b);
       if (base && !is_acgt(prev)) {
         keep = frag_end[r] - frag_start[r] >= k;
         r++;
       }
-      if (base && keep) codes[at++] = ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 0;
-      line += ch == '\n';
-      prev = ch;
+      if (base && keep) codes[at++] = b == 'C' ? 1 : b == 'G' ? 2 : b == 'T' ? 3 : 0;
+      line += b == '\n';
+      prev = b;
     }
   }
   __syncthreads();

@@ -12,6 +12,7 @@
 //             lengths, and every workgroup packs its span of bases into words through LDS
 //             (the two words it shares with its neighbours are ORed in with atomics).
 // gfx950 only.
+#include "ksh_bytes.h"
 #include "ksh_internal.h"
 
 #include <algorithm>
@@ -100,17 +101,16 @@ __global__ __launch_bounds__(kTextThreads) void k_to_text(const uint64_t* __rest
 // flags: bit 0 = a byte that is neither ACGT nor '\n'; bit 1 = a line shorter than K.
 __global__ __launch_bounds__(256) void k_text_count_nl(const unsigned char* __restrict__ text, int64_t n_bytes,
                                                         int64_t* __restrict__ counts, int* __restrict__ flags) {
+  __shared__ unsigned char lds[kChunkLds];
+  const Chunk ch = stage_chunk(text, n_bytes, lds);
+  if (ch.n == 0) return;
   const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  const int64_t n_chunks = (n_bytes + kChunk - 1) / kChunk;
-  if (c >= n_chunks) return;
-  const int64_t b0 = c * kChunk;
-  const int n_here = int(std::min<int64_t>(kChunk, n_bytes - b0));
   int nl = 0;
   bool bad = false;
-  for (int i = 0; i < n_here; i++) {
-    const unsigned char ch = text[b0 + i];
-    nl += ch == '\n';
-    bad |= !(ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T' || ch == '\n');
+  for (int i = 0; i < ch.n; i++) {
+    const unsigned char b = ch.at(i);
+    nl += b == '\n';
+    bad |= !(b == 'A' || b == 'C' || b == 'G' || b == 'T' || b == '\n');
   }
   counts[c] = nl;
   if (bad) atomicOr(flags, 1);
@@ -120,15 +120,16 @@ __global__ __launch_bounds__(256) void k_text_count_nl(const unsigned char* __re
 __global__ __launch_bounds__(256) void k_text_line_ends(const unsigned char* __restrict__ text, int64_t n_bytes,
                                                          const int64_t* __restrict__ nl_before,
                                                          int64_t n_lines, int64_t* __restrict__ line_end) {
+  __shared__ unsigned char lds[kChunkLds];
+  const Chunk ch = stage_chunk(text, n_bytes, lds);
+  if (ch.n == 0) return;
   const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const int64_t n_chunks = (n_bytes + kChunk - 1) / kChunk;
-  if (c >= n_chunks) return;
   const int64_t b0 = c * kChunk;
-  const int n_here = int(std::min<int64_t>(kChunk, n_bytes - b0));
   int64_t line = nl_before[c];
-  for (int i = 0; i < n_here; i++)
-    if (text[b0 + i] == '\n') line_end[line++] = b0 + i;
-  if (c == n_chunks - 1 && text[n_bytes - 1] != '\n') line_end[n_lines - 1] = n_bytes;
+  for (int i = 0; i < ch.n; i++)
+    if (ch.at(i) == '\n') line_end[line++] = b0 + i;
+  if (c == n_chunks - 1 && ch.at(ch.n - 1) != '\n') line_end[n_lines - 1] = n_bytes;
 }
 
 __global__ __launch_bounds__(256) void k_text_lens(const int64_t* __restrict__ line_end, int64_t n_lines, int k,
@@ -150,6 +151,8 @@ __global__ __launch_bounds__(kTextThreads) void k_text_pack(const unsigned char*
                                                             const int64_t* __restrict__ nl_before,
                                                             unsigned long long* __restrict__ words) {
   __shared__ unsigned char codes[kSpan + 32];
+  __shared__ unsigned char lds[kChunkLds];
+  const Chunk ch = stage_chunk(text, n_bytes, lds);
   const int64_t n_chunks = (n_bytes + kChunk - 1) / kChunk;
   const int64_t first_chunk = int64_t(blockIdx.x) * kTextThreads;
   const int64_t last_chunk = std::min<int64_t>(first_chunk + kTextThreads, n_chunks);  // exclusive
@@ -158,14 +161,13 @@ __global__ __launch_bounds__(kTextThreads) void k_text_pack(const unsigned char*
   const int lead = int(base0 & 31);  // the span's first base sits at this position of its word
   for (int i = threadIdx.x; i < lead; i += kTextThreads) codes[i] = 0;
   const int64_t c = first_chunk + threadIdx.x;
-  if (c < n_chunks) {
+  if (ch.n > 0) {
     const int64_t b0 = c * kChunk;
-    const int n_here = int(std::min<int64_t>(kChunk, n_bytes - b0));
     int at = lead + int(b0 - nl_before[c] - base0);
-    for (int i = 0; i < n_here; i++) {
-      const unsigned char ch = text[b0 + i];
-      if (ch == '\n') continue;
-      codes[at++] = ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : 0;
+    for (int i = 0; i < ch.n; i++) {
+      const unsigned char b = ch.at(i);
+      if (b == '\n') continue;
+      codes[at++] = b == 'C' ? 1 : b == 'G' ? 2 : b == 'T' ? 3 : 0;
     }
   }
   __syncthreads();

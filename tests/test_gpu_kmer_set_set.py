@@ -64,6 +64,15 @@ def test_loop_vs_oracle(ctx, case):
     dkss.close()
 
 
+def test_loop_vs_oracle_mid_size(ctx):
+    """6 sets of 2 x 10^5 k-mers (k = 23): arrays of 10^5 .. 10^6 elements inside the encode and
+    the plan, i.e. the mid-size scan paths (single-launch chained scan, packed two-counter sums)
+    that the 2 x 10^4 cases above do not reach; everything against the oracle as there."""
+    sets, osets, okss, dkss = build_both(ctx, 23, 14, 4, 6, 200000, 17)
+    assert compare(sets, osets, okss, dkss) > 0
+    dkss.close()
+
+
 def test_loop_truncated_and_no_merge(ctx):
     k, n, kb = 23, 14, 4
     sets, osets, okss, dkss = build_both(ctx, k, n, kb, 6, 20000, 9, max_iterations=2)

@@ -177,7 +177,8 @@ __device__ __forceinline__ bool sampled_ruler(uint32_t s) { return (s & 30u) == 
 // Chain-rank records.
 //   rinfo[i] (one per sampled ruler, dense index i): end_flag:1 | dist:31 | next:32 -- the next
 //            ruler (or, once end_flag is set, the chain's end state) and the distance to it.
-//   rec[s]   (one per state): kind:2 | off:30 | ref:32
+//   rec[s]   (one per state; for kinds 0 and 1 only the d == 0 state of a k-mer is written, the
+//            other one is its mirror image, see mirror_rec): kind:2 | off:30 | ref:32
 //            kind 0: s lies `off` steps after sampled ruler `ref` (dense index)
 //            kind 1: s lies `off` steps before sampled ruler `ref` (head segment of a chain)
 //            kind 2: the chain's end state is `ref`, `off` steps ahead (no sampled ruler between)
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void k_ruler_walk(const uint32_t* __restrict__
   }
   const uint32_t r = uint32_t(s64);
   uint32_t lk = leave_link(link_pair(link, r), r);
-  rec[r] = make_rec(0, 0, uint32_t(i));
+  if ((r & 1) == 0) rec[r] = make_rec(0, 0, uint32_t(i));
   if (lk == kNone) {
     rinfo[i] = make_rinfo(true, 0, r);
     return;
@@ -222,7 +223,7 @@ __global__ __launch_bounds__(256) void k_ruler_walk(const uint32_t* __restrict__
       rinfo[i] = make_rinfo(false, steps, cur);
       return;
     }
-    rec[cur] = make_rec(0, steps, uint32_t(i));
+    if ((cur & 1) == 0) rec[cur] = make_rec(0, steps, uint32_t(i));  // see mirror_rec
     lk = leave_link(link_pair(link, cur), cur);
     if (lk == kNone) {
       rinfo[i] = make_rinfo(true, steps, cur);
@@ -272,7 +273,7 @@ __global__ __launch_bounds__(256) void k_ruler_heads(const uint32_t* __restrict_
     cur = s0;
     lk = lk0;
     while (true) {
-      rec[cur] = make_rec(kind, left, ref);
+      if (kind == 2 || (cur & 1) == 0) rec[cur] = make_rec(kind, left, ref);  // see mirror_rec
       if (left == 0) break;
       cur = step_to(cur, lk);
       left--;
@@ -295,6 +296,15 @@ __global__ __launch_bounds__(256) void k_ruler_jump(int64_t n_dense,
   rinfo[i] = (theirs & kEndFlag) | (uint64_t(dist & 0x7FFFFFFFu) << 32) | uint32_t(theirs);
   *changed = 1;
 }
+
+// A ruler segment is walked twice, once in each direction (the two states of a k-mer lie on
+// mirror-image chains), and the random 8-byte record writes of those walks are what bounds them
+// (31 G random writes/s against 55 G reads/s).  So a walk only stamps the states with d == 0:
+// every k-mer is stamped once, by whichever walk passes its state 2t, and the record of state
+// 2t + 1 follows from it -- `off` steps after ruler state R means `off` steps before R's mirror
+// R ^ 1 (the two states of a sampled k-mer are neighbours in the dense ruler array), and the
+// other way round.  Chains without a sampled ruler (kind 2) are stamped in both directions.
+__device__ __forceinline__ uint64_t mirror_rec(uint64_t r) { return r ^ ((uint64_t(1) << 62) | 1u); }
 
 // (end state, distance to it) of a state from its record; false on a non-branching loop.
 __device__ __forceinline__ bool resolve_rec(uint64_t r, const unsigned long long* __restrict__ rinfo,
@@ -327,7 +337,8 @@ __global__ __launch_bounds__(256) void k_choose(const unsigned long long* __rest
                                                  uint32_t* __restrict__ hlast) {
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= n) return;
-  const ulonglong2 both = reinterpret_cast<const ulonglong2*>(rec)[t];
+  ulonglong2 both = reinterpret_cast<const ulonglong2*>(rec)[t];
+  if (both.y == kRecUnset && both.x != kRecUnset && (both.x >> 62) < 2) both.y = mirror_rec(both.x);
   uint32_t e0, d0, e1, d1;
   const bool ok = resolve_rec(both.x, rinfo, &e0, &d0) && resolve_rec(both.y, rinfo, &e1, &d1);
   if (!ok) {

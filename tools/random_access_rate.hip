@@ -65,5 +65,13 @@ int main() {
   printf("%-34s %7.2f ms  %6.1f G ops/s\n", names[2], ms, n_ops / ms / 1e6);
   ms = time_it([&] { hipLaunchKernelGGL(k_random<3>, dim3(blocks), dim3(256), 0, 0, a, n_slots, n_ops, sink); });
   printf("%-34s %7.2f ms  %6.1f G ops/s\n", names[3], ms, n_ops / ms / 1e6);
+  // the same reads and writes confined to smaller arrays (L2: 4 MB per XCD, Infinity Cache: 256 MB)
+  for (unsigned long long mb : {8ull, 32ull, 128ull, 256ull, 400ull}) {
+    const unsigned long long slots = mb * 1000 * 1000 / 4;
+    ms = time_it([&] { hipLaunchKernelGGL(k_random<0>, dim3(blocks), dim3(256), 0, 0, a, slots, n_ops, sink); });
+    const float mw = time_it([&] { hipLaunchKernelGGL(k_random<1>, dim3(blocks), dim3(256), 0, 0, a, slots, n_ops, sink); });
+    printf("random 4-byte reads in %4llu MB %7.2f ms  %6.1f G ops/s   writes %7.2f ms  %6.1f G ops/s\n", mb, ms,
+           n_ops / ms / 1e6, mw, n_ops / mw / 1e6);
+  }
   return 0;
 }

@@ -43,18 +43,19 @@ constexpr uint64_t kUnset = ~uint64_t(0);
 
 // ---------------------------------------------------------------------------------- E1
 // Fine index of a set: one workgroup per bucket walks its sorted keys once and records
-// where the top 8 key bits change.
+// where the top fine_bits key bits change.
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_fine_index(const int64_t* __restrict__ off,
                                                      const KeyT* __restrict__ keys, int key_bits,
-                                                     uint32_t* __restrict__ fine,
+                                                     int fine_bits, uint32_t* __restrict__ fine,
                                                      int64_t n_buckets) {
   const int64_t b = blockIdx.x;
   const int64_t lo = off[b], hi = off[b + 1];
-  const int sh = key_bits - 8;
-  uint32_t* f = fine + (b << 8);
+  const int kSlices = 1 << fine_bits;
+  const int sh = key_bits - fine_bits;
+  uint32_t* f = fine + (b << fine_bits);
   if (lo == hi) {
-    f[threadIdx.x] = uint32_t(lo);
+    for (int sub = threadIdx.x; sub < kSlices; sub += 256) f[sub] = uint32_t(lo);
   } else {
     for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
       const int cur = int(uint64_t(keys[i]) >> sh);
@@ -62,9 +63,9 @@ __global__ __launch_bounds__(256) void k_fine_index(const int64_t* __restrict__ 
       for (int sub = prev + 1; sub <= cur; sub++) f[sub] = uint32_t(i);
     }
     const int last = int(uint64_t(keys[hi - 1]) >> sh);
-    for (int sub = last + 1 + int(threadIdx.x); sub < 256; sub += 256) f[sub] = uint32_t(hi);
+    for (int sub = last + 1 + int(threadIdx.x); sub < kSlices; sub += 256) f[sub] = uint32_t(hi);
   }
-  if (b == n_buckets - 1 && threadIdx.x == 0) fine[n_buckets << 8] = uint32_t(hi);
+  if (b == n_buckets - 1 && threadIdx.x == 0) fine[n_buckets << fine_bits] = uint32_t(hi);
 }
 
 template <typename KeyT>
@@ -827,6 +828,7 @@ struct EncPlan {
   uint8_t *ori = nullptr, *hcls = nullptr;
   int64_t *c01 = nullptr, *c23 = nullptr;
   uint32_t* fine = nullptr;
+  int fine_bits = 0;
   // unitig level (own allocation)
   char* ublock = nullptr;
   uint32_t *u_head = nullptr, *u_first = nullptr, *u_last = nullptr, *u_len = nullptr,
@@ -877,8 +879,12 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, int m
   }
   if (n >= int64_t(0x7FFFFFF0)) return fail(KSH_INVALID_ARGUMENT, "set too large for 32-bit indices");
   const int64_t nb = n_buckets(g);
-  const bool use_fine = key_bits(g) >= 8;
-  const size_t fine_entries = use_fine ? size_t(nb) * 256 + 1 : 0;
+  // slices of about 1.5 keys (measured on 10^7- and 10^8-key sets: 9 and 12 bits are the
+  // fastest there; fewer bits mean longer slices, more bits a bigger index to build)
+  int fine_bits = 0;
+  while (fine_bits < 13 && fine_bits < key_bits(g) && (int64_t(3) << fine_bits) < 2 * (n / nb + 1)) fine_bits++;
+  const bool use_fine = fine_bits >= 2;
+  const size_t fine_entries = use_fine ? (size_t(nb) << fine_bits) + 1 : 0;
   const size_t bytes = 2 * al(size_t(2 * n) * 4) + al(size_t(2 * n) * 8) + 5 * al(size_t(n) * 4) +
                        2 * al(size_t(n)) + 2 * al(size_t(n) * 8) + al(fine_entries * 4) + 4096;
   KSH_TRY(slot_reserve(ctx, kSlotEncode, bytes));
@@ -903,8 +909,10 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, int m
   hipStream_t st = ctx->stream;
   if (use_fine) {
     hipLaunchKernelGGL((k_fine_index<KeyT>), dim3(unsigned(nb)), dim3(256), 0, st, sv->d_offsets,
-                       static_cast<const KeyT*>(sv->d_keys), key_bits(g), p->fine, nb);
+                       static_cast<const KeyT*>(sv->d_keys), key_bits(g), fine_bits, p->fine, nb);
     set.fine = p->fine;
+    set.fine_bits = fine_bits;
+    p->fine_bits = fine_bits;
   }
   hipLaunchKernelGGL((k_adjacency<KeyT>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr);
   hipLaunchKernelGGL(k_links, dim3(nblk(n)), dim3(256), 0, st, p->nbr, n, p->link, p->info,
@@ -1049,6 +1057,7 @@ int encode_write_t(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens) {
   DevSet<KeyT> set{p->set.d_offsets, static_cast<const KeyT*>(p->set.d_keys), n_buckets(g), n, g->k,
                    key_bits(g)};
   set.fine = p->fine;
+  set.fine_bits = p->fine_bits;
   hipStream_t st = ctx->stream;
   // byte staging aliases the neighbour array (2n * 4 bytes >= n_bases needs checking)
   const size_t need = size_t(p->n_bases) + 64;

@@ -44,10 +44,13 @@ struct DevSet {
   int64_t n;
   int k;
   int key_bits;
-  // Optional fine index: fine[(b << 8) + sub] = first key index of bucket b whose top 8 key
-  // bits are >= sub (nb * 256 + 1 entries).  Narrows a membership probe from the whole
-  // bucket (~10-13 dependent loads) to a 1/256 slice of it (~2-5).
+  // Optional fine index: fine[(b << fine_bits) + sub] = first key index of bucket b whose top
+  // fine_bits key bits are >= sub (nb * 2^fine_bits + 1 entries).  Narrows a membership probe
+  // from the whole bucket (~10-13 dependent loads) to a slice of one or two keys; the index is
+  // read at the same rate whether it is 16 MB or 256 MB (only an L2-sized one would be faster),
+  // so it is sized for the shortest slices (fine_bits_for).
   const uint32_t* fine = nullptr;
+  int fine_bits = 0;
 
   __device__ __forceinline__ uint64_t key_mask() const {
     return key_bits == 64 ? ~uint64_t(0) : ((uint64_t(1) << key_bits) - 1);
@@ -59,7 +62,7 @@ struct DevSet {
     const KeyT key = KeyT(z & key_mask());
     int64_t lo, hi;
     if (fine) {
-      const int64_t f = (b << 8) + int64_t(uint64_t(key) >> (key_bits - 8));
+      const int64_t f = (b << fine_bits) + int64_t(uint64_t(key) >> (key_bits - fine_bits));
       lo = fine[f];
       hi = fine[f + 1];
     } else {
@@ -80,7 +83,7 @@ struct DevSet {
     const KeyT key = KeyT(z & key_mask());
     int64_t lo, hi;
     if (fine) {
-      const int64_t f = (b << 8) + int64_t(uint64_t(key) >> (key_bits - 8));
+      const int64_t f = (b << fine_bits) + int64_t(uint64_t(key) >> (key_bits - fine_bits));
       lo = fine[f];
       hi = fine[f + 1];
     } else {

@@ -401,36 +401,98 @@ __global__ __launch_bounds__(256) void k_loops(const uint32_t* __restrict__ link
 }
 
 // ---------------------------------------------------------------------------------- E3
-__global__ __launch_bounds__(256) void k_head_counts(const uint8_t* __restrict__ hcls, int64_t n,
-                                                      int64_t* __restrict__ c01,
-                                                      int64_t* __restrict__ c23) {
-  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const uint8_t c = hcls[t];
-  c01[t] = int64_t(c == 0) | (int64_t(c == 1) << 32);
-  c23[t] = int64_t(c == 2) | (int64_t(c == 3) << 32);
+// Unitig ids = rank of (class, head k-mer index): the reference's push order at n_workers == 1.
+// The ranks are not materialised per k-mer (two 8-byte prefix arrays over all k-mers would be
+// written, scanned and read back for the one k-mer in tens or thousands that heads a unitig):
+// a workgroup counts the heads of each class among its 2048 k-mers, the per-workgroup counts
+// are scanned (a few ten thousand values), and k_unitig_fill recomputes the ranks inside its
+// workgroup from the class bytes.
+constexpr int kHeadItems = 8;
+constexpr int kHeadSpan = 256 * kHeadItems;
+
+// Heads of classes 0..3 among kmers [t0, t0 + 8), as four 16-bit counters in one word.
+__device__ __forceinline__ uint64_t head_counts8(const uint8_t* __restrict__ hcls, int64_t t0, int64_t n,
+                                                 uint8_t (&c)[kHeadItems]) {
+  uint64_t packed = 0;
+  if (t0 + kHeadItems <= n) {
+    const uint2 v = *reinterpret_cast<const uint2*>(hcls + t0);  // t0 is a multiple of 8
+#pragma unroll
+    for (int i = 0; i < kHeadItems; i++) c[i] = uint8_t(((i < 4 ? v.x : v.y) >> (8 * (i & 3))) & 0xFF);
+  } else {
+#pragma unroll
+    for (int i = 0; i < kHeadItems; i++) c[i] = t0 + i < n ? hcls[t0 + i] : uint8_t(0xFF);
+  }
+#pragma unroll
+  for (int i = 0; i < kHeadItems; i++)
+    if (c[i] <= 3) packed += uint64_t(1) << (16 * c[i]);
+  return packed;
 }
 
+// Inclusive scan of the four packed counters over the 256 threads of the workgroup; *total gets
+// the workgroup's sum.  Fields stay below 2^16 (at most 2048 heads per workgroup).
+__device__ __forceinline__ uint64_t block_scan_packed(uint64_t v, uint64_t* lds4, uint64_t* total) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint64_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint64_t o = __shfl_up(inc, d, 64);
+    if (lane >= d) inc += o;
+  }
+  if (lane == 63) lds4[wave] = inc;
+  __syncthreads();
+  uint64_t before = 0;
+#pragma unroll
+  for (int w = 0; w < 4; w++)
+    if (w < wave) before += lds4[w];
+  *total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+  return before + inc;
+}
+
+// b01[b] = heads of class 0 | class 1 << 32 in workgroup b's k-mers, b23[b] the same for 2, 3.
+__global__ __launch_bounds__(256) void k_head_block_counts(const uint8_t* __restrict__ hcls, int64_t n,
+                                                            int64_t* __restrict__ b01,
+                                                            int64_t* __restrict__ b23) {
+  __shared__ uint64_t lds4[4];
+  const int64_t t0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * kHeadItems;
+  uint8_t c[kHeadItems];
+  uint64_t total;
+  (void)block_scan_packed(head_counts8(hcls, t0, n, c), lds4, &total);
+  if (threadIdx.x == 0) {
+    b01[blockIdx.x] = int64_t(total & 0xFFFF) | (int64_t((total >> 16) & 0xFFFF) << 32);
+    b23[blockIdx.x] = int64_t((total >> 32) & 0xFFFF) | (int64_t(total >> 48) << 32);
+  }
+}
+
+// b01 / b23: exclusive prefixes of the per-workgroup counts.
 __global__ __launch_bounds__(256) void k_unitig_fill(
-    const uint8_t* __restrict__ hcls, const int64_t* __restrict__ c01,
-    const int64_t* __restrict__ c23, int64_t n, int64_t base1, int64_t base2, int64_t base3,
+    const uint8_t* __restrict__ hcls, const int64_t* __restrict__ b01,
+    const int64_t* __restrict__ b23, int64_t n, int64_t base1, int64_t base2, int64_t base3,
     const uint8_t* __restrict__ ori, const uint32_t* __restrict__ hlen,
     const uint32_t* __restrict__ hlast, uint32_t* __restrict__ uid, uint32_t* __restrict__ u_head,
     uint32_t* __restrict__ u_first, uint32_t* __restrict__ u_last, uint32_t* __restrict__ u_len) {
-  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const uint8_t c = hcls[t];
-  if (c > 3) return;
-  int64_t u;
-  if (c == 0) u = c01[t] & 0xFFFFFFFF;
-  else if (c == 1) u = base1 + (c01[t] >> 32);
-  else if (c == 2) u = base2 + (c23[t] & 0xFFFFFFFF);
-  else u = base3 + (c23[t] >> 32);
-  uid[t] = uint32_t(u);
-  u_head[u] = uint32_t(t);
-  u_first[u] = uint32_t(2 * t) | ori[t];
-  u_last[u] = hlast[t];
-  u_len[u] = hlen[t];
+  __shared__ uint64_t lds4[4];
+  const int64_t t0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * kHeadItems;
+  uint8_t c[kHeadItems];
+  const uint64_t mine = head_counts8(hcls, t0, n, c);
+  uint64_t total;
+  const uint64_t excl = block_scan_packed(mine, lds4, &total) - mine;
+  if (mine == 0) return;
+  const int64_t w01 = b01[blockIdx.x], w23 = b23[blockIdx.x];
+  int64_t next[4] = {(w01 & 0xFFFFFFFF) + int64_t(excl & 0xFFFF),
+                     base1 + (w01 >> 32) + int64_t((excl >> 16) & 0xFFFF),
+                     base2 + (w23 & 0xFFFFFFFF) + int64_t((excl >> 32) & 0xFFFF),
+                     base3 + (w23 >> 32) + int64_t(excl >> 48)};
+#pragma unroll
+  for (int i = 0; i < kHeadItems; i++) {
+    if (c[i] > 3) continue;
+    const int64_t t = t0 + i;
+    const int64_t u = c[i] == 0 ? next[0]++ : c[i] == 1 ? next[1]++ : c[i] == 2 ? next[2]++ : next[3]++;
+    uid[t] = uint32_t(u);
+    u_head[u] = uint32_t(t);
+    u_first[u] = uint32_t(2 * t) | ori[t];
+    u_last[u] = hlast[t];
+    u_len[u] = hlen[t];
+  }
 }
 
 // ---------------------------------------------------------------------------------- E4
@@ -942,11 +1004,14 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, int m
                      p->hcls, p->hlen, p->hlast);
   hipLaunchKernelGGL(k_loops, dim3(nblk(n)), dim3(256), 0, st, p->link, n, p->head, p->pos, p->ori,
                      p->hcls, p->hlen, p->hlast);
-  hipLaunchKernelGGL(k_head_counts, dim3(nblk(n)), dim3(256), 0, st, p->hcls, n, p->c01, p->c23);
+  const int64_t n_hblocks = (n + kHeadSpan - 1) / kHeadSpan;
+  int64_t* b01 = p->c23;              // per-workgroup head counts (n / 2048 values each) live in
+  int64_t* b23 = p->c23 + n_hblocks;  // the front of c23; c01 still holds the ruler records
+  hipLaunchKernelGGL(k_head_block_counts, dim3(unsigned(n_hblocks)), dim3(256), 0, st, p->hcls, n, b01, b23);
   int64_t* d_tot = static_cast<int64_t*>(arena_alloc(ctx, 16));
   if (!d_tot) return fail(KSH_INTERNAL, "scratch arena too small");
-  KSH_TRY(scan_exclusive_i64(ctx, p->c01, p->c01, n, d_tot));
-  KSH_TRY(scan_exclusive_i64(ctx, p->c23, p->c23, n, d_tot + 1));
+  KSH_TRY(scan_exclusive_i64(ctx, b01, b01, n_hblocks, d_tot));
+  KSH_TRY(scan_exclusive_i64(ctx, b23, b23, n_hblocks, d_tot + 1));
   KSH_HIP(hipGetLastError());
   KSH_HIP(hipMemcpyAsync(ctx->h_pinned, d_tot, 16, hipMemcpyDeviceToHost, st));
   KSH_HIP(hipStreamSynchronize(st));
@@ -986,7 +1051,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, int m
   p->sc_used = carve<unsigned long long>(at, 1);
   p->any_live = carve<int>(at, 1);
 
-  hipLaunchKernelGGL(k_unitig_fill, dim3(nblk(n)), dim3(256), 0, st, p->hcls, p->c01, p->c23, n, n0,
+  hipLaunchKernelGGL(k_unitig_fill, dim3(unsigned(n_hblocks)), dim3(256), 0, st, p->hcls, b01, b23, n, n0,
                      n0 + n1, n0 + n1 + n2, p->ori, p->hlen, p->hlast, p->uid, p->u_head, p->u_first,
                      p->u_last, p->u_len);
 

@@ -226,13 +226,20 @@ int ksh_svb_decode_0124(ksh_ctx* ctx, const uint8_t* d_in, int64_t n, uint32_t* 
                         int64_t* bytes_read);
 
 /* ---- SPSS encode ----------------------------------------------------------------------
- * mode 0: KmerSetCompact::FromKmerSet(set, canonical = true, fast = true)
- *         = GetSPSSCanonical (lib/core/spss.h:1835-1858: unitigs, greedy path cover,
- *         loop cut, stitch) + the 2-bit packing constructor
- *         (lib/core/kmer_set_compact.h:36-47,206-266).
- * mode 1: GetUnitigsCanonical (lib/core/spss.h:230-615), every unitig a string.
+ * KmerSetCompact::FromKmerSet(set, canonical, fast, n_workers)
+ * (lib/core/kmer_set_compact.h:36-47) = the SPSS + the 2-bit packing constructor (:206-266).
+ * canonical != 0 (the set holds canonical k-mers only):
+ *   mode 0: GetSPSSCanonical(fast = true) (lib/core/spss.h:1835-1858: unitigs, greedy path
+ *           cover :1358-1539, loop cut :1541-1647, stitch :1649-1829).
+ *   mode 1: GetUnitigsCanonical (lib/core/spss.h:230-615), every unitig a string.
+ *   mode 2: GetSPSSCanonical(fast = false) (lib/core/spss.h:1208-1356): the reference's
+ *           one-thread path extension, replayed by one device thread over the edge table
+ *           (sequential by definition; everything around it is the parallel pipeline).
+ * canonical == 0 (k-mers as they are, edges only forward):
+ *   mode 0 / 2: GetSPSS (lib/core/spss.h:697-1036; FromKmerSet ignores `fast` here).
+ *   mode 1: GetUnitigs (lib/core/spss.h:73-227).
  * The strings and their order are the oracle's (the reference's n_workers == 1
- * control flow with ascending iteration).  Only canonical sets.
+ * control flow with ascending iteration).
  * plan : everything up to the string layout; returns the container's sizes.
  * write: d_words = ceil(n_bases / 32) words, d_lens = n_strings values (len - K). */
 int ksh_spss_encode_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* set, int canonical,

@@ -1,13 +1,12 @@
 // KmerSetCompact<K, N, KeyType>: the reference's SPSS container
 // (lib/core/kmer_set_compact.h:29-348) with its bases resident in HBM: 2 bits per base
 // in 64-bit words + (len - K) per string (layout in include/kmersets_hip.h).
-//   FromKmerSet  -> ksh_spss_encode_plan/write  (GetSPSSCanonical, fast)
+//   FromKmerSet  -> ksh_spss_encode_plan/write  (GetSPSSCanonical fast / slow, or GetSPSS for
+//                   canonical == false)
 //   ToKmerSet    -> ksh_spss_decode_plan/write  (ToStrings + GetKmerSetFromSPSS)
 //   Size, Weight -> ksh_spss_size, n_bases
 //   GetSampledKmerSet -> decode, then the listed buckets (already sorted)
 //   Dump / Load  -> the reference's text format (one string per line)
-// Only canonical sets are supported on the device path (SURVEY.md marks the
-// non-canonical variant out of scope); canonical == false throws.
 #ifndef KSC_CORE_KMER_SET_COMPACT_H_
 #define KSC_CORE_KMER_SET_COMPACT_H_
 
@@ -30,12 +29,13 @@ class KmerSetCompact {
 
   KmerSetCompact() = default;
 
-  static KmerSetCompact FromKmerSet(const Set& kmer_set, bool canonical, bool /*fast*/, int /*n_workers*/) {
-    if (!canonical) throw std::invalid_argument("non-canonical SPSS is outside the device path");
+  // lib/core/kmer_set_compact.h:36-47: canonical ? GetSPSSCanonical(set, fast) : GetSPSS(set).
+  static KmerSetCompact FromKmerSet(const Set& kmer_set, bool canonical, bool fast, int /*n_workers*/) {
     const ksh_geom g = Set::Geom();
     const ksh_set_view v = kmer_set.View();
     KmerSetCompact c;
-    ksc::Check(ksh_spss_encode_plan(ksc::Ctx(), &g, &v, 1, 0, &c.n_, &c.n_bases_));
+    ksc::Check(ksh_spss_encode_plan(ksc::Ctx(), &g, &v, canonical ? 1 : 0, fast ? 0 : 2, &c.n_,
+                                    &c.n_bases_));
     c.words_ = ksc::DeviceBuffer(std::size_t((c.n_bases_ + 31) / 32) * 8);
     c.lens_ = ksc::DeviceBuffer(std::size_t(c.n_) * 4);
     ksc::Check(ksh_spss_encode_write(ksc::Ctx(), static_cast<std::uint64_t*>(c.words_.get()),

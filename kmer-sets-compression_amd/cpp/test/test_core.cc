@@ -146,13 +146,16 @@ static void TestKmerSet() {
 
 // ---- test/spss.cc ----------------------------------------------------------------------------
 template <int K, int N, typename KeyType>
-static void CheckStrings(const std::vector<std::string>& strings, const KmerSet<K, N, KeyType>& want) {
+static void CheckStrings(const std::vector<std::string>& strings, const KmerSet<K, N, KeyType>& want,
+                         bool canonical = true) {
   std::set<std::uint64_t> seen;
   bool ok = true;
   for (const std::string& s : strings) {
     if (static_cast<int>(s.length()) < K) ok = false;
-    for (int i = 0; i + K <= static_cast<int>(s.length()); i++)
-      if (!seen.insert(Kmer<K>(s.substr(i, K)).Canonical().Bits()).second) ok = false;  // no k-mer twice
+    for (int i = 0; i + K <= static_cast<int>(s.length()); i++) {
+      const Kmer<K> kmer(s.substr(i, K));
+      if (!seen.insert((canonical ? kmer.Canonical() : kmer).Bits()).second) ok = false;  // no k-mer twice
+    }
   }
   EXPECT_TRUE(ok);
   auto got = KmerSet<K, N, KeyType>::FromSortedBits(std::vector<std::uint64_t>(seen.begin(), seen.end()));
@@ -168,6 +171,17 @@ static void TestSpss() {
     const auto spss = GetSPSSCanonical(s, true, 4);
     CheckStrings(spss, s);
     EXPECT_TRUE(s.Equals(GetKmerSetFromSPSS<K, N, KeyType>(spss, true, 4), 4));
+    // test/spss.cc:99-124: fast == false
+    const auto slow = GetSPSSCanonical(s, false, 4);
+    CheckStrings(slow, s);
+    EXPECT_TRUE(s.Equals(KmerSetCompact<K, N, KeyType>::FromKmerSet(s, true, false, 4).ToKmerSet(true, 4), 4));
+    // test/spss.cc:15-40,71-96,155-170: the non-canonical variant
+    auto f = RandomKmerSet<K, N, KeyType>(size, false);
+    CheckStrings(GetUnitigs(f, 4), f, false);
+    const auto fw = GetSPSS(f, 4);
+    CheckStrings(fw, f, false);
+    EXPECT_TRUE(f.Equals(GetKmerSetFromSPSS<K, N, KeyType>(fw, false, 4), 4));
+    EXPECT_TRUE(f.Equals(KmerSetCompact<K, N, KeyType>::FromKmerSet(f, false, true, 4).ToKmerSet(false, 4), 4));
   }
   {  // outputs of the reference's own headers
     auto of = [](const std::string& seq) {

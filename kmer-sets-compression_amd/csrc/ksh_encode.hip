@@ -68,13 +68,44 @@ __global__ __launch_bounds__(256) void k_fine_index(const int64_t* __restrict__ 
   if (b == n_buckets - 1 && threadIdx.x == 0) fine[n_buckets << fine_bits] = uint32_t(hi);
 }
 
-template <typename KeyT>
+template <typename KeyT, bool kDirected>
 __global__ __launch_bounds__(256) void k_adjacency(DevSet<KeyT> set, uint32_t* __restrict__ nbr) {
   __shared__ int64_t s_bucket;
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const uint64_t x = set.kmer_in_block(t, &s_bucket);
   if (t >= set.n) return;
   const int k = set.k;
+  int cnt[2] = {0, 0};
+  uint32_t single[2] = {kNone, kNone};
+  if (kDirected) {
+    // Non-canonical sets (GetUnitigs, spss.h:76-96): k-mers as they are, side 1 = outgoing edges
+    // Next(x, .) (four consecutive values, one bounded search), side 0 = incoming edges
+    // Prev(x, .) (four buckets, probed one by one); no edge flips an orientation.
+    {
+      const uint64_t g0 = kmer_next(x, k, 0);
+      int64_t end;
+      const int64_t p0 = set.lower_bound(g0, &end);
+      const uint64_t gkey = g0 & set.key_mask();
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int64_t idx = p0 + e;
+        if (idx >= end) break;
+        if (uint64_t(set.keys[idx]) - gkey >= 4) break;
+        if (idx == t) continue;  // next != kmer (spss.h:81)
+        cnt[1]++;
+        single[1] = uint32_t(idx) << 1;
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const uint64_t z = kmer_prev(x, k, c);
+      if (z == x) continue;  // prev != kmer (spss.h:91)
+      const int64_t idx = set.find(z);
+      if (idx < 0) continue;
+      cnt[0]++;
+      single[0] = uint32_t(idx) << 1;
+    }
+  } else {
   // The 8 candidates of the reference (Next / Prev of x, each as is or reverse-complemented,
   // spss.h:238-273) in two kinds.  The four Next(x, c) are consecutive values, and so are the
   // four Next(rc(x), c) = rc(Prev(x, 3 - c)): one bounded search each finds all of their
@@ -82,8 +113,6 @@ __global__ __launch_bounds__(256) void k_adjacency(DevSet<KeyT> set, uint32_t* _
   // Prev(x, c) and Prev(rc(x), c) = rc(Next(x, 3 - c)), sit in four different buckets and are
   // probed one by one, and only when they are the canonical form.
   const uint64_t rx = revcomp(x, k);
-  int cnt[2] = {0, 0};
-  uint32_t single[2] = {kNone, kNone};
 #pragma unroll
   for (int side = 0; side < 2; side++) {
     // group: side 1 -> Next(x, .) (neighbour as is);  side 0 -> Next(rc(x), .) (neighbour
@@ -114,6 +143,7 @@ __global__ __launch_bounds__(256) void k_adjacency(DevSet<KeyT> set, uint32_t* _
       cnt[side]++;
       single[side] = (uint32_t(idx) << 1) | (side ? 1u : 0u);
     }
+  }
   }
   nbr[2 * t] = cnt[0] == 0 ? kNone : (cnt[0] == 1 ? single[0] : kMulti);
   nbr[2 * t + 1] = cnt[1] == 0 ? kNone : (cnt[1] == 1 ? single[1] : kMulti);
@@ -328,9 +358,11 @@ __device__ __forceinline__ bool resolve_rec(uint64_t r, const unsigned long long
 // For k-mer t the chain of (t, 0) ends at E0 and the chain of (t, 1) ends at E1, i.e. the
 // forward chain runs from k-mer E1 >> 1 to k-mer E0 >> 1; the spelling starts at the larger
 // end (spss.h:511,555).  hcls: 0xFE marks a k-mer on a non-branching loop (k_loops fills it in).
+// directed (non-canonical sets): every chain is spelled forward from its start k-mer, and all
+// heads are one class, in start-k-mer order (spss.h:159-199).
 __global__ __launch_bounds__(256) void k_choose(const unsigned long long* __restrict__ rec,
                                                  const unsigned long long* __restrict__ rinfo,
-                                                 int64_t n, uint32_t* __restrict__ head,
+                                                 int64_t n, bool directed, uint32_t* __restrict__ head,
                                                  uint32_t* __restrict__ pos,
                                                  uint8_t* __restrict__ ori,
                                                  uint8_t* __restrict__ hcls,
@@ -349,14 +381,14 @@ __global__ __launch_bounds__(256) void k_choose(const unsigned long long* __rest
   }
   hcls[t] = 0xFF;
   const uint32_t fwd_start = e1 >> 1, fwd_end = e0 >> 1;
-  const uint32_t d = fwd_start >= fwd_end ? 0u : 1u;
+  const uint32_t d = (directed || fwd_start >= fwd_end) ? 0u : 1u;
   const uint32_t start_state = (d ? e0 : e1) ^ 1;
   const uint32_t p = d ? d0 : d1;
   head[t] = start_state >> 1;
   pos[t] = p;
   ori[t] = uint8_t(d);
   if (p == 0) {
-    hcls[t] = fwd_start == fwd_end ? 0 : ((start_state & 1) == 0 ? 1 : 2);
+    hcls[t] = (directed || fwd_start == fwd_end) ? 0 : ((start_state & 1) == 0 ? 1 : 2);
     hlen[t] = d0 + d1 + 1;
     hlast[t] = d ? e1 : e0;
   }
@@ -497,8 +529,12 @@ __global__ __launch_bounds__(256) void k_unitig_fill(
 
 // ---------------------------------------------------------------------------------- E4
 // vertex v = 2u + side (0 = left end, 1 = right end); edges[4v + c] = other vertex or kNone.
+// directed (spss.h:706-726): the right end is the unitig's outgoing port, the left end its
+// incoming one; an edge joins the last k-mer of u to a first k-mer Next(last, c) of another
+// unitig, k-mers as they are.  (A k-mer with an edge from another unitig is an end of its own:
+// inside a unitig every k-mer has exactly one neighbour on that side.)
 template <typename KeyT>
-__global__ __launch_bounds__(256) void k_edges(DevSet<KeyT> set, int64_t n_vertices,
+__global__ __launch_bounds__(256) void k_edges(DevSet<KeyT> set, int64_t n_vertices, bool directed,
                                                 const uint32_t* __restrict__ u_first,
                                                 const uint32_t* __restrict__ u_last,
                                                 const uint32_t* __restrict__ head,
@@ -514,18 +550,26 @@ __global__ __launch_bounds__(256) void k_edges(DevSet<KeyT> set, int64_t n_verti
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     const uint64_t y = side ? kmer_next(o, k, c) : kmer_prev(o, k, c);
-    const uint64_t r = revcomp(y, k);
-    const uint64_t z = y < r ? y : r;
     uint32_t out = kNone;
-    const int64_t i = set.find(z);
-    if (i >= 0) {
-      const uint32_t u2 = uid[head[i]];
-      if (u2 != u) {
-        // side of k-mer z this edge touches
-        const uint32_t f = side ? (y == z ? 0u : 1u) : (y == z ? 1u : 0u);
-        const uint32_t fs = u_first[u2];
-        const uint32_t side2 = ((fs >> 1) == uint32_t(i) && (fs & 1) == f) ? 0u : 1u;
-        out = 2 * u2 + side2;
+    if (directed) {
+      const int64_t i = set.find(y);
+      if (i >= 0) {
+        const uint32_t u2 = uid[head[i]];
+        if (u2 != u) out = 2 * u2 + (side ? 0u : 1u);
+      }
+    } else {
+      const uint64_t r = revcomp(y, k);
+      const uint64_t z = y < r ? y : r;
+      const int64_t i = set.find(z);
+      if (i >= 0) {
+        const uint32_t u2 = uid[head[i]];
+        if (u2 != u) {
+          // side of k-mer z this edge touches
+          const uint32_t f = side ? (y == z ? 0u : 1u) : (y == z ? 1u : 0u);
+          const uint32_t fs = u_first[u2];
+          const uint32_t side2 = ((fs >> 1) == uint32_t(i) && (fs & 1) == f) ? 0u : 1u;
+          out = 2 * u2 + side2;
+        }
       }
     }
     edges[4 * v + c] = out;
@@ -533,13 +577,17 @@ __global__ __launch_bounds__(256) void k_edges(DevSet<KeyT> set, int64_t n_verti
 }
 
 // ---------------------------------------------------------------------------------- E5
-__device__ __forceinline__ uint64_t slot_priority(uint32_t v, int c) {
+// When the reference's sweep first considers the edge in slot c of vertex v: node by node, the
+// right side's edges before the left side's (spss.h:1445-1499).  directed: only the outgoing
+// port enumerates (spss.h:797-815), an incoming port takes the priority of the other end.
+__device__ __forceinline__ uint64_t slot_priority(uint32_t v, int c, bool directed) {
+  if (directed && !(v & 1)) return ~uint64_t(0);
   return uint64_t(v >> 1) * 8 + ((v & 1) ? 0 : 4) + uint64_t(c);
 }
 
 __global__ __launch_bounds__(256) void k_match_best(const uint32_t* __restrict__ edges,
                                                      const uint32_t* __restrict__ mate,
-                                                     int64_t n_vertices,
+                                                     int64_t n_vertices, bool directed,
                                                      unsigned long long* __restrict__ best_prio,
                                                      uint32_t* __restrict__ best_w,
                                                      int* __restrict__ any_live) {
@@ -552,11 +600,11 @@ __global__ __launch_bounds__(256) void k_match_best(const uint32_t* __restrict__
     for (int c = 0; c < 4; c++) {
       const uint32_t w = edges[4 * v + c];
       if (w == kNone || mate[w] != kNone) continue;
-      uint64_t pr = slot_priority(uint32_t(v), c);
+      uint64_t pr = slot_priority(uint32_t(v), c, directed);
 #pragma unroll
       for (int c2 = 0; c2 < 4; c2++) {
         if (edges[4 * int64_t(w) + c2] == uint32_t(v)) {
-          const uint64_t p2 = slot_priority(w, c2);
+          const uint64_t p2 = slot_priority(w, c2, directed);
           pr = p2 < pr ? p2 : pr;
         }
       }
@@ -582,6 +630,39 @@ __global__ __launch_bounds__(256) void k_match_commit(const unsigned long long* 
   if (best_w[w] == uint32_t(v) && best_prio[w] == best_prio[v]) mate[v] = w;
 }
 
+// GetSPSSCanonical(fast = false) (spss.h:1208-1322): the reference's one-thread path extension.
+// From every node that has no edge yet, a walk leaves through the right side if it has edges
+// (else the left) and keeps taking the first edge whose far side is free and that does not
+// come back to the walk's start.  Each choice depends on all earlier ones, so this is one
+// thread replaying the sweep over the edge table (latency-bound by design, like the reference's).
+__global__ __launch_bounds__(64) void k_match_slow(const uint32_t* __restrict__ edges,
+                                                    uint32_t* __restrict__ mate, int64_t n_u) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  for (int64_t i = 0; i < n_u; i++) {
+    if (mate[2 * i] != kNone || mate[2 * i + 1] != kNone) continue;
+    bool any_r = false, any_l = false;
+    for (int c = 0; c < 4; c++) {
+      any_l |= edges[8 * i + c] != kNone;
+      any_r |= edges[8 * i + 4 + c] != kNone;
+    }
+    if (!any_r && !any_l) continue;
+    uint32_t v = uint32_t(2 * i) | (any_r ? 1u : 0u);
+    int64_t steps = 0;
+    while (mate[v] == kNone && steps++ <= 2 * n_u) {
+      uint32_t pick = kNone;
+      for (int c = 0; c < 4 && pick == kNone; c++) {
+        const uint32_t w = edges[4 * int64_t(v) + c];
+        if (w == kNone || (w >> 1) == uint32_t(i) || mate[w] != kNone) continue;
+        pick = w;
+      }
+      if (pick == kNone) break;
+      mate[v] = pick;
+      mate[pick] = v;
+      v = pick ^ 1;  // arrived through side pick & 1, goes on from the other side
+    }
+  }
+}
+
 // ---------------------------------------------------------------------------------- E6
 __global__ __launch_bounds__(256) void k_cover_mark(const uint32_t* __restrict__ mate, int64_t n_u,
                                                      uint8_t* __restrict__ visited) {
@@ -604,8 +685,9 @@ __global__ __launch_bounds__(256) void k_cover_mark(const uint32_t* __restrict__
 // One thread per loop of the path cover (the loop's smallest unitig).  Replays the
 // reference's sequential union-by-rank over the loop's nodes in ascending order
 // (spss.h:1551-1566, parallel_disjoint_set.h:53-78) to find the root, then drops the
-// root's left edge and its mate entry (spss.h:1626-1643).
-__global__ __launch_bounds__(64) void k_loop_cut(uint32_t* __restrict__ mate, int64_t n_u,
+// root's left edge and its mate entry (spss.h:1626-1643).  directed: only the outgoing edges
+// are united (spss.h:866-870) and the root's outgoing edge is the one dropped (:922-926).
+__global__ __launch_bounds__(64) void k_loop_cut(uint32_t* __restrict__ mate, int64_t n_u, bool directed,
                                                   const uint8_t* __restrict__ visited,
                                                   uint32_t* __restrict__ scratch_nodes,
                                                   uint32_t* __restrict__ scratch_parent,
@@ -701,28 +783,44 @@ __global__ __launch_bounds__(64) void k_loop_cut(uint32_t* __restrict__ mate, in
   };
   for (int64_t i = 0; i < len; i++) {
     const uint32_t a = nodes[i];
-    unite(uint32_t(i), index_of(mate[2 * int64_t(a)] >> 1));      // edge_left first
+    if (!directed) unite(uint32_t(i), index_of(mate[2 * int64_t(a)] >> 1));  // edge_left first
     unite(uint32_t(i), index_of(mate[2 * int64_t(a) + 1] >> 1));
   }
   const uint32_t root_node = nodes[find(0)];
-  const uint32_t w = mate[2 * int64_t(root_node)];
-  mate[2 * int64_t(root_node)] = kNone;
+  const int64_t cut = 2 * int64_t(root_node) + (directed ? 1 : 0);
+  const uint32_t w = mate[cut];
+  mate[cut] = kNone;
   mate[w] = kNone;
 }
 
 // ---------------------------------------------------------------------------------- E7
 // scls[u]: 0 = kept walk from a left terminal, 1 = kept walk from a right terminal,
 //          2 = isolated unitig, 0xFF = not the start of an output string.
+// directed: a string starts at every node without an incoming edge and runs forward
+// (spss.h:931-1011); isolated unitigs are class 0 like the others.
 __global__ __launch_bounds__(256) void k_string_starts(const uint32_t* __restrict__ mate,
                                                         const uint32_t* __restrict__ u_len,
-                                                        int64_t n_u, uint8_t* __restrict__ scls,
+                                                        int64_t n_u, bool directed,
+                                                        uint8_t* __restrict__ scls,
                                                         int64_t* __restrict__ s_nk) {
   const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (u >= n_u) return;
   const bool hl = mate[2 * u] != kNone, hr = mate[2 * u + 1] != kNone;
   uint8_t cls = 0xFF;
   int64_t nk = 0;
-  if (!hl && !hr) {
+  if (directed) {
+    if (!hl) {
+      uint32_t cur = uint32_t(u);
+      int64_t steps = 0;
+      while (true) {
+        nk += u_len[cur];
+        const uint32_t w = mate[2 * int64_t(cur) + 1];
+        if (w == kNone || steps++ > n_u) break;
+        cur = w >> 1;
+      }
+      cls = 0;
+    }
+  } else if (!hl && !hr) {
     cls = 2;
     nk = u_len[u];
   } else if (!hl || !hr) {
@@ -742,34 +840,43 @@ __global__ __launch_bounds__(256) void k_string_starts(const uint32_t* __restric
   s_nk[u] = nk;
 }
 
+// one_sequence (fast = false, spss.h:1328-1350): the strings come in node order whatever their
+// class; otherwise class by class (spss.h:1731-1829).
 __global__ __launch_bounds__(256) void k_string_counts(const uint8_t* __restrict__ scls, int64_t n_u,
+                                                        bool one_sequence,
                                                         int64_t* __restrict__ c01,
                                                         int64_t* __restrict__ c2) {
   const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (u >= n_u) return;
   const uint8_t c = scls[u];
-  c01[u] = int64_t(c == 0) | (int64_t(c == 1) << 32);
-  c2[u] = int64_t(c == 2);
+  if (one_sequence) {
+    c01[u] = int64_t(c != 0xFF);
+    c2[u] = 0;
+  } else {
+    c01[u] = int64_t(c == 0) | (int64_t(c == 1) << 32);
+    c2[u] = int64_t(c == 2);
+  }
 }
 
 __global__ __launch_bounds__(256) void k_string_assign(
     const uint32_t* __restrict__ mate, const uint32_t* __restrict__ u_len, int64_t n_u,
     const uint8_t* __restrict__ scls, const int64_t* __restrict__ c01,
     const int64_t* __restrict__ c2, const int64_t* __restrict__ s_nk, int64_t base1, int64_t base2,
-    int k, uint32_t* __restrict__ u_sid, uint32_t* __restrict__ u_koff,
+    bool one_sequence, int k, uint32_t* __restrict__ u_sid, uint32_t* __restrict__ u_koff,
     uint8_t* __restrict__ u_flip, uint32_t* __restrict__ lens, int64_t* __restrict__ str_bases) {
   const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (u >= n_u) return;
   const uint8_t c = scls[u];
   if (c == 0xFF) return;
   int64_t sid;
-  if (c == 0) sid = c01[u] & 0xFFFFFFFF;
+  if (one_sequence || c == 0) sid = c01[u] & 0xFFFFFFFF;
   else if (c == 1) sid = base1 + (c01[u] >> 32);
   else sid = base2 + c2[u];
   lens[sid] = uint32_t(s_nk[u] - 1);
   str_bases[sid] = s_nk[u] + k - 1;
   uint32_t cur = uint32_t(u);
-  bool going_right = c != 1;
+  // fast = false spells an isolated unitig through FindPath(i, false), i.e. reverse-complemented
+  bool going_right = c == 2 ? !one_sequence : c != 1;
   uint32_t koff = 0;
   int64_t steps = 0;
   while (true) {
@@ -924,7 +1031,7 @@ void free_plan(ksh_ctx* ctx) {
 }
 
 template <typename KeyT>
-int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, int mode,
+int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool directed, int mode,
                   int64_t* n_strings, int64_t* n_bases) {
   free_plan(ctx);
   EncPlan* p = new EncPlan;
@@ -976,7 +1083,10 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, int m
     set.fine_bits = fine_bits;
     p->fine_bits = fine_bits;
   }
-  hipLaunchKernelGGL((k_adjacency<KeyT>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr);
+  if (directed)
+    hipLaunchKernelGGL((k_adjacency<KeyT, true>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr);
+  else
+    hipLaunchKernelGGL((k_adjacency<KeyT, false>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr);
   hipLaunchKernelGGL(k_links, dim3(nblk(n)), dim3(256), 0, st, p->nbr, n, p->link, p->info,
                      p->hcls);  // hcls doubles as the start-flag bytes until k_choose
   {
@@ -1000,7 +1110,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, int m
     }
   }
   hipLaunchKernelGGL(k_choose, dim3(nblk(n)), dim3(256), 0, st, p->info,
-                     reinterpret_cast<const unsigned long long*>(p->c01), n, p->head, p->pos, p->ori,
+                     reinterpret_cast<const unsigned long long*>(p->c01), n, directed, p->head, p->pos, p->ori,
                      p->hcls, p->hlen, p->hlast);
   hipLaunchKernelGGL(k_loops, dim3(nblk(n)), dim3(256), 0, st, p->link, n, p->head, p->pos, p->ori,
                      p->hcls, p->hlen, p->hlast);
@@ -1060,30 +1170,36 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, int m
     hipLaunchKernelGGL(k_unitig_strings, dim3(nblk(n_u)), dim3(256), 0, st, p->u_len, n_u, g->k,
                        p->u_sid, p->u_koff, p->u_flip, p->lens, p->str_start);
   } else {
-    hipLaunchKernelGGL((k_edges<KeyT>), dim3(nblk(2 * n_u)), dim3(256), 0, st, set, 2 * n_u,
+    hipLaunchKernelGGL((k_edges<KeyT>), dim3(nblk(2 * n_u)), dim3(256), 0, st, set, 2 * n_u, directed,
                        p->u_first, p->u_last, p->head, p->uid, p->edges);
     KSH_HIP(hipMemsetAsync(p->mate, 0xFF, size_t(2 * n_u) * 4, st));
     p->rounds = 0;
-    while (true) {
-      KSH_HIP(hipMemsetAsync(p->any_live, 0, sizeof(int), st));
-      hipLaunchKernelGGL(k_match_best, dim3(nblk(2 * n_u)), dim3(256), 0, st, p->edges, p->mate,
-                         2 * n_u, p->best_prio, p->best_w, p->any_live);
-      hipLaunchKernelGGL(k_match_commit, dim3(nblk(2 * n_u)), dim3(256), 0, st, p->best_prio,
-                         p->best_w, 2 * n_u, p->mate);
-      KSH_HIP(hipMemcpyAsync(ctx->h_pinned, p->any_live, sizeof(int), hipMemcpyDeviceToHost, st));
-      KSH_HIP(hipStreamSynchronize(st));
-      p->rounds++;
-      if (*reinterpret_cast<int*>(ctx->h_pinned) == 0) break;
-      if (p->rounds > 100000) return fail(KSH_INTERNAL, "matching did not converge");
+    const bool slow = mode == 2;
+    if (slow) {
+      hipLaunchKernelGGL(k_match_slow, dim3(1), dim3(64), 0, st, p->edges, p->mate, n_u);
+    } else {
+      while (true) {
+        KSH_HIP(hipMemsetAsync(p->any_live, 0, sizeof(int), st));
+        hipLaunchKernelGGL(k_match_best, dim3(nblk(2 * n_u)), dim3(256), 0, st, p->edges, p->mate,
+                           2 * n_u, directed, p->best_prio, p->best_w, p->any_live);
+        hipLaunchKernelGGL(k_match_commit, dim3(nblk(2 * n_u)), dim3(256), 0, st, p->best_prio,
+                           p->best_w, 2 * n_u, p->mate);
+        KSH_HIP(hipMemcpyAsync(ctx->h_pinned, p->any_live, sizeof(int), hipMemcpyDeviceToHost, st));
+        KSH_HIP(hipStreamSynchronize(st));
+        p->rounds++;
+        if (*reinterpret_cast<int*>(ctx->h_pinned) == 0) break;
+        if (p->rounds > 100000) return fail(KSH_INTERNAL, "matching did not converge");
+      }
+      // the path extension of fast = false never closes a loop; the greedy matching can
+      KSH_HIP(hipMemsetAsync(p->visited, 0, size_t(n_u), st));
+      KSH_HIP(hipMemsetAsync(p->sc_used, 0, 8, st));
+      hipLaunchKernelGGL(k_cover_mark, dim3(nblk(n_u)), dim3(256), 0, st, p->mate, n_u, p->visited);
+      hipLaunchKernelGGL(k_loop_cut, dim3(unsigned((n_u + 63) / 64)), dim3(64), 0, st, p->mate, n_u,
+                         directed, p->visited, p->sc_nodes, p->sc_parent, p->sc_rank, p->sc_used);
     }
-    KSH_HIP(hipMemsetAsync(p->visited, 0, size_t(n_u), st));
-    KSH_HIP(hipMemsetAsync(p->sc_used, 0, 8, st));
-    hipLaunchKernelGGL(k_cover_mark, dim3(nblk(n_u)), dim3(256), 0, st, p->mate, n_u, p->visited);
-    hipLaunchKernelGGL(k_loop_cut, dim3(unsigned((n_u + 63) / 64)), dim3(64), 0, st, p->mate, n_u,
-                       p->visited, p->sc_nodes, p->sc_parent, p->sc_rank, p->sc_used);
     hipLaunchKernelGGL(k_string_starts, dim3(nblk(n_u)), dim3(256), 0, st, p->mate, p->u_len, n_u,
-                       p->scls, p->s_nk);
-    hipLaunchKernelGGL(k_string_counts, dim3(nblk(n_u)), dim3(256), 0, st, p->scls, n_u, p->sc01,
+                       directed, p->scls, p->s_nk);
+    hipLaunchKernelGGL(k_string_counts, dim3(nblk(n_u)), dim3(256), 0, st, p->scls, n_u, slow, p->sc01,
                        p->sc2);
     arena_reset(ctx);
     int64_t* d_t2 = static_cast<int64_t*>(arena_alloc(ctx, 16));
@@ -1095,7 +1211,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, int m
                   s2 = ctx->h_pinned[1];
     ns = s0 + s1 + s2;
     hipLaunchKernelGGL(k_string_assign, dim3(nblk(n_u)), dim3(256), 0, st, p->mate, p->u_len, n_u,
-                       p->scls, p->sc01, p->sc2, p->s_nk, s0, s0 + s1, g->k, p->u_sid, p->u_koff,
+                       p->scls, p->sc01, p->sc2, p->s_nk, s0, s0 + s1, slow, g->k, p->u_sid, p->u_koff,
                        p->u_flip, p->lens, p->str_start);
   }
   // string starts in bases
@@ -1155,15 +1271,15 @@ int ksh_spss_encode_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* se
                          int mode, int64_t* n_strings, int64_t* n_bases) {
   if (!ctx || !set || !n_strings || !n_bases) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
   KSH_TRY(check_geom(g));
-  if (!canonical_flag)
-    return fail(KSH_INVALID_ARGUMENT, "only canonical k-mer sets are supported (SURVEY.md: the "
-                                      "non-canonical variant is outside the hot path)");
-  if (mode != 0 && mode != 1) return fail(KSH_INVALID_ARGUMENT, "mode must be 0 (SPSS) or 1 (unitigs)");
+  if (mode < 0 || mode > 2)
+    return fail(KSH_INVALID_ARGUMENT, "mode must be 0 (SPSS), 1 (unitigs) or 2 (SPSS, fast = false)");
+  const bool directed = !canonical_flag;
+  if (directed && mode == 2) mode = 0;  // FromKmerSet ignores `fast` for non-canonical sets
   if (set->n_keys < 0 || !set->d_offsets || (set->n_keys > 0 && !set->d_keys))
     return fail(KSH_INVALID_ARGUMENT, "bad set view");
   KSH_HIP(hipSetDevice(ctx->device));
-  return g->key_bytes == 4 ? encode_plan_t<uint32_t>(ctx, g, set, mode, n_strings, n_bases)
-                           : encode_plan_t<uint64_t>(ctx, g, set, mode, n_strings, n_bases);
+  return g->key_bytes == 4 ? encode_plan_t<uint32_t>(ctx, g, set, directed, mode, n_strings, n_bases)
+                           : encode_plan_t<uint64_t>(ctx, g, set, directed, mode, n_strings, n_bases);
 }
 
 int ksh_spss_encode_write(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens) {

@@ -115,10 +115,11 @@ static int decode_to_set(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s
   return KSH_OK;
 }
 
-static int encode_set(ksh_ctx* ctx, const ksh_geom* g, const KssSet& s, KssCompact* out) {
+static int encode_set(ksh_ctx* ctx, const ksh_geom* g, const KssSet& s, int canonical_flag,
+                      KssCompact* out) {
   const ksh_set_view v = view_of(s);
   int64_t ns = 0, nbases = 0;
-  KSH_TRY(ksh_spss_encode_plan(ctx, g, &v, 1, 0, &ns, &nbases));
+  KSH_TRY(ksh_spss_encode_plan(ctx, g, &v, canonical_flag, 0, &ns, &nbases));
   out->owned = true;
   KSH_TRY(pool_alloc(ctx, std::max<size_t>(size_t((nbases + 31) / 32) * 8, 16),
                      reinterpret_cast<void**>(&out->words)));
@@ -140,7 +141,7 @@ static int ensure_compacts(ksh_kss* k) {
     for (size_t i = 0; i < k->compacts.size(); i++) {
       if (k->compacts[i].valid) continue;
       KssCompact c;
-      KSH_TRY(encode_set(k->ctx, &k->g, k->sets[i], &c));
+      KSH_TRY(encode_set(k->ctx, &k->g, k->sets[i], k->canonical, &c));
       k->compacts[i] = c;
       k->n_encodes++;
       k->n_encoded_kmers += k->sets[i].n;
@@ -175,7 +176,7 @@ static int ensure_compacts(ksh_kss* k) {
     const int holder = holder_of[q];
     KssCompact c;
     if (holder == k->rank) {
-      KSH_TRY(encode_set(k->ctx, &k->g, k->sets[i], &c));
+      KSH_TRY(encode_set(k->ctx, &k->g, k->sets[i], k->canonical, &c));
       k->n_encodes++;
       k->n_encoded_kmers += k->sets[i].n;
       send[2 * q] = c.n_strings;
@@ -406,7 +407,6 @@ int ksh_kss_build(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* inputs, 
   *out = nullptr;
   KSH_TRY(check_geom(g));
   if (n_inputs < 0 || n_ids < 0) return fail(KSH_INVALID_ARGUMENT, "negative count");
-  if (!canonical_flag) return fail(KSH_INVALID_ARGUMENT, "only canonical k-mer sets are supported");
   KSH_HIP(hipSetDevice(ctx->device));
   ksh_kss* k = new ksh_kss;
   k->ctx = ctx;
@@ -431,7 +431,6 @@ int ksh_kss_build_sharded(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* 
   *out = nullptr;
   KSH_TRY(check_geom(g));
   if (n_inputs < 0 || n_ids < 0) return fail(KSH_INVALID_ARGUMENT, "negative count");
-  if (!canonical_flag) return fail(KSH_INVALID_ARGUMENT, "only canonical k-mer sets are supported");
   if (world < 1 || rank < 0 || rank >= world) return fail(KSH_INVALID_ARGUMENT, "bad rank / world");
   if (world > 1 && !gather) return fail(KSH_INVALID_ARGUMENT, "a sharded build needs the all-gather callback");
   KSH_HIP(hipSetDevice(ctx->device));

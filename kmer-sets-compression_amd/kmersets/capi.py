@@ -458,7 +458,8 @@ class Context:
 
     # KmerSetCompact::FromKmerSet / GetUnitigsCanonical ---------------------------------------
     def spss_encode(self, s, mode=0, canonical=True):
-        """mode 0: SPSS (GetSPSSCanonical, fast); mode 1: unitigs.  Returns a DeviceSpss."""
+        """mode 0: SPSS (GetSPSSCanonical fast, or GetSPSS when canonical is False); mode 1: unitigs;
+        mode 2: GetSPSSCanonical(fast = false).  Returns a DeviceSpss."""
         import torch
 
         ns, nbases = C.c_int64(), C.c_int64()

@@ -174,8 +174,9 @@ def from_bucketed(offsets, keys, k, n_bits):
     return (buckets << U(key_bits)) | np.asarray(keys, dtype=U)
 
 
-def circular_with_tails(k, length, n_tails, tail_len, seed):
-    """Canonical k-mers of a circular genome with short branches hanging off it.
+def circular_with_tails(k, length, n_tails, tail_len, seed, canonical_form=True):
+    """Canonical k-mers (or, canonical_form=False, the k-mers as read) of a circular genome with
+    short branches hanging off it.
 
     Loops are what the reference's serial passes exist for (spss.h:585-610 for
     non-branching loops of k-mers, :1578-1644 for loops in the path cover); tails
@@ -192,7 +193,8 @@ def circular_with_tails(k, length, n_tails, tail_len, seed):
         anchor = circ[p:p + k - 1]
         seq = np.concatenate([anchor, tail]) if out_going else np.concatenate([tail, anchor])
         parts.append(kmers_of_bases(seq, k))
-    return np.unique(canonical(np.concatenate(parts), k))
+    allk = np.concatenate(parts)
+    return np.unique(canonical(allk, k) if canonical_form else allk)
 
 
 def pack_strings(strings, k):

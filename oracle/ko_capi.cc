@@ -251,6 +251,22 @@ void* ko_spss_canonical(void* set) {
   h->v = s->wide() ? ko::spss_canonical(*s->s64) : ko::spss_canonical(*s->s32);
   return h;
 }
+// variant: 0 = canonical fast, 1 = canonical slow (fast == false), 2 = non-canonical.
+void* ko_spss_variant(void* set, int variant) {
+  SetH* s = static_cast<SetH*>(set);
+  StringsH* h = new StringsH;
+  if (variant == 2)
+    h->v = s->wide() ? ko::spss_directed(*s->s64) : ko::spss_directed(*s->s32);
+  else
+    h->v = s->wide() ? ko::spss_canonical(*s->s64, variant == 0) : ko::spss_canonical(*s->s32, variant == 0);
+  return h;
+}
+void* ko_unitigs_directed(void* set) {
+  SetH* s = static_cast<SetH*>(set);
+  StringsH* h = new StringsH;
+  h->v = s->wide() ? ko::unitigs_directed(*s->s64) : ko::unitigs_directed(*s->s32);
+  return h;
+}
 void* ko_spss_from_unitigs(void* unitigs, int k) {
   StringsH* u = static_cast<StringsH*>(unitigs);
   StringsH* h = new StringsH;
@@ -286,6 +302,13 @@ void* ko_compact_from_set(void* set) {
   SetH* s = static_cast<SetH*>(set);
   CompactH* h = new CompactH;
   h->c = s->wide() ? ko::Compact::from_kmer_set(*s->s64) : ko::Compact::from_kmer_set(*s->s32);
+  return h;
+}
+void* ko_compact_from_set_variant(void* set, int canon, int fast) {
+  SetH* s = static_cast<SetH*>(set);
+  CompactH* h = new CompactH;
+  h->c = s->wide() ? ko::Compact::from_kmer_set(*s->s64, canon != 0, fast != 0)
+                   : ko::Compact::from_kmer_set(*s->s32, canon != 0, fast != 0);
   return h;
 }
 void ko_compact_free(void* h) { delete static_cast<CompactH*>(h); }

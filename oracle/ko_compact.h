@@ -129,9 +129,10 @@ class Compact {
     lengths_compressed_.shrink_to_fit();
   }
 
+  // FromKmerSet(kmer_set, canonical, fast, n_workers) (kmer_set_compact.h:36-47).
   template <typename KeyT>
-  static Compact from_kmer_set(const KmerSet<KeyT>& kmer_set) {
-    return Compact(kmer_set.geom(), spss_canonical(kmer_set));
+  static Compact from_kmer_set(const KmerSet<KeyT>& kmer_set, bool canon = true, bool fast = true) {
+    return Compact(kmer_set.geom(), canon ? spss_canonical(kmer_set, fast) : spss_directed(kmer_set));
   }
 
   const Geom& geom() const { return g_; }

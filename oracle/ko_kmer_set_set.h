@@ -183,12 +183,12 @@ class KmerSetSet {
           const KmerSet<KeyT> set_n = set_intersection(set_j, set_k);
           set_j.sub_set(set_n);
           set_k.sub_set(set_n);
-          compacts_.push_back(Compact::from_kmer_set(set_n));
+          compacts_.push_back(Compact::from_kmer_set(set_n, canon, true));
           sampled.push_back(compacts_[n].template sampled<KeyT>(bucket_ids, canon));
         }
-        compacts_[j] = Compact::from_kmer_set(set_j);
+        compacts_[j] = Compact::from_kmer_set(set_j, canon, true);
         sampled[j] = compacts_[j].template sampled<KeyT>(bucket_ids, canon);
-        compacts_[k] = Compact::from_kmer_set(set_k);
+        compacts_[k] = Compact::from_kmer_set(set_k, canon, true);
         sampled[k] = compacts_[k].template sampled<KeyT>(bucket_ids, canon);
         children_[j].push_back(n);
         children_[k].push_back(n);

@@ -1,11 +1,15 @@
 // ORACLE (test infrastructure, not product code).
 //
-// CPU restatement of the reference's canonical SPSS algorithms, with the
-// reference's n_workers == 1 control flow and the oracle's ordering rule
-// (KmerSet::find ascending).  Strings are ASCII over ACGT as in the reference.
+// CPU restatement of the reference's SPSS algorithms (canonical fast and slow, and the
+// non-canonical variant), with the reference's n_workers == 1 control flow and the oracle's
+// ordering rule (KmerSet::find ascending).  Strings are ASCII over ACGT as in the reference.
 //
 // Follows lib/core/spss.h:
 //   :27-41      internal::ConcatenateKmers            -> concatenate_kmers
+//   :73-227     GetUnitigs (non-canonical)            -> unitigs_directed
+//   :697-1014   GetSPSS(unitigs, prefixes)            -> spss_directed_from_unitigs
+//   :1018-1036  GetSPSS(kmer_set)                     -> spss_directed
+//   :1208-1356  GetSPSSCanonical, fast == false       -> spss_canonical_from_unitigs(fast = false)
 //   :230-615    GetUnitigsCanonical                   -> unitigs_canonical
 //       :238-273  GetNeighborsRight / GetNeighborsLeft
 //       :276-313  IsTerminalLeft / IsTerminalRight
@@ -207,10 +211,11 @@ inline EndMap suffixes_from_unitigs(const std::vector<std::string>& unitigs, int
   return m;
 }
 
-// fast == true, n_workers == 1.
+// n_workers == 1; fast == false is the reference's one-thread path extension (:1208-1356).
 inline std::vector<std::string> spss_canonical_from_unitigs(const std::vector<std::string>& unitigs,
                                                             const EndMap& prefixes,
-                                                            const EndMap& suffixes, int k) {
+                                                            const EndMap& suffixes, int k,
+                                                            bool fast = true) {
   const std::int64_t n = static_cast<std::int64_t>(unitigs.size());
   using Edge = std::pair<std::int64_t, bool>;  // (node, same side)
 
@@ -294,6 +299,57 @@ inline std::vector<std::string> spss_canonical_from_unitigs(const std::vector<st
 
   const auto has_left = [&](std::int64_t i) { return edge_left.find(i) != edge_left.end(); };
   const auto has_right = [&](std::int64_t i) { return edge_right.find(i) != edge_right.end(); };
+
+  if (!fast) {
+    // :1208-1322: from every node without an edge yet, extend one path as far as it goes.
+    for (std::int64_t i = 0; i < n; i++) {
+      if (has_left(i) || has_right(i)) continue;
+      std::int64_t current = i;
+      bool is_right_side;
+      {
+        const std::vector<Edge> er = edges_right(current);
+        const std::vector<Edge> el = edges_left(current);
+        if (er.empty() && el.empty()) continue;
+        is_right_side = !er.empty();
+      }
+      while (true) {
+        auto& mine = is_right_side ? edge_right : edge_left;
+        if (mine.find(current) != mine.end()) break;
+        const std::vector<Edge> edges = is_right_side ? edges_right(current) : edges_left(current);
+        if (edges.empty()) break;
+        std::int64_t nx = -1;
+        bool is_same_side = false, found = false;
+        for (const Edge& e : edges) {
+          nx = e.first;
+          is_same_side = e.second;
+          if (nx == i) continue;  // would close a loop
+          // the side of nx this edge lands on: the same side as ours, or the opposite one
+          const bool lands_right = is_same_side ? is_right_side : !is_right_side;
+          if (lands_right ? has_right(nx) : has_left(nx)) continue;
+          found = true;
+          break;
+        }
+        if (!found) break;
+        mine[current] = {nx, is_same_side};
+        if (is_same_side) {
+          mine[nx] = {current, is_same_side};
+          is_right_side = !is_right_side;
+        } else {
+          (is_right_side ? edge_left : edge_right)[nx] = {current, is_same_side};
+        }
+        current = nx;
+      }
+    }
+    // :1328-1350
+    std::vector<std::string> spss;
+    for (std::int64_t i = 0; i < n; i++) {
+      const bool hl = has_left(i), hr = has_right(i);
+      if (hl && hr) continue;
+      const Path path = hr ? find_path(i, true) : find_path(i, false);
+      if (path.front().first <= path.back().first) spss.push_back(string_from_path(path));
+    }
+    return spss;
+  }
 
   for (std::int64_t i = 0; i < n; i++) {
     for (const Edge& e : edges_right(i)) {
@@ -387,12 +443,161 @@ inline std::vector<std::string> spss_canonical_from_unitigs(const std::vector<st
 }
 
 template <typename KeyT>
-std::vector<std::string> spss_canonical(const KmerSet<KeyT>& kmer_set) {
+std::vector<std::string> spss_canonical(const KmerSet<KeyT>& kmer_set, bool fast = true) {
   const int k = kmer_set.geom().k;
   const std::vector<std::string> unitigs = unitigs_canonical(kmer_set);
   const EndMap prefixes = prefixes_from_unitigs(unitigs, k);
   const EndMap suffixes = suffixes_from_unitigs(unitigs, k);
-  return spss_canonical_from_unitigs(unitigs, prefixes, suffixes, k);
+  return spss_canonical_from_unitigs(unitigs, prefixes, suffixes, k, fast);
+}
+
+// ---- non-canonical variant: k-mers as they are, edges only forward -------------------------
+// :73-227.  Ordering rule as above: start k-mers and the loop pass ascend.
+template <typename KeyT>
+std::vector<std::string> unitigs_directed(const KmerSet<KeyT>& kmer_set) {
+  const int k = kmer_set.geom().k;
+
+  const auto nexts = [&](std::uint64_t kmer, std::uint64_t* out) {
+    int cnt = 0;
+    for (int c = 0; c < 4; c++) {
+      const std::uint64_t nx = next(kmer, k, c);
+      if (nx != kmer && kmer_set.contains(nx)) out[cnt++] = nx;
+    }
+    return cnt;
+  };
+  const auto prevs = [&](std::uint64_t kmer, std::uint64_t* out) {
+    int cnt = 0;
+    for (int c = 0; c < 4; c++) {
+      const std::uint64_t pv = prev(kmer, k, c);
+      if (pv != kmer && kmer_set.contains(pv)) out[cnt++] = pv;
+    }
+    return cnt;
+  };
+
+  // :96-116: no incoming edge, several, or the one predecessor branches.
+  const auto is_start = [&](std::uint64_t kmer) {
+    std::uint64_t p[4], q[4];
+    const int np = prevs(kmer, p);
+    if (np != 1) return true;
+    return nexts(p[0], q) >= 2;
+  };
+  // :119-146
+  const auto is_end = [&](std::uint64_t kmer) {
+    std::uint64_t p[4], q[4];
+    const int nn = nexts(kmer, p);
+    if (nn != 1) return true;
+    return prevs(p[0], q) >= 2;
+  };
+
+  const std::vector<std::uint64_t> start_kmers = kmer_set.find(is_start);
+
+  std::vector<std::string> unitigs;
+  std::unordered_set<std::uint64_t> visited;
+  visited.reserve(static_cast<std::size_t>(kmer_set.size()));
+
+  for (std::uint64_t start : start_kmers) {  // :159-199
+    std::vector<std::uint64_t> path;
+    std::uint64_t current = start;
+    while (true) {
+      visited.insert(current);
+      path.push_back(current);
+      if (is_end(current)) break;
+      std::uint64_t q[4];
+      nexts(current, q);
+      current = q[0];
+    }
+    unitigs.push_back(concatenate_kmers(path, k));
+  }
+
+  // :203-224: loops in which every k-mer has one incoming and one outgoing edge.
+  const std::vector<std::uint64_t> not_visited =
+      kmer_set.find([&](std::uint64_t kmer) { return visited.find(kmer) == visited.end(); });
+  for (std::uint64_t kmer : not_visited) {
+    if (visited.find(kmer) != visited.end()) continue;
+    std::uint64_t current = kmer;
+    std::vector<std::uint64_t> path;
+    while (visited.find(current) == visited.end()) {
+      path.push_back(current);
+      visited.insert(current);
+      std::uint64_t q[4];
+      nexts(current, q);
+      current = q[0];
+    }
+    unitigs.push_back(concatenate_kmers(path, k));
+  }
+  return unitigs;
+}
+
+// :697-1014, n_workers == 1.
+inline std::vector<std::string> spss_directed_from_unitigs(const std::vector<std::string>& unitigs,
+                                                           const EndMap& prefixes, int k) {
+  const std::int64_t n = static_cast<std::int64_t>(unitigs.size());
+
+  const auto edges_out = [&](std::int64_t i) {  // :706-726
+    std::vector<std::int64_t> edges;
+    const std::string& u = unitigs[i];
+    const std::uint64_t suffix = kmer_from_string(u.data() + u.length() - k, k);
+    for (int c = 0; c < 4; c++) {
+      auto it = prefixes.find(next(suffix, k, c));
+      if (it == prefixes.end()) continue;
+      for (std::int64_t j : it->second)
+        if (i != j) edges.push_back(j);
+    }
+    return edges;
+  };
+
+  std::unordered_map<std::int64_t, std::int64_t> edge_in, edge_out;
+
+  for (std::int64_t i = 0; i < n; i++) {  // :797-815
+    for (std::int64_t j : edges_out(i)) {
+      if (edge_out.find(i) == edge_out.end() && edge_in.find(j) == edge_in.end()) {
+        edge_out[i] = j;
+        edge_in[j] = i;
+      }
+    }
+  }
+
+  {  // :853-929
+    DisjointSet ds(static_cast<int>(n));
+    for (std::int64_t i = 0; i < n; i++) {
+      auto it = edge_out.find(i);
+      if (it != edge_out.end()) ds.unite(static_cast<int>(i), static_cast<int>(it->second));
+    }
+    std::unordered_set<int> groups, groups_with_terminals;
+    for (std::int64_t i = 0; i < n; i++) {
+      const int group = ds.find(static_cast<int>(i));
+      groups.insert(group);
+      if (edge_out.find(i) == edge_out.end()) groups_with_terminals.insert(group);
+    }
+    for (int i : groups) {
+      if (groups_with_terminals.find(i) != groups_with_terminals.end()) continue;
+      const std::int64_t j = edge_out[i];
+      edge_out.erase(i);
+      edge_in.erase(j);
+    }
+  }
+
+  std::vector<std::string> spss;  // :931-1011
+  for (std::int64_t start = 0; start < n; start++) {
+    if (edge_in.find(start) != edge_in.end()) continue;
+    std::string s = unitigs[start];
+    std::int64_t current = start;
+    while (true) {
+      auto it = edge_out.find(current);
+      if (it == edge_out.end()) break;
+      current = it->second;
+      s += unitigs[current].substr(k - 1, unitigs[current].length() - (k - 1));
+    }
+    spss.push_back(std::move(s));
+  }
+  return spss;
+}
+
+template <typename KeyT>
+std::vector<std::string> spss_directed(const KmerSet<KeyT>& kmer_set) {
+  const int k = kmer_set.geom().k;
+  const std::vector<std::string> unitigs = unitigs_directed(kmer_set);
+  return spss_directed_from_unitigs(unitigs, prefixes_from_unitigs(unitigs, k), k);
 }
 
 template <typename KeyT>

@@ -82,12 +82,15 @@ def lib():
         "ko_unitigs_canonical": (vp, [vp]),
         "ko_spss_canonical": (vp, [vp]),
         "ko_spss_from_unitigs": (vp, [vp, i]),
+        "ko_spss_variant": (vp, [vp, i]),
+        "ko_unitigs_directed": (vp, [vp]),
         "ko_set_from_spss": (vp, [vp, i, i, i, i]),
         "ko_svb_max_compressed_bytes": (i64, [u32]),
         "ko_svb_encode_0124": (i64, [u32p, u32, u8p]),
         "ko_svb_decode_0124": (i64, [u8p, u32p, u32]),
         "ko_compact_from_strings": (vp, [vp, i, i, i]),
         "ko_compact_from_set": (vp, [vp]),
+        "ko_compact_from_set_variant": (vp, [vp, i, i]),
         "ko_compact_free": (None, [vp]),
         "ko_compact_to_set": (vp, [vp, i]),
         "ko_compact_to_strings": (vp, [vp]),
@@ -239,8 +242,22 @@ class Set:
     def spss(self):
         return Strings(lib().ko_spss_canonical(self.h)).to_list()
 
-    def compact(self):
-        return Compact(self.k, self.n, self.key_bytes, lib().ko_compact_from_set(self.h))
+    def spss_slow(self):
+        """GetSPSSCanonical(kmer_set, fast = false)."""
+        return Strings(lib().ko_spss_variant(self.h, 1)).to_list()
+
+    def unitigs_directed(self):
+        """GetUnitigs: the non-canonical variant."""
+        return Strings(lib().ko_unitigs_directed(self.h)).to_list()
+
+    def spss_directed(self):
+        """GetSPSS: the non-canonical variant."""
+        return Strings(lib().ko_spss_variant(self.h, 2)).to_list()
+
+    def compact(self, canonical=True, fast=True):
+        """KmerSetCompact::FromKmerSet(set, canonical, fast, 1)."""
+        return Compact(self.k, self.n, self.key_bytes,
+                       lib().ko_compact_from_set_variant(self.h, int(canonical), int(fast)))
 
     @classmethod
     def from_spss(cls, strings, k, n, key_bytes, canonical=True):

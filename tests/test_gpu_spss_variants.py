@@ -1,0 +1,179 @@
+"""GPU parity tests for the other two SPSS constructions of KmerSetCompact::FromKmerSet
+(lib/core/kmer_set_compact.h:36-47), through the C ABI, against the oracle on the same inputs,
+string for string and in order:
+  canonical == false : GetUnitigs / GetSPSS (lib/core/spss.h:73-227, :697-1036), and the
+                       KmerSetSet loop on non-canonical sets;
+  fast == false      : GetSPSSCanonical's one-thread path extension (lib/core/spss.h:1208-1356).
+The reference's own tests hold these to the invariants only (test/spss.cc:15-40,71-96,99-124:
+every k-mer of the set exactly once); those are checked too."""
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from kmersets import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(gpu):
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def dev_set(ctx, k, n, kmers):
+    return capi.DeviceSet.from_kmers(capi.geom(k, n), np.asarray(kmers, dtype=np.uint64), ctx.device)
+
+
+def check_directed(ctx, k, n, kb, kmers):
+    oset = ol.Set.from_kmers(k, n, kb, kmers)
+    d = dev_set(ctx, k, n, oset.kmers())
+    assert ctx.spss_encode(d, mode=1, canonical=False).to_strings() == oset.unitigs_directed()
+    want = oset.spss_directed()
+    for mode in (0, 2):                       # FromKmerSet ignores `fast` when canonical is false
+        sp = ctx.spss_encode(d, mode=mode, canonical=False)
+        assert sp.to_strings() == want
+    assert sp.n_strings == len(want) and sp.n_bases == sum(len(x) for x in want)
+    assert sp.weight() == oset.compact(canonical=False).weight()
+    assert ctx.spss_size(sp) == d.n_keys                        # no k-mer twice
+    back = ctx.spss_decode(sp, canonical=False)
+    assert back.n_keys == d.n_keys and ctx.set_diff(back, d) == 0
+    return ctx.spss_encode_stats()
+
+
+def check_slow(ctx, k, n, kb, kmers):
+    oset = ol.Set.from_kmers(k, n, kb, kmers)
+    d = dev_set(ctx, k, n, oset.kmers())
+    want = oset.spss_slow()
+    sp = ctx.spss_encode(d, mode=2)
+    assert sp.to_strings() == want
+    assert sp.weight() == oset.compact(fast=False).weight()
+    assert ctx.spss_size(sp) == d.n_keys
+    back = ctx.spss_decode(sp)
+    assert back.n_keys == d.n_keys and ctx.set_diff(back, d) == 0
+    return sp
+
+
+def forward_kmers(seq, k):
+    return np.unique(synth.kmers_of_bases(synth.bases_of_string(seq), k))
+
+
+# ---------------------------------------------------------------------- canonical == false
+def test_directed_small_shapes(ctx):
+    k, n, kb = 5, 3, 1
+    for seq in ["AACCGTTAGCAT", "ACGTACGTACG", "AAAAAAAAA", "AACCGGTT", "ATATATATAT",
+                "GATTACAGATTACAGATTACA", "CCCCCCGGGGGG", "ACGTA"]:
+        check_directed(ctx, k, n, kb, forward_kmers(seq, k))
+    # a k-mer and its reverse complement are two unrelated members here
+    check_directed(ctx, k, n, kb, np.array([ol.kmer("ACGTT"), ol.kmer("AACGT")], dtype=np.uint64))
+    e = dev_set(ctx, k, n, np.zeros(0, dtype=np.uint64))
+    sp = ctx.spss_encode(e, mode=0, canonical=False)
+    assert sp.n_strings == 0 and sp.n_bases == 0
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_directed_random_reads(ctx, seed):
+    """test/spss.cc:15-40,71-96 shapes (K = 9, N = 10, GetRandomKmerSet(canonical = false))."""
+    k = [5, 7, 9, 9, 11, 15, 9, 9][seed]
+    size = [50, 300, 2000, 20000, 3000, 3000, 65536, 1][seed]
+    km = synth.random_read_kmers(k, min(size, 4 ** k // 3), seed=seed, canonical=False)
+    check_directed(ctx, k, min(10, 2 * k - 4), 4, km)
+
+
+def test_directed_dense_graphs(ctx):
+    """Random subsets of all 4^5 (4^6) k-mers: every branching pattern, loops of unitigs in the
+    path cover (the union-by-rank root decides the cut, spss.h:853-929) and self-loops."""
+    rng = np.random.default_rng(21)
+    for trial in range(40):
+        k = 5 if trial % 2 == 0 else 6
+        m = int(rng.integers(1, 4 ** k))
+        km = np.unique(rng.integers(0, 4 ** k, size=m, dtype=np.uint64))
+        check_directed(ctx, k, min(10, 2 * k - 4), 4, km)
+
+
+def test_directed_loops(ctx):
+    for seed in range(40):
+        k = [5, 7, 9, 11][seed % 4]
+        km = synth.circular_with_tails(k, 20 + (seed * 7) % 150, seed % 5, 1 + seed % 4, seed,
+                                       canonical_form=False)
+        check_directed(ctx, k, min(10, 2 * k - 4), 4, km)
+
+
+@pytest.mark.parametrize("geom", [(15, 14, 2), (23, 14, 4), (31, 14, 8)])
+def test_directed_genomes(ctx, geom):
+    k, n, kb = geom
+    genomes = synth.phylogeny_genomes(3, 30000 + k - 1, seed=k)
+    sets = [np.unique(synth.kmers_of_bases(g, k)) for g in genomes]
+    stats = check_directed(ctx, k, n, kb, sets[0])
+    assert stats["unitigs"] >= 1
+    check_directed(ctx, k, n, kb, np.intersect1d(sets[0], sets[1]))
+    check_directed(ctx, k, n, kb, np.setdiff1d(sets[0], sets[1]))
+
+
+def test_directed_kmer_set_set(ctx):
+    """KmerSetSet(compacts, canonical = false, ...): trace, DAG, every node's strings and Get(i)
+    equal to the oracle's (kmer_set_set.h:109-454 with FromKmerSet / ToKmerSet non-canonical)."""
+    k, n, kb = 15, 14, 2
+    genomes = synth.phylogeny_genomes(6, 20000 + k - 1, seed=12)
+    sets = [np.unique(synth.kmers_of_bases(g, k)) for g in genomes]
+    osets = [ol.Set.from_kmers(k, n, kb, s) for s in sets]
+    ocompacts = [s.compact(canonical=False) for s in osets]
+    ids = synth.sample_bucket_ids(n, seed=13)
+    okss = ol.KmerSetSet(ocompacts, ids, canonical=False)
+    g = capi.geom(k, n)
+    dcompacts = [capi.DeviceSpss.from_strings(g, c.strings(), ctx.device) for c in ocompacts]
+    dkss = capi.DeviceKmerSetSet(ctx, dcompacts, ids, canonical=False)
+    it, cp, imp = dkss.trace()
+    assert np.array_equal(it, okss.iterations()) and it.shape[0] > 0
+    ocp, oimp = okss.checkpoints()
+    assert np.array_equal(cp, ocp) and np.array_equal(imp, oimp)
+    assert dkss.size() == okss.size() and dkss.meta() == okss.meta()
+    for i in range(okss.size()):
+        assert dkss.node_strings(i) == okss.node(i).strings(), "node %d" % i
+    for i in range(len(sets)):
+        assert np.array_equal(dkss.get_kmers(i), sets[i])
+    dkss.close()
+
+
+# ---------------------------------------------------------------------- fast == false
+def test_slow_small_shapes(ctx):
+    k, n, kb = 5, 3, 1
+    for seq in ["AACCGTTAGCAT", "ACGTACGTACG", "AAAAAAAAA", "AACCGGTT", "ACGTTGCAACGT", "ATATATATAT",
+                "GATTACAGATTACAGATTACA", "CCCCCCGGGGGG"]:
+        check_slow(ctx, k, n, kb, synth.canonical_set_of_bases(synth.bases_of_string(seq), k))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_slow_random_reads(ctx, seed):
+    """test/spss.cc:99-124 (GetSPSSCanonical(kmer_set, false, n_workers))."""
+    k = [5, 7, 9, 9, 11, 15][seed]
+    size = [50, 300, 2000, 20000, 3000, 3000][seed]
+    km = synth.random_read_kmers(k, min(size, 4 ** k // 3), seed=seed, canonical=True)
+    check_slow(ctx, k, min(10, 2 * k - 4), 4, km)
+
+
+def test_slow_dense_graphs_and_loops(ctx):
+    """Odd k only: with an even k a k-mer can be its own reverse complement, which no canonical
+    instantiation of the reference has (K = 15, 19, 23; the tests use 9)."""
+    rng = np.random.default_rng(22)
+    for trial in range(30):
+        k = 5 if trial % 2 == 0 else 7
+        m = int(rng.integers(1, 4 ** k))
+        km = np.unique(synth.canonical(rng.integers(0, 4 ** k, size=m, dtype=np.uint64), k))
+        n = min(10, 2 * k - 4)
+        check_slow(ctx, k, n, 4, km)
+        # the fast construction on the same dense graphs (not reached by the read-shaped cases)
+        fast = ctx.spss_encode(dev_set(ctx, k, n, km), mode=0)
+        assert fast.to_strings() == ol.Set.from_kmers(k, n, 4, km).spss()
+    for seed in range(20):
+        k = [5, 7, 9, 11][seed % 4]
+        km = synth.circular_with_tails(k, 20 + (seed * 7) % 150, seed % 5, 1 + seed % 4, seed)
+        check_slow(ctx, k, min(10, 2 * k - 4), 4, km)
+
+
+def test_slow_family(ctx):
+    k, n, kb = 23, 14, 4
+    sets = synth.phylogeny_sets(k, 2, 30000, seed=3)
+    check_slow(ctx, k, n, kb, sets[0])
+    check_slow(ctx, k, n, kb, np.setdiff1d(sets[0], sets[1]))

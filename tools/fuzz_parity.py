@@ -111,6 +111,20 @@ def main():
                 again = ctx.spss_from_text(g, text)
                 assert again.to_strings() == strings
             n_cases["spss"] += 1
+            # the other two constructions of FromKmerSet: fast == false, and canonical == false on
+            # the k-mers as they are (here: the same values read as a non-canonical set, and a
+            # small dense random graph)
+            if km.size <= 20000 and k % 2 == 1:
+                assert ctx.spss_encode(ds, mode=2).to_strings() == oset.spss_slow()
+            fw = km if rng.random() < 0.5 else np.unique(rng.integers(0, 4 ** min(k, 6), size=int(rng.integers(1, 3000)), dtype=np.uint64))
+            if fw.size <= 20000:
+                fset = ol.Set.from_kmers(k, n, kb, fw)
+                fd = capi.DeviceSet.from_kmers(g, fw, ctx.device)
+                fsp = ctx.spss_encode(fd, mode=0, canonical=False)
+                assert fsp.to_strings() == fset.spss_directed()
+                assert ctx.spss_encode(fd, mode=1, canonical=False).to_strings() == fset.unitigs_directed()
+                assert ctx.set_diff(ctx.spss_decode(fsp, canonical=False), fd) == 0
+                n_cases["variants"] = n_cases.get("variants", 0) + 1
 
         # counting: random reads with N's against the oracle
         if k >= 5 and rng.random() < 0.5:

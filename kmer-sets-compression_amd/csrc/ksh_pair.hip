@@ -389,7 +389,38 @@ __global__ __launch_bounds__(kThreads * kGroupWaves) void k_tile_merge(
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kThreads);  // uniform: stays scalar
   KeyT* const lds = lds_all[wave];
   const int64_t t_first = (int64_t(blockIdx.x) * kGroupWaves + wave) * tiles_per_wave;
-  const int64_t n_tiles = *total_tiles;
+
+  // Everything a tile needs besides its keys: the descriptor, and for the write pass the lane's
+  // saved split, the tile's prefix of common keys and (batch launches) its pair's outputs.  All
+  // of it is requested in one go, before anything waits: a wave's life is mostly memory round
+  // trips, and these used to be five of them in a row (tile count, descriptor, keys, split,
+  // prefix / owner / pair).
+  struct TileMeta {
+    int64_t ioff;
+    TileOwner own;
+  };
+  auto load_meta = [&](int64_t t) {
+    TileMeta m{};
+    if constexpr (kWrite) {
+      m.ioff = tile_ioff[t];
+      // (unconditional, so that it travels with the others: without a batch the value is unused
+      // and the descriptor array stands in as readable memory)
+      m.own = *(batch ? owner + t : reinterpret_cast<const TileOwner*>(desc + t));
+    }
+    return m;
+  };
+  // The first tile's requests go out before the tile count is known; tile max_tiles - 1 is
+  // allocated whatever the count turns out to be (launches have max_tiles >= 1).
+  const int64_t t_safe = min(t_first, max_tiles - 1);
+  TileDesc d_next = desc[t_safe];
+  TileMeta m_next = load_meta(t_safe);
+  int64_t n_tiles = *total_tiles;
+  // The scalar requests above have to be out before the early exit below needs the tile count
+  // (left alone, the compiler sinks them past that branch, one more round trip each).  The
+  // statement ties them to the count by data flow only: it is not volatile, because a volatile
+  // asm counts as a possible store and every load after it would stop being a scalar load.
+  asm("" : "+s"(n_tiles) : "s"(d_next.a_keys), "s"(d_next.b_keys), "s"(d_next.a0), "s"(d_next.a1),
+      "s"(d_next.b0), "s"(d_next.b1), "s"(m_next.ioff), "s"(m_next.own.seg));
   const int64_t t_end = min(t_first + tiles_per_wave, n_tiles);
   if (!kWrite) {
     // the prefix scan over tile_m runs to max_tiles: tiles that do not exist count zero
@@ -400,7 +431,8 @@ __global__ __launch_bounds__(kThreads * kGroupWaves) void k_tile_merge(
 
   KSH_MARK(0, t_first);
   // Everything after a tile's keys are in LDS (and a barrier has passed).
-  auto process = [&](const TileDesc& d, const Stage& st, int64_t t) {
+  auto process = [&](const TileDesc& d, const Stage& st, int64_t t, const TileMeta& meta,
+                     const BatchPair& bp, uint32_t saved_split) {
     KSH_MARK(2, t);
 #ifdef KSH_TRACE
     if (g_tile_stop_after == 1) {
@@ -423,7 +455,7 @@ __global__ __launch_bounds__(kThreads * kGroupWaves) void k_tile_merge(
     const int s0 = a_lo + b_lo + d0;  // i + (LDS index of B's head) at step 0
     int i;                            // LDS index of A's head
     if constexpr (kWrite) {
-      i = a_lo + int(split[t * kThreads + lane]);
+      i = a_lo + int(saved_split);
     } else {
       // The answer is the number of m in [m_lo, m_hi) with a[m] <= b[d0 - 1 - m] (true for a
       // prefix).  Bit-by-bit descent with a wave-uniform trip count: `pos` is the last index
@@ -500,9 +532,8 @@ __global__ __launch_bounds__(kThreads * kGroupWaves) void k_tile_merge(
       const uint32_t excl_i = excl & 0xFFFF, excl_a = excl >> 16;
       const uint32_t excl_b = uint32_t(d0) - 2 * excl_i - excl_a + uint32_t(straddle);
       wave_sync();  // every lane is done reading the inputs: reuse the LDS for compaction
-      int64_t ioff = tile_ioff[t];
+      int64_t ioff = meta.ioff;
       if (batch) {  // a batch launch: this tile's pair says where its results go
-        const BatchPair bp = batch[owner[t].seg >> batch_bucket_bits];
         out_i = static_cast<KeyT*>(bp.out_i);
         out_amb = static_cast<KeyT*>(bp.out_amb);
         out_bma = static_cast<KeyT*>(bp.out_bma);
@@ -565,16 +596,25 @@ __global__ __launch_bounds__(kThreads * kGroupWaves) void k_tile_merge(
   };
 
   // One tile after the other; the next tile's descriptor is fetched while this one is merged.
-  TileDesc d_next = desc[t_first];
   for (int64_t t = t_first; t < t_end; t++) {
     const TileDesc d = d_next;
-    if (t + 1 < t_end) d_next = desc[t + 1];
+    const TileMeta meta = m_next;
+    BatchPair bp{};
+    if constexpr (kWrite) {
+      if (batch) bp = batch[meta.own.seg >> batch_bucket_bits];  // in flight with the keys
+    }
+    if (t + 1 < t_end) {
+      d_next = desc[t + 1];
+      m_next = load_meta(t + 1);
+    }
+    uint32_t saved_split = 0;
+    if constexpr (kWrite) saved_split = split[t * kThreads + lane];  // ahead of the keys, not after them
     Stage st;
     st.init(d);
     KSH_MARK(1, t);
     st.copy(lds);
     wave_sync();
-    process(d, st, t);
+    process(d, st, t, meta, bp, saved_split);
   }
 }
 

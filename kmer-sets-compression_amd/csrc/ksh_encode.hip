@@ -70,9 +70,9 @@ __global__ __launch_bounds__(256) void k_fine_index(const int64_t* __restrict__ 
 
 template <typename KeyT, bool kDirected>
 __global__ __launch_bounds__(256) void k_adjacency(DevSet<KeyT> set, uint32_t* __restrict__ nbr) {
-  __shared__ int64_t s_bucket;
+  __shared__ int64_t s_bucket[2];
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  const uint64_t x = set.kmer_in_block(t, &s_bucket);
+  const uint64_t x = set.kmer_in_block(t, s_bucket);
   if (t >= set.n) return;
   const int k = set.k;
   int cnt[2] = {0, 0};
@@ -81,21 +81,11 @@ __global__ __launch_bounds__(256) void k_adjacency(DevSet<KeyT> set, uint32_t* _
     // Non-canonical sets (GetUnitigs, spss.h:76-96): k-mers as they are, side 1 = outgoing edges
     // Next(x, .) (four consecutive values, one bounded search), side 0 = incoming edges
     // Prev(x, .) (four buckets, probed one by one); no edge flips an orientation.
-    {
-      const uint64_t g0 = kmer_next(x, k, 0);
-      int64_t end;
-      const int64_t p0 = set.lower_bound(g0, &end);
-      const uint64_t gkey = g0 & set.key_mask();
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        const int64_t idx = p0 + e;
-        if (idx >= end) break;
-        if (uint64_t(set.keys[idx]) - gkey >= 4) break;
-        if (idx == t) continue;  // next != kmer (spss.h:81)
-        cnt[1]++;
-        single[1] = uint32_t(idx) << 1;
-      }
-    }
+    set.for_group4(kmer_next(x, k, 0), [&](int64_t idx) {
+      if (idx == t) return;  // next != kmer (spss.h:81)
+      cnt[1]++;
+      single[1] = uint32_t(idx) << 1;
+    });
 #pragma unroll
     for (int c = 0; c < 4; c++) {
       const uint64_t z = kmer_prev(x, k, c);
@@ -117,20 +107,11 @@ __global__ __launch_bounds__(256) void k_adjacency(DevSet<KeyT> set, uint32_t* _
   for (int side = 0; side < 2; side++) {
     // group: side 1 -> Next(x, .) (neighbour as is);  side 0 -> Next(rc(x), .) (neighbour
     // reverse-complemented, i.e. a same-side edge)
-    const uint64_t g0 = kmer_next(side ? x : rx, k, 0);
-    int64_t end;
-    const int64_t p0 = set.lower_bound(g0, &end);
-    const uint64_t gkey = g0 & set.key_mask();
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const int64_t idx = p0 + e;
-      if (idx >= end) break;
-      const uint64_t kk = uint64_t(set.keys[idx]);
-      if (kk - gkey >= 4) break;
-      if (idx == t) continue;  // kmer != next (spss.h:242,248)
+    set.for_group4(kmer_next(side ? x : rx, k, 0), [&](int64_t idx) {
+      if (idx == t) return;  // kmer != next (spss.h:242,248)
       cnt[side]++;
       single[side] = (uint32_t(idx) << 1) | (side ? 0u : 1u);
-    }
+    });
     // singles: side 1 -> Prev(rc(x), c) = rc(Next(x, 3 - c));  side 0 -> Prev(x, c) as is
     const uint64_t base = side ? rx : x;
 #pragma unroll
@@ -942,9 +923,9 @@ __global__ __launch_bounds__(256) void k_emit(DevSet<KeyT> set, const uint32_t* 
                                                const uint32_t* __restrict__ uid,
                                                const UnitigPlace* __restrict__ place,
                                                uint8_t* __restrict__ bytes) {
-  __shared__ int64_t s_bucket;
+  __shared__ int64_t s_bucket[2];
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  const uint64_t x = set.kmer_in_block(t, &s_bucket);
+  const uint64_t x = set.kmer_in_block(t, s_bucket);
   if (t >= set.n) return;
   const uint32_t h = head[t];
   if (h == kNone) return;
@@ -1051,7 +1032,8 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   // slices of about 1.5 keys (measured on 10^7- and 10^8-key sets: 9 and 12 bits are the
   // fastest there; fewer bits mean longer slices, more bits a bigger index to build)
   int fine_bits = 0;
-  while (fine_bits < 13 && fine_bits < key_bits(g) && (int64_t(3) << fine_bits) < 2 * (n / nb + 1)) fine_bits++;
+  // (at least four values per slice: the four consecutive candidates of a group probe share one)
+  while (fine_bits < 13 && fine_bits + 2 < key_bits(g) && (int64_t(3) << fine_bits) < 2 * (n / nb + 1)) fine_bits++;
   const bool use_fine = fine_bits >= 2;
   const size_t fine_entries = use_fine ? (size_t(nb) << fine_bits) + 1 : 0;
   const size_t bytes = 2 * al(size_t(2 * n) * 4) + al(size_t(2 * n) * 8) + 5 * al(size_t(n) * 4) +

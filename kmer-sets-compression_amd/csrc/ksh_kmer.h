@@ -48,7 +48,8 @@ struct DevSet {
   // fine_bits key bits are >= sub (nb * 2^fine_bits + 1 entries).  Narrows a membership probe
   // from the whole bucket (~10-13 dependent loads) to a slice of one or two keys; the index is
   // read at the same rate whether it is 16 MB or 256 MB (only an L2-sized one would be faster),
-  // so it is sized for the shortest slices (fine_bits_for).
+  // so it is sized for the shortest slices (fine_bits_for).  Slices are at least four values
+  // wide (fine_bits <= key_bits - 2).
   const uint32_t* fine = nullptr;
   int fine_bits = 0;
 
@@ -56,19 +57,43 @@ struct DevSet {
     return key_bits == 64 ? ~uint64_t(0) : ((uint64_t(1) << key_bits) - 1);
   }
 
+  // Two adjacent array elements in one request (they need not be aligned as a pair).  The encode
+  // kernels are bound by the number of load requests they issue, not by the bytes or the
+  // distinct lines behind them, so the probes below ask for as much as they can per request.
+  template <typename T>
+  __device__ static __forceinline__ void load_pair(const T* p, T* a, T* b) {
+    struct __attribute__((packed, aligned(alignof(T)))) Pair {
+      T x, y;
+    };
+    const Pair v = *reinterpret_cast<const Pair*>(p);
+    *a = v.x;
+    *b = v.y;
+  }
+
+  // [lo, hi) of the keys that can equal `key` (its slice of the fine index, or its bucket).
+  __device__ __forceinline__ void probe_range(int64_t b, KeyT key, int64_t* lo, int64_t* hi) const {
+    if (fine) {
+      uint32_t x, y;
+      load_pair(fine + (b << fine_bits) + int64_t(uint64_t(key) >> (key_bits - fine_bits)), &x, &y);
+      *lo = x;
+      *hi = y;
+    } else {
+      load_pair(off + b, lo, hi);
+    }
+  }
+
   // Index of k-mer z in the set's ascending order, or -1.
   __device__ int64_t find(uint64_t z) const {
     const int64_t b = int64_t(z >> key_bits);
     const KeyT key = KeyT(z & key_mask());
     int64_t lo, hi;
-    if (fine) {
-      const int64_t f = (b << fine_bits) + int64_t(uint64_t(key) >> (key_bits - fine_bits));
-      lo = fine[f];
-      hi = fine[f + 1];
-    } else {
-      lo = off[b];
-      hi = off[b + 1];
-    }
+    probe_range(b, key, &lo, &hi);
+    if (lo >= hi) return -1;
+    if (hi - lo == 1) return keys[lo] == key ? lo : int64_t(-1);
+    KeyT k0, k1;
+    load_pair(keys + lo, &k0, &k1);
+    if (key <= k1) return key == k0 ? lo : (key == k1 ? lo + 1 : int64_t(-1));
+    lo += 2;
     const int64_t end = hi;
     while (lo < hi) {
       const int64_t mid = (lo + hi) >> 1;
@@ -77,25 +102,38 @@ struct DevSet {
     return (lo < end && keys[lo] == key) ? lo : int64_t(-1);
   }
 
-  // First index whose k-mer is >= z inside z's bucket; *end = end of that bucket.
-  __device__ int64_t lower_bound(uint64_t z, int64_t* end) const {
-    const int64_t b = int64_t(z >> key_bits);
-    const KeyT key = KeyT(z & key_mask());
+  // The members among the four consecutive k-mers g0 .. g0 + 3 (g0 ends in base A: they share
+  // a bucket and, slices being at least four values wide, a slice): f(index) for each, ascending.
+  template <typename F>
+  __device__ __forceinline__ void for_group4(uint64_t g0, F f) const {
+    const int64_t b = int64_t(g0 >> key_bits);
+    const KeyT gkey = KeyT(g0 & key_mask());
     int64_t lo, hi;
-    if (fine) {
-      const int64_t f = (b << fine_bits) + int64_t(uint64_t(key) >> (key_bits - fine_bits));
-      lo = fine[f];
-      hi = fine[f + 1];
-    } else {
-      lo = off[b];
-      hi = off[b + 1];
+    probe_range(b, gkey, &lo, &hi);
+    if (lo >= hi) return;
+    if (hi - lo == 1) {
+      if (uint64_t(keys[lo]) - uint64_t(gkey) < 4) f(lo);
+      return;
     }
+    KeyT k0, k1;
+    load_pair(keys + lo, &k0, &k1);
+    if (hi - lo == 2 || k1 >= gkey + 3) {  // nothing after these two can be a member
+      if (uint64_t(k0) - uint64_t(gkey) < 4) f(lo);
+      if (uint64_t(k1) - uint64_t(gkey) < 4) f(lo + 1);
+      return;
+    }
+    const int64_t end = hi;
     while (lo < hi) {
       const int64_t mid = (lo + hi) >> 1;
-      if (keys[mid] < key) lo = mid + 1; else hi = mid;
+      if (keys[mid] < gkey) lo = mid + 1; else hi = mid;
     }
-    *end = off[b + 1];
-    return lo;
+#pragma unroll
+    for (int e = 0; e < 4; e++) {
+      const int64_t idx = lo + e;
+      if (idx >= end) break;
+      if (uint64_t(keys[idx]) - uint64_t(gkey) >= 4) break;
+      f(idx);
+    }
   }
 
   // Bucket holding index t (largest b with off[b] <= t).
@@ -113,16 +151,22 @@ struct DevSet {
   }
 
   // For kernels whose workgroup owns 256 consecutive indices: one binary search per
-  // workgroup (its first index), then every thread steps forward from that bucket.
-  __device__ __forceinline__ uint64_t kmer_in_block(int64_t t, int64_t* lds_first_bucket) const {
+  // workgroup (its first index); lds2[0] = that bucket, lds2[1] = where it ends.  A thread
+  // inside the first bucket asks memory for nothing but its key; the others step forward.
+  __device__ __forceinline__ uint64_t kmer_in_block(int64_t t, int64_t* lds2) const {
     if (threadIdx.x == 0) {
       const int64_t t0 = int64_t(blockIdx.x) * blockDim.x;
-      *lds_first_bucket = bucket_of(t0 < n ? t0 : n - 1);
+      const int64_t b0 = bucket_of(t0 < n ? t0 : n - 1);
+      lds2[0] = b0;
+      lds2[1] = off[b0 + 1];
     }
     __syncthreads();
     if (t >= n) return 0;
-    int64_t b = *lds_first_bucket;
-    while (off[b + 1] <= t) b++;
+    int64_t b = lds2[0];
+    if (t >= lds2[1]) {
+      b++;
+      while (off[b + 1] <= t) b++;
+    }
     return (uint64_t(b) << key_bits) | uint64_t(keys[t]);
   }
 };

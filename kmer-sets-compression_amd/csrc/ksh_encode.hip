@@ -37,6 +37,13 @@
 
 namespace ksh {
 
+// Sampled rulers: both states of every kRulerEvery-th k-mer (E2).
+#ifndef KSH_RULER_SHIFT
+#define KSH_RULER_SHIFT 4
+#endif
+constexpr int kRulerShift = KSH_RULER_SHIFT;
+constexpr uint32_t kRulerEvery = 1u << kRulerShift;
+
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kMulti = 0xFFFFFFFEu;
 constexpr uint64_t kUnset = ~uint64_t(0);
@@ -154,7 +161,7 @@ __global__ __launch_bounds__(256) void k_links(const uint32_t* __restrict__ nbr,
   reinterpret_cast<ulonglong2*>(info)[t] = make_ulonglong2(kUnset, kUnset);  // chain-rank records
   // which of its two states start a chain without being a sampled ruler (k_ruler_heads):
   // state 2t enters through side 0, state 2t + 1 through side 1
-  const bool sampled = (t & 15) == 0;
+  const bool sampled = (t & (kRulerEvery - 1)) == 0;
   start_flags[t] = sampled ? 0 : uint8_t((out[0] == kNone ? 1 : 0) | (out[1] == kNone ? 2 : 0));
 }
 
@@ -184,7 +191,7 @@ __device__ __forceinline__ uint32_t step_to(uint32_t s, uint32_t lk) {
 // order, so this is as good as a hash), which makes them enumerable without compaction:
 // dense thread i <-> state 32 * (i >> 1) + (i & 1).  The other rulers are chain starts and
 // chain ends; "is a ruler" needs only the state's own link pair, which the walk loads anyway.
-__device__ __forceinline__ bool sampled_ruler(uint32_t s) { return (s & 30u) == 0; }
+__device__ __forceinline__ bool sampled_ruler(uint32_t s) { return (s & (2u * kRulerEvery - 2u)) == 0; }
 
 // Chain-rank records.
 //   rinfo[i] (one per sampled ruler, dense index i): end_flag:1 | dist:31 | next:32 -- the next
@@ -200,7 +207,7 @@ __device__ __forceinline__ bool sampled_ruler(uint32_t s) { return (s & 30u) == 
 constexpr uint64_t kRecUnset = ~uint64_t(0);
 constexpr uint64_t kEndFlag = uint64_t(1) << 63;
 
-__device__ __forceinline__ uint32_t dense_index(uint32_t s) { return ((s >> 5) << 1) | (s & 1); }
+__device__ __forceinline__ uint32_t dense_index(uint32_t s) { return ((s >> (kRulerShift + 1)) << 1) | (s & 1); }
 __device__ __forceinline__ uint64_t make_rec(uint32_t kind, uint32_t off, uint32_t ref) {
   return (uint64_t(kind) << 62) | (uint64_t(off & 0x3FFFFFFFu) << 32) | ref;
 }
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(256) void k_ruler_walk(const uint32_t* __restrict__
                                                      unsigned long long* __restrict__ rec) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n_dense) return;
-  const int64_t s64 = 32 * (i >> 1) + (i & 1);
+  const int64_t s64 = 2 * int64_t(kRulerEvery) * (i >> 1) + (i & 1);
   if (s64 >= n_states) {
     rinfo[i] = make_rinfo(true, 0, 0);
     return;
@@ -1075,7 +1082,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     int* changed = static_cast<int*>(arena_alloc(ctx, 16));
     if (!changed) return fail(KSH_INTERNAL, "scratch arena too small");
     const int64_t ns2 = 2 * n;
-    const int64_t n_dense = 2 * ((n + 15) / 16);
+    const int64_t n_dense = 2 * ((n + kRulerEvery - 1) / kRulerEvery);
     unsigned long long* rinfo = reinterpret_cast<unsigned long long*>(p->c01);  // n_dense * 8 <= 8n
     hipLaunchKernelGGL(k_ruler_walk, dim3(nblk(n_dense)), dim3(256), 0, st, p->link, ns2, n_dense, rinfo,
                        p->info);

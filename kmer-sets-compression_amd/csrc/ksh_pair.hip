@@ -274,44 +274,25 @@ struct TileStage {
   }
   // global -> LDS: every load of both ranges is issued before the first one is waited for
   // (a loop that loads and stores one vector per trip pays one memory round trip per trip).
+  // The two ranges are one sequence of va + vb vectors dealt out 64 at a time, so a lane asks
+  // for kVecs vectors in all, not kVecs per side.
   __device__ __forceinline__ void copy(KeyT* lds) const {
     Vec* l = reinterpret_cast<Vec*>(lds);
     const uint32_t lane = threadIdx.x & (kThreads - 1);
-    Vec ra[Cfg::kVecs], rb[Cfg::kVecs];
-    // Straight-line, unconditional loads: lanes past a range's end re-read its last vector
-    // (one coalesced request), an empty range reads from the other one (a tile is never empty
-    // on both sides); only the stores are predicated.  Conditional loads would make the
-    // compiler wait at every join.
-    const GlobalVecs safe_a = va ? ga : gb, safe_b = vb ? gb : ga;
-    const uint32_t last_a = (va ? va : vb) - 1, last_b = (vb ? vb : va) - 1;
-#pragma unroll
-    for (int j = 0; j < Cfg::kVecs; j++) ra[j] = safe_a[min(lane + j * kThreads, last_a)];
-#pragma unroll
-    for (int j = 0; j < Cfg::kVecs; j++) rb[j] = safe_b[min(lane + j * kThreads, last_b)];
+    Vec r[Cfg::kVecs];
+    // Straight-line, unconditional loads: lanes past the end re-read the last vector (one
+    // coalesced request; a tile is never empty on both sides); only the stores are predicated.
+    // Conditional loads would make the compiler wait at every join.
+    const uint32_t n_vecs = va + vb;
 #pragma unroll
     for (int j = 0; j < Cfg::kVecs; j++) {
-      const uint32_t v = lane + j * kThreads;
-      if (uint32_t(j * kThreads) < va && v < va) l[v] = ra[j];
+      const uint32_t v = min(lane + j * kThreads, n_vecs - 1);
+      r[j] = *(v < va ? ga + v : gb + (v - va));
     }
 #pragma unroll
     for (int j = 0; j < Cfg::kVecs; j++) {
       const uint32_t v = lane + j * kThreads;
-      if (uint32_t(j * kThreads) < vb && v < vb) l[b_vec0 + v] = rb[j];
-    }
-  }
-  __device__ __forceinline__ void load(Vec (&r)[Cfg::kVecs]) const {
-#pragma unroll
-    for (int j = 0; j < Cfg::kVecs; j++) {
-      const uint32_t v = (threadIdx.x & (kThreads - 1)) + j * kThreads;
-      if (v < va + vb) r[j] = *(v < va ? ga + v : gb + (v - va));
-    }
-  }
-  __device__ __forceinline__ void store(const Vec (&r)[Cfg::kVecs], KeyT* lds) const {
-    Vec* l = reinterpret_cast<Vec*>(lds);
-#pragma unroll
-    for (int j = 0; j < Cfg::kVecs; j++) {
-      const uint32_t v = (threadIdx.x & (kThreads - 1)) + j * kThreads;
-      if (v < va + vb) l[v < va ? v : b_vec0 + (v - va)] = r[j];
+      if (uint32_t(j * kThreads) < n_vecs && v < n_vecs) l[v < va ? v : b_vec0 + (v - va)] = r[j];
     }
   }
 };
@@ -372,7 +353,7 @@ __device__ int g_tile_stop_after = 0;  // 1: return once the tile's keys are in 
 template <typename KeyT, int kMode>
 __global__ __launch_bounds__(kThreads * kGroupWaves) void k_tile_merge(
     const TileDesc* __restrict__ desc, const int64_t* __restrict__ total_tiles, int64_t max_tiles,
-    int tiles_per_wave, int64_t* __restrict__ tile_m, const int64_t* __restrict__ tile_ioff,
+    int64_t* __restrict__ tile_m, const int64_t* __restrict__ tile_ioff,
     uint16_t* __restrict__ split, KeyT* __restrict__ out_i, KeyT* __restrict__ out_amb,
     KeyT* __restrict__ out_bma, const BatchPair* __restrict__ batch, const TileOwner* __restrict__ owner,
     int batch_bucket_bits) {
@@ -382,13 +363,14 @@ __global__ __launch_bounds__(kThreads * kGroupWaves) void k_tile_merge(
   constexpr bool kWrite = kMode != 0;
   __shared__ __attribute__((aligned(16))) KeyT lds_all[kGroupWaves][Cfg::kLds];
 
-  // This wave owns tiles [t_first, t_end), consecutive tiles (tiles_per_wave is 1 unless
-  // forced, see tiles_per_wave()), and one slice of the workgroup's LDS.  Nothing below
-  // synchronises across waves: wave_sync() orders this wave's own LDS traffic.
+  // This wave owns one tile and one slice of the workgroup's LDS.  Nothing below synchronises
+  // across waves: wave_sync() orders this wave's own LDS traffic.  (Several consecutive tiles
+  // per wave, with or without the next tile's keys prefetched into registers, measured slower at
+  // every count: DESIGN.md 3.1.)
   const int lane = threadIdx.x & (kThreads - 1);
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kThreads);  // uniform: stays scalar
   KeyT* const lds = lds_all[wave];
-  const int64_t t_first = (int64_t(blockIdx.x) * kGroupWaves + wave) * tiles_per_wave;
+  const int64_t t = int64_t(blockIdx.x) * kGroupWaves + wave;
 
   // Everything a tile needs besides its keys: the descriptor, and for the write pass the lane's
   // saved split, the tile's prefix of common keys and (batch launches) its pair's outputs.  All
@@ -409,30 +391,28 @@ __global__ __launch_bounds__(kThreads * kGroupWaves) void k_tile_merge(
     }
     return m;
   };
-  // The first tile's requests go out before the tile count is known; tile max_tiles - 1 is
-  // allocated whatever the count turns out to be (launches have max_tiles >= 1).
-  const int64_t t_safe = min(t_first, max_tiles - 1);
-  TileDesc d_next = desc[t_safe];
-  TileMeta m_next = load_meta(t_safe);
+  // The requests go out before the tile count is known; tile max_tiles - 1 is allocated
+  // whatever the count turns out to be (launches have max_tiles >= 1).
+  const int64_t t_safe = min(t, max_tiles - 1);
+  const TileDesc d = desc[t_safe];
+  const TileMeta meta = load_meta(t_safe);
   int64_t n_tiles = *total_tiles;
   // The scalar requests above have to be out before the early exit below needs the tile count
   // (left alone, the compiler sinks them past that branch, one more round trip each).  The
   // statement ties them to the count by data flow only: it is not volatile, because a volatile
   // asm counts as a possible store and every load after it would stop being a scalar load.
-  asm("" : "+s"(n_tiles) : "s"(d_next.a_keys), "s"(d_next.b_keys), "s"(d_next.a0), "s"(d_next.a1),
-      "s"(d_next.b0), "s"(d_next.b1), "s"(m_next.ioff), "s"(m_next.own.seg));
-  const int64_t t_end = min(t_first + tiles_per_wave, n_tiles);
-  if (!kWrite) {
+  asm("" : "+s"(n_tiles) : "s"(d.a_keys), "s"(d.b_keys), "s"(d.a0), "s"(d.a1), "s"(d.b0), "s"(d.b1),
+      "s"(meta.ioff), "s"(meta.own.seg));
+  if (t >= n_tiles) {
     // the prefix scan over tile_m runs to max_tiles: tiles that do not exist count zero
-    const int64_t z = max(t_first, n_tiles) + lane;
-    if (z < min(t_first + tiles_per_wave, max_tiles)) tile_m[z] = 0;
+    if (!kWrite && lane == 0 && t < max_tiles) tile_m[t] = 0;
+    return;
   }
-  if (t_first >= t_end) return;
 
-  KSH_MARK(0, t_first);
+  KSH_MARK(0, t);
   // Everything after a tile's keys are in LDS (and a barrier has passed).
   auto process = [&](const TileDesc& d, const Stage& st, int64_t t, const TileMeta& meta,
-                     const BatchPair& bp, uint32_t saved_split) {
+                     uint32_t saved_split) {
     KSH_MARK(2, t);
 #ifdef KSH_TRACE
     if (g_tile_stop_after == 1) {
@@ -504,6 +484,13 @@ __global__ __launch_bounds__(kThreads * kGroupWaves) void k_tile_merge(
         i += int(take_a);
       }
     }
+    // (batch launches) where this tile's pair wants its results: asked for here, behind the
+    // merge, so that nothing waits for it -- ahead of the key loads it held them back by one
+    // more scalar round trip
+    BatchPair bp{};
+    if constexpr (kWrite) {
+      if (batch) bp = batch[meta.own.seg >> batch_bucket_bits];
+    }
     if constexpr (kWrite) {
       m_a <<= kVT - n_steps;  // step's bit is bit (kVT - 1 - step) whatever n_steps is
       m_x = (m_x << (kVT - n_steps)) | ((1u << (kVT - n_steps)) - 1);  // steps not run: dropped
@@ -526,7 +513,6 @@ __global__ __launch_bounds__(kThreads * kGroupWaves) void k_tile_merge(
     if constexpr (!kWrite) {
       if (lane == 0) tile_m[t] = tot_i;
       KSH_MARK(5, t);
-      wave_sync();  // all reads of this tile's keys are done before the next tile lands
     } else {
       KSH_MARK(5, t);
       const uint32_t excl_i = excl & 0xFFFF, excl_a = excl >> 16;
@@ -591,31 +577,17 @@ __global__ __launch_bounds__(kThreads * kGroupWaves) void k_tile_merge(
         if (out_bma) copy_out(lds, tot_i + tot_a, tot_b, out_bma + (d.b0 - ioff));
       }
       KSH_MARK(7, t);
-      wave_sync();  // the compacted keys are read out before the next tile lands
     }
   };
 
-  // One tile after the other; the next tile's descriptor is fetched while this one is merged.
-  for (int64_t t = t_first; t < t_end; t++) {
-    const TileDesc d = d_next;
-    const TileMeta meta = m_next;
-    BatchPair bp{};
-    if constexpr (kWrite) {
-      if (batch) bp = batch[meta.own.seg >> batch_bucket_bits];  // in flight with the keys
-    }
-    if (t + 1 < t_end) {
-      d_next = desc[t + 1];
-      m_next = load_meta(t + 1);
-    }
-    uint32_t saved_split = 0;
-    if constexpr (kWrite) saved_split = split[t * kThreads + lane];  // ahead of the keys, not after them
-    Stage st;
-    st.init(d);
-    KSH_MARK(1, t);
-    st.copy(lds);
-    wave_sync();
-    process(d, st, t, meta, bp, saved_split);
-  }
+  uint32_t saved_split = 0;
+  if constexpr (kWrite) saved_split = split[t * kThreads + lane];  // ahead of the keys, not after them
+  Stage st;
+  st.init(d);
+  KSH_MARK(1, t);
+  st.copy(lds);
+  wave_sync();
+  process(d, st, t, meta, saved_split);
 }
 
 // Bucket offsets of the three results from the per-tile prefix of common keys.
@@ -723,26 +695,13 @@ inline void plan_carve(char* base, int64_t n_segs, int64_t max_tiles, Plan* p) {
   p->owner = reinterpret_cast<TileOwner*>(at);
 }
 
-// Consecutive tiles handled by one wave of k_tile_merge.
-inline int tiles_per_wave(int64_t max_tiles) {
-  (void)max_tiles;
-  // Measured on config 2 (docs: DESIGN.md 3.1): more than one tile per wave is slower at every
-  // size tried, with or without register prefetch of the next tile -- many short waves keep
-  // more memory requests in flight than few long ones.  The knob stays for experiments.
-  const char* e = std::getenv("KSH_TILES_PER_WAVE");
-  const int forced = e ? std::atoi(e) : 0;
-  return forced > 0 ? forced : 1;
-}
-
 template <typename KeyT, int kMode>
 void launch_tile_merge(ksh_ctx* ctx, const Plan& p, int64_t* tile_m, const int64_t* tile_ioff,
                        uint16_t* split, KeyT* out_i, KeyT* out_amb, KeyT* out_bma,
                        const BatchPair* batch = nullptr, int batch_bucket_bits = 0) {
-  const int tpw = tiles_per_wave(p.max_tiles);
-  const int64_t waves = (p.max_tiles + tpw - 1) / tpw;
-  const int64_t groups = (waves + kGroupWaves - 1) / kGroupWaves;
+  const int64_t groups = (p.max_tiles + kGroupWaves - 1) / kGroupWaves;
   hipLaunchKernelGGL((k_tile_merge<KeyT, kMode>), dim3(unsigned(groups)), dim3(kThreads * kGroupWaves), 0, ctx->stream,
-                     p.desc, p.tile_base + p.n_segs, p.max_tiles, tpw, tile_m, tile_ioff, split, out_i,
+                     p.desc, p.tile_base + p.n_segs, p.max_tiles, tile_m, tile_ioff, split, out_i,
                      out_amb, out_bma, batch, p.owner, batch_bucket_bits);
 }
 

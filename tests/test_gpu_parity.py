@@ -213,16 +213,14 @@ def test_config2_properties(ctx):
             assert np.array_equal(inter.kmers(), np.intersect1d(sets[i], sets[j]))
 
 
-@pytest.mark.parametrize("tiles_per_wave", ["1", "3"])
-def test_large_pair_properties(ctx, tiles_per_wave, monkeypatch):
+def test_large_pair_properties(ctx):
     """Two device-generated k=23 sets of 6.5e7 k-mers: more than 2^17 tiles, so the tile-count
     prefix takes the chained scan with more than 64 workgroups and the multi-launch scan is
-    used for nothing; several tiles per bucket; optionally several tiles per wave.  Checked
-    through identities that need no host copy of the sets."""
+    used for nothing; several tiles per bucket.  Checked through identities that need no host
+    copy of the sets."""
     import torch
     from kmersets import synth_torch
 
-    monkeypatch.setenv("KSH_TILES_PER_WAVE", tiles_per_wave)
     k, n = 23, 14
     size = int(float(os.environ.get("KMERSETS_TEST_LARGE", "6.5e7")))
     g = capi.geom(k, n)

@@ -156,7 +156,7 @@ def test_survey_known_answers(golden):
 
 
 # ----------------------------------------------------------------------------- spss.h
-def check_spss_invariants(strings, k, n, kb, want_set):
+def check_spss_invariants(strings, k, n, kb, want_set, canonical=True):
     """test/spss.cc:29-40,113-124,141-152: every string >= K long, no k-mer twice,
     union equals the input."""
     L = ol.lib()
@@ -164,7 +164,9 @@ def check_spss_invariants(strings, k, n, kb, want_set):
     for s in strings:
         assert len(s) >= k
         for i in range(len(s) - k + 1):
-            c = int(L.ko_canonical(ol.kmer(s[i:i + k]), k))
+            c = ol.kmer(s[i:i + k])
+            if canonical:
+                c = int(L.ko_canonical(c, k))
             assert c not in seen
             seen.add(c)
     got = ol.Set.from_kmers(k, n, kb, np.array(sorted(seen), dtype=np.uint64))
@@ -184,6 +186,65 @@ def test_unitigs_and_spss_random(seed):
     spss = s.spss()
     check_spss_invariants(spss, k, n, kb, s)
     assert ol.Set.from_spss(spss, k, n, kb).equals(s)
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_noncanonical_and_slow_random(seed):
+    """test/spss.cc:15-40 (GetUnitigsRandom), :71-96 (GetSPSSRandom), :155-170
+    (GetKmerSetFromSPSSRandom) on non-canonical sets, and :99-124 (GetSPSSCanonicalRandom,
+    fast = false); K=9, N=10, uint8 keys."""
+    k, n, kb = 9, 10, 1
+    size = [1, 17, 300, 4000, 20000, 65536][seed]
+    fw = synth.random_read_kmers(k, size, seed=200 + seed, canonical=False)
+    f = ol.Set.from_kmers(k, n, kb, fw)
+    check_spss_invariants(f.unitigs_directed(), k, n, kb, f, canonical=False)
+    spss = f.spss_directed()
+    check_spss_invariants(spss, k, n, kb, f, canonical=False)
+    assert ol.Set.from_spss(spss, k, n, kb, canonical=False).equals(f)
+    c = f.compact(canonical=False)
+    assert c.size() == f.size() and c.weight() == sum(len(x) for x in spss)
+    assert c.to_set(canonical=False).equals(f)
+    cs = ol.Set.from_kmers(k, n, kb, synth.random_read_kmers(k, size, seed=300 + seed, canonical=True))
+    slow = cs.spss_slow()
+    check_spss_invariants(slow, k, n, kb, cs)
+    assert cs.compact(fast=False).weight() == sum(len(x) for x in slow)
+    assert ol.Set.from_spss(slow, k, n, kb).equals(cs)
+
+
+def test_noncanonical_and_slow_dense_and_special():
+    """Dense random graphs (k = 5: every branching pattern, loops in the path cover) and the
+    special shapes, both constructions."""
+    rng = np.random.default_rng(4)
+    k, n, kb = 5, 3, 1
+    for trial in range(20):
+        fw = np.unique(rng.integers(0, 4 ** k, size=int(rng.integers(1, 1500)), dtype=np.uint64))
+        f = ol.Set.from_kmers(k, n, kb, fw)
+        check_spss_invariants(f.unitigs_directed(), k, n, kb, f, canonical=False)
+        check_spss_invariants(f.spss_directed(), k, n, kb, f, canonical=False)
+        cs = ol.Set.from_kmers(k, n, kb, np.unique(synth.canonical(fw, k)))
+        check_spss_invariants(cs.spss_slow(), k, n, kb, cs)
+    for seq in ["ACGTACGTACG", "AAAAAAAAA", "AACCGGTT", "ATATATATAT", "GATTACAGATTACAGATTACA"]:
+        fw = np.unique(synth.kmers_of_bases(synth.bases_of_string(seq), k))
+        f = ol.Set.from_kmers(k, n, kb, fw)
+        check_spss_invariants(f.spss_directed(), k, n, kb, f, canonical=False)
+    # a forward walk spells its k-mers in order: one string for a sequence without repeats
+    f = ol.Set.from_kmers(k, n, kb, np.unique(synth.kmers_of_bases(synth.bases_of_string("AACCGTTAGCAT"), k)))
+    assert f.spss_directed() == ["AACCGTTAGCAT"] and f.unitigs_directed() == ["AACCGTTAGCAT"]
+    empty = ol.Set(k, n, kb)
+    assert empty.unitigs_directed() == [] and empty.spss_directed() == [] and empty.spss_slow() == []
+
+
+def test_kmer_set_set_noncanonical():
+    """KmerSetSet(..., canonical = false, ...): Get(i) gives the inputs back
+    (test/kmer_set_set.cc:30-34 with the flag the other way)."""
+    k, n, kb = 15, 14, 2
+    genomes = synth.phylogeny_genomes(4, 3000 + k - 1, seed=21)
+    sets = [np.unique(synth.kmers_of_bases(g, k)) for g in genomes]
+    compacts = [ol.Set.from_kmers(k, n, kb, s).compact(canonical=False) for s in sets]
+    kss = ol.KmerSetSet(compacts, synth.sample_bucket_ids(n, seed=2), canonical=False)
+    assert kss.size() > len(sets)
+    for i, s in enumerate(sets):
+        assert np.array_equal(kss.get(i).kmers(), s)
 
 
 @pytest.mark.parametrize("geom", [(5, 3, 1), (15, 14, 2), (19, 10, 4), (23, 14, 4), (31, 14, 8)])

@@ -240,6 +240,8 @@ int ksh_svb_decode_0124(ksh_ctx* ctx, const uint8_t* d_in, int64_t n, uint32_t* 
  *   mode 1: GetUnitigs (lib/core/spss.h:73-227).
  * The strings and their order are the oracle's (the reference's n_workers == 1
  * control flow with ascending iteration).
+ * KSH_INVALID_ARGUMENT for a canonical set that holds a k-mer equal to its own reverse
+ * complement (even k only).
  * plan : everything up to the string layout; returns the container's sizes.
  * write: d_words = ceil(n_bases / 32) words, d_lens = n_strings values (len - K). */
 int ksh_spss_encode_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* set, int canonical,

@@ -75,8 +75,12 @@ __global__ __launch_bounds__(256) void k_fine_index(const int64_t* __restrict__ 
   if (b == n_buckets - 1 && threadIdx.x == 0) fine[n_buckets << fine_bits] = uint32_t(hi);
 }
 
+// *self_rc is raised when a canonical set holds a k-mer that is its own reverse complement
+// (possible for even k only): its two sides coincide, which the edge table of the path cover (one
+// slot per base) does not model, and no instantiation of the reference has an even K.
 template <typename KeyT, bool kDirected>
-__global__ __launch_bounds__(256) void k_adjacency(DevSet<KeyT> set, uint32_t* __restrict__ nbr) {
+__global__ __launch_bounds__(256) void k_adjacency(DevSet<KeyT> set, uint32_t* __restrict__ nbr,
+                                                    int* __restrict__ self_rc) {
   __shared__ int64_t s_bucket[2];
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const uint64_t x = set.kmer_in_block(t, s_bucket);
@@ -110,6 +114,7 @@ __global__ __launch_bounds__(256) void k_adjacency(DevSet<KeyT> set, uint32_t* _
   // Prev(x, c) and Prev(rc(x), c) = rc(Next(x, 3 - c)), sit in four different buckets and are
   // probed one by one, and only when they are the canonical form.
   const uint64_t rx = revcomp(x, k);
+  if (rx == x) *self_rc = 1;
 #pragma unroll
   for (int side = 0; side < 2; side++) {
     // group: side 1 -> Next(x, .) (neighbour as is);  side 0 -> Next(rc(x), .) (neighbour
@@ -1072,15 +1077,17 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     set.fine_bits = fine_bits;
     p->fine_bits = fine_bits;
   }
+  int* flags = static_cast<int*>(arena_alloc(ctx, 16));  // [0] pointer-jumping progress, [1] self_rc
+  if (!flags) return fail(KSH_INTERNAL, "scratch arena too small");
+  KSH_HIP(hipMemsetAsync(flags, 0, 16, st));
   if (directed)
-    hipLaunchKernelGGL((k_adjacency<KeyT, true>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr);
+    hipLaunchKernelGGL((k_adjacency<KeyT, true>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr, flags + 1);
   else
-    hipLaunchKernelGGL((k_adjacency<KeyT, false>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr);
+    hipLaunchKernelGGL((k_adjacency<KeyT, false>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr, flags + 1);
   hipLaunchKernelGGL(k_links, dim3(nblk(n)), dim3(256), 0, st, p->nbr, n, p->link, p->info,
                      p->hcls);  // hcls doubles as the start-flag bytes until k_choose
   {
-    int* changed = static_cast<int*>(arena_alloc(ctx, 16));
-    if (!changed) return fail(KSH_INTERNAL, "scratch arena too small");
+    int* changed = flags;
     const int64_t ns2 = 2 * n;
     const int64_t n_dense = 2 * ((n + kRulerEvery - 1) / kRulerEvery);
     unsigned long long* rinfo = reinterpret_cast<unsigned long long*>(p->c01);  // n_dense * 8 <= 8n
@@ -1093,9 +1100,12 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       KSH_HIP(hipMemsetAsync(changed, 0, sizeof(int), st));
       for (int b = 0; b < 4 && round < max_rounds; b++, round++)
         hipLaunchKernelGGL(k_ruler_jump, dim3(nblk(n_dense)), dim3(256), 0, st, n_dense, rinfo, changed);
-      KSH_HIP(hipMemcpyAsync(ctx->h_pinned, changed, sizeof(int), hipMemcpyDeviceToHost, st));
+      KSH_HIP(hipMemcpyAsync(ctx->h_pinned, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
       KSH_HIP(hipStreamSynchronize(st));
-      if (*reinterpret_cast<int*>(ctx->h_pinned) == 0) break;
+      if (reinterpret_cast<int*>(ctx->h_pinned)[1])
+        return fail(KSH_INVALID_ARGUMENT, "the canonical set holds a k-mer that is its own reverse "
+                                          "complement (even k): not supported");
+      if (reinterpret_cast<int*>(ctx->h_pinned)[0] == 0) break;
     }
   }
   hipLaunchKernelGGL(k_choose, dim3(nblk(n)), dim3(256), 0, st, p->info,

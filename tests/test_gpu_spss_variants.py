@@ -177,3 +177,23 @@ def test_slow_family(ctx):
     sets = synth.phylogeny_sets(k, 2, 30000, seed=3)
     check_slow(ctx, k, n, kb, sets[0])
     check_slow(ctx, k, n, kb, np.setdiff1d(sets[0], sets[1]))
+
+
+def test_even_k_canonical(ctx):
+    """An even k lets a k-mer be its own reverse complement.  Sets without such a k-mer encode
+    like any other; one that holds one is refused by name, not mis-encoded."""
+    k, n, kb = 6, 8, 1
+    rng = np.random.default_rng(5)
+    km = np.unique(synth.canonical(rng.integers(0, 4 ** k, size=1500, dtype=np.uint64), k))
+    own = synth.revcomp(km, k) == km
+    assert own.any()
+    clean = km[~own]
+    oset = ol.Set.from_kmers(k, n, kb, clean)
+    d = dev_set(ctx, k, n, clean)
+    assert ctx.spss_encode(d, mode=0).to_strings() == oset.spss()
+    assert ctx.spss_encode(d, mode=2).to_strings() == oset.spss_slow()
+    with pytest.raises(capi.KshError, match="own reverse"):
+        ctx.spss_encode(dev_set(ctx, k, n, km), mode=0)
+    # read as a non-canonical set the same k-mers are fine
+    fset = ol.Set.from_kmers(k, n, kb, km)
+    assert ctx.spss_encode(dev_set(ctx, k, n, km), mode=0, canonical=False).to_strings() == fset.spss_directed()

@@ -308,7 +308,7 @@ __device__ __forceinline__ void copy_out(const KeyT* __restrict__ lds, uint32_t 
   GlobalBytes o = (GlobalBytes)out;
   const char* l = reinterpret_cast<const char*>(lds + lds_first);
   const uint32_t end = cnt * uint32_t(sizeof(KeyT));
-#pragma unroll 2
+#pragma unroll 1
   for (uint32_t x = (threadIdx.x & (kThreads - 1)) * uint32_t(sizeof(KeyT)); x < end; x += kThreads * uint32_t(sizeof(KeyT)))
     *(GlobalKeys)(o + x) = *reinterpret_cast<const KeyT*>(l + x);
 }

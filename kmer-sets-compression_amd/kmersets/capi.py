@@ -276,7 +276,8 @@ class DeviceSpss:
 
 class BatchResult:
     """Results of Context.pair_algebra_batch: indexable / iterable as [(A & B, A \\ B, B \\ A), ...];
-    the DeviceSet objects (slices of the two batch-wide allocations) are made on first access."""
+    the DeviceSet objects (slices of the two batch-wide allocations) are made on first access;
+    `totals` is the list [pair][|A&B|, |A\\B|, |B\\A|]."""
 
     def __init__(self, g, off_rows, key_pool, starts, byte_caps, totals):
         self.g, self.off_rows, self.key_pool, self.starts, self.byte_caps = g, off_rows, key_pool, starts, byte_caps
@@ -284,7 +285,7 @@ class BatchResult:
         self._made = {}
 
     def __len__(self):
-        return self.totals.shape[0]
+        return len(self.totals)
 
     def __getitem__(self, idx):
         if idx < 0:
@@ -293,8 +294,8 @@ class BatchResult:
             trio = []
             for r in range(3):
                 s_ = DeviceSet.carved(self.g, self.off_rows, 3 * idx + r, self.key_pool,
-                                      int(self.starts[3 * idx + r]), int(self.byte_caps[idx, r]))
-                s_.n_keys = int(self.totals[idx, r])
+                                      self.starts[3 * idx + r], self.byte_caps[3 * idx + r])
+                s_.n_keys = self.totals[idx][r]
                 trio.append(s_)
             self._made[idx] = trio
         return self._made[idx]
@@ -524,33 +525,39 @@ class Context:
     def pair_algebra_batch(self, pairs):
         """[(A, B), ...] -> [(A & B, A \\ B, B \\ A), ...]: every pair of the batch tiled together, one
         count launch, one write launch and one stream synchronisation for all sizes
-        (ksh_pair_algebra_batch).  The result behaves like that list; `.totals` is the int64
-        array [pair][|A&B|, |A\\B|, |B\\A|] for callers that only need the sizes."""
+        (ksh_pair_algebra_batch).  The result behaves like that list; `.totals` is the list
+        [pair][|A&B|, |A\\B|, |B\\A|] for callers that only need the sizes."""
         import torch
 
         g = pairs[0][0].g
         kb = g.key_bytes
         n = len(pairs)
-        # the job records as one int64 table with PairJob's layout (15 eight-byte fields):
-        # a.{offsets, keys, n}, b.{offsets, keys, n}, 3 offset pointers, 3 key pointers, 3 totals
+        # The job records as one int64 table with PairJob's layout (15 eight-byte fields):
+        # a.{offsets, keys, n}, b.{offsets, keys, n}, 3 offset pointers, 3 key pointers, 3 totals.
+        # Built with plain integers and converted once: a handful of pairs is far below the size
+        # where numpy's per-call cost pays, and this runs once per merge step.
         assert C.sizeof(PairJob) == 15 * 8
-        jobs = np.zeros((n, 15), dtype=np.int64)
-        for idx, (a, b) in enumerate(pairs):
-            jobs[idx, 0:2] = a.pointers()
-            jobs[idx, 2] = a.n_keys
-            jobs[idx, 3:5] = b.pointers()
-            jobs[idx, 5] = b.n_keys
-        caps = np.stack([np.minimum(jobs[:, 2], jobs[:, 5]), jobs[:, 2], jobs[:, 5]], axis=1)
-        sizes = (np.maximum(caps * kb, 16) + 255) & ~255          # bytes reserved per result
-        starts = np.concatenate(([0], np.cumsum(sizes.reshape(-1))))
-        # one offsets block and one key pool for the whole batch, carved by pointer arithmetic
         nb1 = (1 << g.n_bucket_bits) + 1
+        byte_caps, starts = [], [0]
+        for a, b in pairs:
+            for cap in (min(a.n_keys, b.n_keys), a.n_keys, b.n_keys):
+                nbytes = max(cap * kb, 16)
+                byte_caps.append(nbytes)
+                starts.append(starts[-1] + ((nbytes + 255) & ~255))       # bytes reserved per result
+        # one offsets block and one key pool for the whole batch, carved by pointer arithmetic
         off_rows = torch.empty((3 * n, nb1), dtype=torch.int64, device=self.device)
-        key_pool = torch.empty(int(starts[-1]), dtype=torch.uint8, device=self.device)
-        jobs[:, 6:9] = off_rows.data_ptr() + 8 * nb1 * np.arange(3 * n, dtype=np.int64).reshape(n, 3)
-        jobs[:, 9:12] = key_pool.data_ptr() + starts[:-1].reshape(n, 3)
+        key_pool = torch.empty(starts[-1], dtype=torch.uint8, device=self.device)
+        off0, key0 = off_rows.data_ptr(), key_pool.data_ptr()
+        rows = []
+        for idx, (a, b) in enumerate(pairs):
+            pa, pb = a.pointers(), b.pointers()
+            r = 3 * idx
+            rows.append((pa[0], pa[1], a.n_keys, pb[0], pb[1], b.n_keys,
+                         off0 + 8 * nb1 * r, off0 + 8 * nb1 * (r + 1), off0 + 8 * nb1 * (r + 2),
+                         key0 + starts[r], key0 + starts[r + 1], key0 + starts[r + 2], 0, 0, 0))
+        jobs = np.array(rows, dtype=np.int64)
         check(lib().ksh_pair_algebra_batch(self.h, C.byref(g), C.cast(jobs.ctypes.data, C.POINTER(PairJob)), n))
-        return BatchResult(g, off_rows, key_pool, starts, np.maximum(caps * kb, 16), jobs[:, 12:15].copy())
+        return BatchResult(g, off_rows, key_pool, starts, byte_caps, jobs[:, 12:15].tolist())
 
     def set_union(self, a, b):
         """KmerSet::Add: A | B as a new DeviceSet."""

@@ -328,7 +328,11 @@ class Context:
             lib().ksh_ctx_destroy(self.h)
             self.h = None
 
-    __del__ = close
+    def __del__(self):
+        # at interpreter shutdown the module globals may already be gone: the process's exit
+        # releases the device memory then
+        if lib is not None and _lib is not None:
+            self.close()
 
     def sync(self):
         check(lib().ksh_ctx_sync(self.h))

@@ -903,7 +903,10 @@ __global__ __launch_bounds__(256) void k_unitig_strings(const uint32_t* __restri
 }
 
 // ---------------------------------------------------------------------------------- E8
-// Where a unitig's k-mers go in the output base stream.
+// Where a unitig's k-mers go in the output base stream.  The records live at the index of the
+// unitig's head k-mer (an array of one record per k-mer, touched only at the heads: it reuses the
+// two 8-byte scan arrays, dead by then), so that k_emit gets from a k-mer's head straight to its
+// place: one dependent random read per k-mer instead of two (unitig id, then place).
 struct UnitigPlace {
   int64_t base;    // base position of the unitig's first k-mer slot (in traversal order)
   uint32_t len;    // k-mers in the unitig
@@ -915,8 +918,9 @@ __global__ __launch_bounds__(256) void k_unitig_place(const uint32_t* __restrict
                                                        const uint32_t* __restrict__ u_koff,
                                                        const uint8_t* __restrict__ u_flip,
                                                        const int64_t* __restrict__ str_start,
-                                                       const uint32_t* __restrict__ lens, int64_t n_u,
-                                                       UnitigPlace* __restrict__ place) {
+                                                       const uint32_t* __restrict__ lens,
+                                                       const uint32_t* __restrict__ u_head, int64_t n_u,
+                                                       UnitigPlace* __restrict__ place_at_head) {
   const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (u >= n_u) return;
   const uint32_t sid = u_sid[u];
@@ -925,15 +929,14 @@ __global__ __launch_bounds__(256) void k_unitig_place(const uint32_t* __restrict
   pl.len = u_len[u];
   const bool is_last = u_koff[u] + u_len[u] == lens[sid] + 1;  // lens = k-mers in the string - 1
   pl.flags = uint32_t(u_flip[u] & 1) | (is_last ? 2u : 0u);
-  place[u] = pl;
+  place_at_head[u_head[u]] = pl;
 }
 
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_emit(DevSet<KeyT> set, const uint32_t* __restrict__ head,
                                                const uint32_t* __restrict__ pos,
                                                const uint8_t* __restrict__ ori,
-                                               const uint32_t* __restrict__ uid,
-                                               const UnitigPlace* __restrict__ place,
+                                               const UnitigPlace* __restrict__ place_at_head,
                                                uint8_t* __restrict__ bytes) {
   __shared__ int64_t s_bucket[2];
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -941,7 +944,7 @@ __global__ __launch_bounds__(256) void k_emit(DevSet<KeyT> set, const uint32_t* 
   if (t >= set.n) return;
   const uint32_t h = head[t];
   if (h == kNone) return;
-  const UnitigPlace pl = place[uid[h]];
+  const UnitigPlace pl = place_at_head[h];
   const uint32_t flip = pl.flags & 1;
   const uint32_t q = flip ? (pl.len - 1 - pos[t]) : pos[t];
   const int k = set.k;
@@ -1001,7 +1004,6 @@ struct EncPlan {
   uint8_t *visited = nullptr, *scls = nullptr, *u_flip = nullptr;
   int64_t *s_nk = nullptr, *sc01 = nullptr, *sc2 = nullptr, *str_start = nullptr;
   int* any_live = nullptr;
-  UnitigPlace* place = nullptr;
   int rounds = 0;
 };
 
@@ -1064,8 +1066,8 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   p->uid = carve<uint32_t>(at, size_t(n));
   p->ori = carve<uint8_t>(at, size_t(n));
   p->hcls = carve<uint8_t>(at, size_t(n));
-  p->c01 = carve<int64_t>(at, size_t(n));
-  p->c23 = carve<int64_t>(at, size_t(n));
+  p->c01 = carve<int64_t>(at, size_t(2 * n));  // two arrays of n, one block: later the place records
+  p->c23 = p->c01 + n;
   p->fine = use_fine ? carve<uint32_t>(at, fine_entries) : nullptr;
 
   DevSet<KeyT> set{sv->d_offsets, static_cast<const KeyT*>(sv->d_keys), nb, n, g->k, key_bits(g)};
@@ -1130,12 +1132,11 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   p->n_u = n_u;
 
   // unitig-level block
-  const size_t ub = al(size_t(n_u) * sizeof(UnitigPlace)) + 10 * al(size_t(n_u) * 4) + al(size_t(8 * n_u) * 4) + 2 * al(size_t(2 * n_u) * 4) +
+  const size_t ub = 10 * al(size_t(n_u) * 4) + al(size_t(8 * n_u) * 4) + 2 * al(size_t(2 * n_u) * 4) +
                     al(size_t(2 * n_u) * 8) + 3 * al(size_t(n_u)) + 4 * al(size_t(n_u + 1) * 8) +
                     3 * al(size_t(n_u) * 4) + 4096;
   KSH_TRY(pool_alloc(ctx, ub, reinterpret_cast<void**>(&p->ublock)));
   at = p->ublock;
-  p->place = carve<UnitigPlace>(at, size_t(n_u));
   p->u_head = carve<uint32_t>(at, size_t(n_u));
   p->u_first = carve<uint32_t>(at, size_t(n_u));
   p->u_last = carve<uint32_t>(at, size_t(n_u));
@@ -1217,7 +1218,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   arena_reset(ctx);
   KSH_TRY(scan_exclusive_i64(ctx, p->str_start, p->str_start, ns, p->str_start + ns));
   hipLaunchKernelGGL(k_unitig_place, dim3(nblk(n_u)), dim3(256), 0, st, p->u_len, p->u_sid, p->u_koff,
-                     p->u_flip, p->str_start, p->lens, n_u, p->place);
+                     p->u_flip, p->str_start, p->lens, p->u_head, n_u, reinterpret_cast<UnitigPlace*>(p->c01));
   KSH_HIP(hipGetLastError());
   KSH_HIP(hipMemcpyAsync(ctx->h_pinned, p->str_start + ns, 8, hipMemcpyDeviceToHost, st));
   KSH_HIP(hipStreamSynchronize(st));
@@ -1250,7 +1251,7 @@ int encode_write_t(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens) {
     bytes = static_cast<uint8_t*>(tmp);
   }
   hipLaunchKernelGGL((k_emit<KeyT>), dim3(nblk(n)), dim3(256), 0, st, set, p->head, p->pos, p->ori,
-                     p->uid, p->place, bytes);
+                     reinterpret_cast<const UnitigPlace*>(p->c01), bytes);
   const int64_t n_words = (p->n_bases + 31) / 32;
   hipLaunchKernelGGL(k_pack, dim3(nblk(n_words)), dim3(256), 0, st, bytes, p->n_bases, n_words,
                      d_words);

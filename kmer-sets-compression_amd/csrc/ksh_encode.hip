@@ -201,11 +201,13 @@ __device__ __forceinline__ bool sampled_ruler(uint32_t s) { return (s & (2u * kR
 // Chain-rank records.
 //   rinfo[i] (one per sampled ruler, dense index i): end_flag:1 | dist:31 | next:32 -- the next
 //            ruler (or, once end_flag is set, the chain's end state) and the distance to it.
-//   rec[s]   (one per state; for kinds 0 and 1 only the d == 0 state of a k-mer is written, the
-//            other one is its mirror image, see mirror_rec): kind:2 | off:30 | ref:32
+//   rec[s]   (one per state; only the d == 0 state of a k-mer is written, the other one follows
+//            from it, see mirror_rec and k_ruler_heads): kind:2 | off:30 | ref:32
 //            kind 0: s lies `off` steps after sampled ruler `ref` (dense index)
-//            kind 1: s lies `off` steps before sampled ruler `ref` (head segment of a chain)
-//            kind 2: the chain's end state is `ref`, `off` steps ahead (no sampled ruler between)
+//            kind 1: s lies `off` steps before sampled ruler `ref` (only as the mirror of kind 0)
+//            kind 2: s is a chain of its own (one state), written for both states of the k-mer
+//            kind 3: s lies `off` steps after the chain start `ref` (a state); what lies ahead of
+//                    that start is in chain_info (k_ruler_heads)
 // The dense ruler array is 1/16 of the states (L2/MALL resident at 10^8 k-mers), so pointer
 // jumping and the final lookups stay on-chip; every state's link pair is read once and its
 // record written once.
@@ -257,12 +259,22 @@ __global__ __launch_bounds__(256) void k_ruler_walk(const uint32_t* __restrict__
 }
 
 // One thread per k-mer; acts on those of its two states that start a chain without being a
-// sampled ruler (flags from k_links): the head segment is ranked relative to the first
-// sampled ruler ahead (kind 1) or to the chain's end (kind 2).
+// sampled ruler (flags from k_links).  One walk from the start S to the first sampled ruler ahead,
+// or to the chain's end: the d == 0 states it passes are stamped "off steps after start S" (kind
+// 3), and what lies ahead goes into chain_info at S's k-mer (a k-mer starts at most one chain of
+// two or more states: its other state then enters through the side that has the link).  Both
+// states of the stamped k-mer follow from that record: its forward state is off steps into the
+// chain, its mirror state off steps before the mirror chain's end S ^ 1.
+//   chain_info: ahead:1 (0 = the chain's end state, 1 = a sampled ruler, dense index) | steps:31 | ref:32
+__device__ __forceinline__ uint64_t make_chain_info(bool ruler_ahead, uint32_t steps, uint32_t ref) {
+  return (ruler_ahead ? kEndFlag : 0) | (uint64_t(steps & 0x7FFFFFFFu) << 32) | ref;
+}
+
 __global__ __launch_bounds__(256) void k_ruler_heads(const uint32_t* __restrict__ link,
                                                       const uint8_t* __restrict__ start_flags,
                                                       int64_t n,
-                                                      unsigned long long* __restrict__ rec) {
+                                                      unsigned long long* __restrict__ rec,
+                                                      unsigned long long* __restrict__ chain_info) {
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= n) return;
   const uint32_t flags = start_flags[t];
@@ -270,39 +282,26 @@ __global__ __launch_bounds__(256) void k_ruler_heads(const uint32_t* __restrict_
   for (uint32_t d = 0; d < 2; d++) {
     if (!(flags & (1u << d))) continue;
     const uint32_t s0 = uint32_t(2 * t) | d;
-    const uint32_t lk0 = leave_link(link_pair(link, s0), s0);
-    if (lk0 == kNone) {
-      rec[s0] = make_rec(2, 0, s0);  // a one-state chain
+    uint32_t lk = leave_link(link_pair(link, s0), s0);
+    if (lk == kNone) {
+      rec[s0] = make_rec(2, 0, s0);  // a one-state chain: its own end, in both orientations
       continue;
     }
-    // first walk: what lies ahead
-    uint32_t cur = s0, steps = 0, lk = lk0, kind, ref;
+    uint32_t cur = s0, off = 0;
     while (true) {
+      if ((cur & 1) == 0) rec[cur] = make_rec(3, off, s0);
       cur = step_to(cur, lk);
-      steps++;
+      off++;
       if (sampled_ruler(cur)) {
-        kind = 1;
-        ref = dense_index(cur);
+        chain_info[t] = make_chain_info(true, off, dense_index(cur));
         break;
       }
       lk = leave_link(link_pair(link, cur), cur);
-      if (lk == kNone || steps >= 0x3FFFFFFFu) {
-        kind = 2;
-        ref = cur;
+      if (lk == kNone || off >= 0x3FFFFFFFu) {
+        if ((cur & 1) == 0) rec[cur] = make_rec(3, off, s0);
+        chain_info[t] = make_chain_info(false, off, cur);
         break;
       }
-    }
-    // second walk: stamp the head segment (the target ruler stamps itself; an end state is ours)
-    uint32_t left = steps;
-    cur = s0;
-    lk = lk0;
-    while (true) {
-      if (kind == 2 || (cur & 1) == 0) rec[cur] = make_rec(kind, left, ref);  // see mirror_rec
-      if (left == 0) break;
-      cur = step_to(cur, lk);
-      left--;
-      if (left == 0 && kind == 1) break;
-      lk = leave_link(link_pair(link, cur), cur);
     }
   }
 }
@@ -327,7 +326,7 @@ __global__ __launch_bounds__(256) void k_ruler_jump(int64_t n_dense,
 // every k-mer is stamped once, by whichever walk passes its state 2t, and the record of state
 // 2t + 1 follows from it -- `off` steps after ruler state R means `off` steps before R's mirror
 // R ^ 1 (the two states of a sampled k-mer are neighbours in the dense ruler array), and the
-// other way round.  Chains without a sampled ruler (kind 2) are stamped in both directions.
+// other way round.  Head segments (kind 3, k_ruler_heads) follow the same rule.
 __device__ __forceinline__ uint64_t mirror_rec(uint64_t r) { return r ^ ((uint64_t(1) << 62) | 1u); }
 
 // (end state, distance to it) of a state from its record; false on a non-branching loop.
@@ -355,6 +354,7 @@ __device__ __forceinline__ bool resolve_rec(uint64_t r, const unsigned long long
 // heads are one class, in start-k-mer order (spss.h:159-199).
 __global__ __launch_bounds__(256) void k_choose(const unsigned long long* __restrict__ rec,
                                                  const unsigned long long* __restrict__ rinfo,
+                                                 const unsigned long long* __restrict__ chain_info,
                                                  int64_t n, bool directed, uint32_t* __restrict__ head,
                                                  uint32_t* __restrict__ pos,
                                                  uint8_t* __restrict__ ori,
@@ -364,9 +364,30 @@ __global__ __launch_bounds__(256) void k_choose(const unsigned long long* __rest
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= n) return;
   ulonglong2 both = reinterpret_cast<const ulonglong2*>(rec)[t];
-  if (both.y == kRecUnset && both.x != kRecUnset && (both.x >> 62) < 2) both.y = mirror_rec(both.x);
   uint32_t e0, d0, e1, d1;
-  const bool ok = resolve_rec(both.x, rinfo, &e0, &d0) && resolve_rec(both.y, rinfo, &e1, &d1);
+  bool ok;
+  if (both.x != kRecUnset && (both.x >> 62) == 3) {
+    // off steps after chain start S: the forward state goes on to what lies ahead of S's walk,
+    // the mirror state is off steps before the mirror chain's end S ^ 1
+    const uint32_t off = uint32_t((both.x >> 32) & 0x3FFFFFFFu), start = uint32_t(both.x);
+    const uint64_t ci = chain_info[start >> 1];
+    const uint32_t steps = uint32_t((ci >> 32) & 0x7FFFFFFFu);
+    ok = true;
+    if (ci & kEndFlag) {  // a sampled ruler ahead
+      const uint64_t ri = rinfo[uint32_t(ci)];
+      ok = (ri & kEndFlag) != 0;  // a chain with a start is no loop: always set
+      e0 = uint32_t(ri);
+      d0 = steps - off + uint32_t((ri >> 32) & 0x7FFFFFFFu);
+    } else {
+      e0 = uint32_t(ci);
+      d0 = steps - off;
+    }
+    e1 = start ^ 1;
+    d1 = off;
+  } else {
+    if (both.y == kRecUnset && both.x != kRecUnset && (both.x >> 62) < 2) both.y = mirror_rec(both.x);
+    ok = resolve_rec(both.x, rinfo, &e0, &d0) && resolve_rec(both.y, rinfo, &e1, &d1);
+  }
   if (!ok) {
     head[t] = kNone;
     hcls[t] = 0xFE;
@@ -1095,7 +1116,8 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     unsigned long long* rinfo = reinterpret_cast<unsigned long long*>(p->c01);  // n_dense * 8 <= 8n
     hipLaunchKernelGGL(k_ruler_walk, dim3(nblk(n_dense)), dim3(256), 0, st, p->link, ns2, n_dense, rinfo,
                        p->info);
-    hipLaunchKernelGGL(k_ruler_heads, dim3(nblk(n)), dim3(256), 0, st, p->link, p->hcls, n, p->info);
+    hipLaunchKernelGGL(k_ruler_heads, dim3(nblk(n)), dim3(256), 0, st, p->link, p->hcls, n, p->info,
+                       reinterpret_cast<unsigned long long*>(p->c23));  // c23: chain_info until k_choose is done
     int max_rounds = 2;
     for (int64_t x = n_dense; x > 1; x >>= 1) max_rounds++;
     for (int round = 0; round < max_rounds;) {
@@ -1111,7 +1133,8 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     }
   }
   hipLaunchKernelGGL(k_choose, dim3(nblk(n)), dim3(256), 0, st, p->info,
-                     reinterpret_cast<const unsigned long long*>(p->c01), n, directed, p->head, p->pos, p->ori,
+                     reinterpret_cast<const unsigned long long*>(p->c01),
+                     reinterpret_cast<const unsigned long long*>(p->c23), n, directed, p->head, p->pos, p->ori,
                      p->hcls, p->hlen, p->hlast);
   hipLaunchKernelGGL(k_loops, dim3(nblk(n)), dim3(256), 0, st, p->link, n, p->head, p->pos, p->ori,
                      p->hcls, p->hlen, p->hlast);

@@ -368,7 +368,7 @@ __global__ __launch_bounds__(kThreads * kGroupWaves) void k_tile_merge(
   // per wave, with or without the next tile's keys prefetched into registers, measured slower at
   // every count: DESIGN.md 3.1.)
   const int lane = threadIdx.x & (kThreads - 1);
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kThreads);  // uniform: stays scalar
+  const int wave = kGroupWaves == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x / kThreads);  // uniform: stays scalar
   KeyT* const lds = lds_all[wave];
   const int64_t t = int64_t(blockIdx.x) * kGroupWaves + wave;
 
@@ -460,28 +460,37 @@ __global__ __launch_bounds__(kThreads * kGroupWaves) void k_tile_merge(
     bool prev_common = straddle;
 
     KeyT vals[kVT];
-    uint32_t m_a = 0, m_x = 0;  // bit (kVT - 1 - step) belongs to `step`
+    uint32_t m_a = 0, m_x = 0;  // bit (kVT - 1 - step) belongs to `step`: from A / the other class of its side
+    uint32_t m_c = 0;           // the same as two-bit class codes, for the compaction
     int n_i = 0, n_a = 0;
+    // The heads as byte offsets into the wave's LDS slice: an LDS instruction takes a byte address
+    // plus an immediate, so the A head needs no arithmetic and the B head one subtraction.
+    constexpr uint32_t kKey = uint32_t(sizeof(KeyT));
+    const char* const lds_b = reinterpret_cast<const char*>(lds);
+    uint32_t ia = uint32_t(i) * kKey;
+    const uint32_t sb = uint32_t(s0) * kKey, a_end = uint32_t(a_hi) * kKey, b_end = uint32_t(b_hi) * kKey;
 #pragma unroll
     for (int step = 0; step < kVT; step++) {
       if (step < n_steps) {  // wave-uniform
-        const int jj = s0 + step - i;
-        const KeyT av = lds[i];
-        const KeyT bv = lds[jj];
-        const bool has_a = i < a_hi, has_b = jj < b_hi;
+        const uint32_t jb0 = sb - ia;  // the B head is at jb0 + step keys: the step goes into the immediate
+        const KeyT av = *reinterpret_cast<const KeyT*>(lds_b + ia);
+        const KeyT bv = *reinterpret_cast<const KeyT*>(lds_b + jb0 + uint32_t(step) * kKey);
+        // (signed: a tiny tile's B end can lie below step keys; every offset is far below 2^31)
+        const bool has_a = ia < a_end, has_b = int(jb0) < int(b_end) - step * int(kKey);
         const bool take_a = has_a & (!has_b | (av <= bv));
         const bool common = take_a & has_b & (av == bv);
+        const uint32_t took = uint32_t(take_a);
         if constexpr (kWrite) {
           const bool keep_b = !take_a & has_b & !prev_common;
           const bool x = (take_a & !common) | (!take_a & !keep_b);
           vals[step] = take_a ? av : bv;
-          m_a = m_a + m_a + uint32_t(take_a);
+          m_a = m_a + m_a + took;
           m_x = m_x + m_x + uint32_t(x);
           prev_common = common;
         } else {
           n_i += int(common);
         }
-        i += int(take_a);
+        ia += took * kKey;
       }
     }
     // (batch launches) where this tile's pair wants its results: asked for here, behind the
@@ -496,6 +505,15 @@ __global__ __launch_bounds__(kThreads * kGroupWaves) void k_tile_merge(
       m_x = (m_x << (kVT - n_steps)) | ((1u << (kVT - n_steps)) - 1);  // steps not run: dropped
       n_i = __popc(m_a & ~m_x);
       n_a = __popc(m_a & m_x);
+      // class code of a step = (not from A) << 1 | x: 0 = A&B, 1 = A\B, 2 = B\A, 3 = dropped; its
+      // two bits sit at 2 (kVT - 1 - step)
+      auto spread = [](uint32_t v) {  // bit b -> bit 2 b (16 bits in)
+        v = (v | (v << 8)) & 0x00FF00FFu;
+        v = (v | (v << 4)) & 0x0F0F0F0Fu;
+        v = (v | (v << 2)) & 0x33333333u;
+        return (v | (v << 1)) & 0x55555555u;
+      };
+      m_c = (spread(~m_a & ((1u << kVT) - 1)) << 1) | spread(m_x);
     }
     KSH_MARK(4, t);
 
@@ -533,8 +551,7 @@ __global__ __launch_bounds__(kThreads * kGroupWaves) void k_tile_merge(
 #pragma unroll
         for (int step = 0; step < kVT; step++) {
           if (step < n_steps) {
-            const uint32_t bit = 1u << (kVT - 1 - step);
-            const bool keep = ((m_a & bit) != 0) | ((m_x & bit) == 0);
+            const bool keep = ((m_c >> (2 * (kVT - 1 - step))) & 3) != 3;
             if (keep) lds[p_u] = vals[step];
             p_u += uint32_t(keep);
           }
@@ -544,12 +561,11 @@ __global__ __launch_bounds__(kThreads * kGroupWaves) void k_tile_merge(
 #pragma unroll
         for (int step = 0; step < kVT; step++) {
           if (step < n_steps) {
-            const uint32_t bit = 1u << (kVT - 1 - step);
-            const bool from_a = (m_a & bit) != 0, x = (m_x & bit) != 0;
-            const bool keep = from_a | !x;
-            const uint32_t sh = from_a ? (x ? 10u : 0u) : 20u;
-            if (keep) lds[(pos3 >> sh) & 1023] = vals[step];
-            pos3 += keep ? (1u << sh) : 0u;
+            const uint32_t c = (m_c >> (2 * (kVT - 1 - step))) & 3;
+            const bool keep = c != 3;
+            const uint32_t sh = c * 10;  // the class's field of pos3; a dropped key counts in the spare
+            if (keep) lds[(pos3 >> sh) & 1023] = vals[step];  // bits 30-31, which nothing reads
+            pos3 += 1u << sh;
           }
         }
       } else {
@@ -557,13 +573,12 @@ __global__ __launch_bounds__(kThreads * kGroupWaves) void k_tile_merge(
 #pragma unroll
         for (int step = 0; step < kVT; step++) {
           if (step < n_steps) {
-            const uint32_t bit = 1u << (kVT - 1 - step);
-            const bool from_a = (m_a & bit) != 0, x = (m_x & bit) != 0;
-            const uint32_t pos = from_a ? (x ? p_a : p_i) : p_b;
-            if (from_a | !x) lds[pos] = vals[step];
-            p_i += uint32_t(from_a & !x);
-            p_a += uint32_t(from_a & x);
-            p_b += uint32_t(!from_a & !x);
+            const uint32_t c = (m_c >> (2 * (kVT - 1 - step))) & 3;
+            const uint32_t pos = c == 0 ? p_i : (c == 1 ? p_a : p_b);
+            if (c != 3) lds[pos] = vals[step];
+            p_i += uint32_t(c == 0);
+            p_a += uint32_t(c == 1);
+            p_b += uint32_t(c == 2);
           }
         }
       }

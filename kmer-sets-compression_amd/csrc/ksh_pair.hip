@@ -26,11 +26,12 @@
 namespace ksh {
 
 // One wavefront per tile: 64 lanes x up to kVT keys each.  A bucket of a pair holds about
-// 1.2 k merged keys at 10^7 keys per set, and the per-tile fixed cost (descriptor and key
-// loads, the split search, the wave scan) is what a small tile pays for, so 4-byte keys use
-// tiles large enough to take such a bucket whole.  Single-wave workgroups need no cross-wave
-// scan and no barrier that waits for another wave.  The LDS footprint (6 KB) keeps 26
-// tiles in flight per CU; 8-byte keys use smaller tiles to stay at that occupancy.
+// 1.2 k merged keys at 10^7 keys per set and is cut into two balanced tiles of about 610; the
+// per-tile fixed cost (descriptor and key loads, the split search, the wave scan) is what a small
+// tile pays for (kVT = 15 and 13 measure the same on config 2, 11 and 9 are 6 % and 11 % slower).
+// Single-wave workgroups need no cross-wave scan and no barrier that waits for another wave.
+// The LDS footprint (4 KB) lets the hardware's 32 waves per CU be resident; 8-byte keys use
+// smaller tiles to stay at that footprint.
 constexpr int kThreads = 64;        // lanes per tile (one wavefront)
 // Wavefronts per workgroup of k_tile_merge.  The waves of a workgroup work on different tiles and
 // never talk to each other.  The dispatcher launches about 4.4 workgroups per ns whatever their

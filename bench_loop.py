@@ -35,6 +35,9 @@ def main():
                     help="untimed builds before the timed one: the first build of a process pays the "
                          "driver's one-off cost of mapping fresh VRAM (10-40 us per MB on this pool, box by "
                          "box), which the context's caching pool then keeps")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed build: Size and XOR Hash of Get(i) against the decoded input, every i "
+                         "(the reference's --check, src/kmerset-multiple-compress.cc:104-126), on the device")
     ap.add_argument("--gpus", type=int, default=1,
                     help="strong scaling of the loop: N processes (python -m torch.distributed.run "
                          "--nproc-per-node N bench_loop.py --gpus N ...), every rank runs the loop on "
@@ -139,6 +142,18 @@ def main():
                                   "1 process per GPU, sets replicated, SPSS encodes dealt out by node, "
                                   "all-gather of (n_strings, n_bases) at the convergence checks"},
     }
+    if args.verify:
+        bad = []
+        for i, c in enumerate(compacts):
+            want = ctx.spss_decode(c)
+            got = kss.get_size_and_hash(i)
+            if got != (want.n_keys, ctx.set_hash(want)):
+                bad.append(i)
+            del want
+        out["verified"] = {"sets": len(compacts), "mismatches": bad,
+                           "method": "Size and XOR Hash of Get(i) == those of the decoded input i, on the device"}
+        if bad:
+            raise SystemExit("verification failed for sets %s" % bad)
     if args.cpu_iterations > 0 and rank == 0:
         import oracle_lib as ol
 

@@ -740,6 +740,21 @@ class DeviceKmerSetSet:
         out["phase_seconds"] = dict(zip(["decode_inputs", "weights", "merges", "encodes"], [float(x) for x in ph]))
         return out
 
+    def get_size_and_hash(self, i):
+        """(KmerSet::Size, KmerSet::Hash) of KmerSetSet::Get(i), computed on the device: what
+        kmerset-multiple-compress --check compares per input set (src/kmerset-multiple-compress.cc:104-126)."""
+        d_off, d_keys, n = C.c_void_p(), C.c_void_p(), C.c_int64()
+        check(lib().ksh_kss_get(self.h, i, C.byref(d_off), C.byref(d_keys), C.byref(n)))
+        try:
+            v = SetView(d_off.value, d_keys.value, n.value)
+            out = C.c_uint64()
+            check(lib().ksh_set_hash(self.ctx.h, C.byref(self.g), C.byref(v), C.byref(out)))
+            return n.value, out.value
+        finally:
+            dev = self.ctx.device.index
+            lib().ksh_free(dev, d_off)
+            lib().ksh_free(dev, d_keys)
+
     def get_kmers(self, i):
         """KmerSetSet::Get(i) as a sorted uint64 array (downloaded)."""
         d_off, d_keys, n = C.c_void_p(), C.c_void_p(), C.c_int64()

@@ -185,6 +185,10 @@ def main():
         # sets: Intersection(j, k) [two by-value copies + two Sub], then j.Sub(n), k.Sub(n).
         done_units, spent = 0, 0.0
         used = []
+        # one more (untimed) batch whose three outputs per pair are compared with the oracle's by
+        # size and XOR hash (BASELINE config 2: counts and hashes bit-exact against the CPU path)
+        check_res = ctx.pair_algebra_batch([(sets[i], sets[j]) for (i, j) in pairs])
+        gpu_sig = [[(s_.n_keys, ctx.set_hash(s_)) for s_ in check_res[idx]] for idx in range(len(pairs))]
         for (i, j) in pairs:
             a = ol.Set.from_kmers(k, nbits, g.key_bytes, host_sets[i])
             b = ol.Set.from_kmers(k, nbits, g.key_bytes, host_sets[j])
@@ -196,6 +200,9 @@ def main():
             done_units += host_sets[i].size + host_sets[j].size
             used.append((i, j))
             assert a.size() + b.size() == diffs[pairs.index((i, j))]
+            cpu_sig = [(n.size(), n.hash()), (a.size(), a.hash()), (b.size(), b.hash())]
+            assert cpu_sig == gpu_sig[pairs.index((i, j))], "pair %s: GPU %s != oracle %s" % (
+                (i, j), gpu_sig[pairs.index((i, j))], cpu_sig)
             if spent >= args.cpu_baseline_seconds:
                 break
         cpu_baseline = {
@@ -205,6 +212,7 @@ def main():
             "kind": "port",
             "sample": "oracle hash-set algebra (Intersection + 2 Sub) on pairs %s of the same "
                       "workload, full size, set construction excluded, %.1f s of CPU" % (used, spent),
+            "checked": "sizes and XOR hashes of A&B, A\\B, B\\A of those pairs: GPU == oracle",
         }
 
     spss = None

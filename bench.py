@@ -110,6 +110,12 @@ def main():
 
     # two slots: the all-gather of step s travels while step s + 1 computes
     diff_local = [torch.zeros(len(pairs), dtype=torch.int64, device=coll_dev) for _ in range(2)]
+    # pinned staging for the per-step sizes: the copy to the device is enqueued, not waited for (a
+    # slot is reused two steps later, after a batch call that ends with a stream synchronisation)
+    diff_host = [torch.zeros(len(pairs), dtype=torch.int64) for _ in range(2)]
+    if world > 1 and coll_dev.type == "cuda":
+        diff_host = [t.pin_memory() for t in diff_host]
+    diff_host_np = [t.numpy() for t in diff_host]
     gathered = [[torch.zeros_like(diff_local[0]) for _ in range(world)] for _ in range(2)] if world > 1 else None
     pending = [None]
     step_no = [0]
@@ -136,7 +142,8 @@ def main():
         if world > 1:
             slot = step_no[0] & 1
             step_no[0] += 1
-            diff_local[slot].copy_(torch.tensor(diffs, dtype=torch.int64), non_blocking=False)
+            diff_host_np[slot][:] = diffs
+            diff_local[slot].copy_(diff_host[slot], non_blocking=True)
             work = dist.all_gather(gathered[slot], diff_local[slot], async_op=True)
             if pending[0] is not None:
                 pending[0].wait()      # the previous step's exchange; this one overlaps the next step

@@ -57,12 +57,18 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=120)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--progress-seconds", type=float, default=60,
+                    help="a line with the case counts this often (a silent GPU job is taken to be hung)")
     args = ap.parse_args()
     rng = np.random.default_rng(args.seed)
     ctx = capi.Context(0)
     t_end = time.time() + args.seconds
     n_cases = {"algebra": 0, "spss": 0, "count": 0}
+    t_note = time.time() + args.progress_seconds
     while time.time() < t_end:
+        if time.time() >= t_note:
+            print("fuzz running: seed %d, %.0f s left, cases %s" % (args.seed, t_end - time.time(), n_cases), flush=True)
+            t_note = time.time() + args.progress_seconds
         k, n, kb = GEOMS[int(rng.integers(0, len(GEOMS)))]
         g = capi.geom(k, n)
         kind = ["uniform", "clustered", "dense", "genome"][int(rng.integers(0, 4))]

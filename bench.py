@@ -1,30 +1,37 @@
 #!/usr/bin/env python3
-"""bench.py -- Mk-mers/s of the k-mer-set hot path on MI355X.
+"""bench.py -- Mk-mers/s of kmerset-multiple-compress's hot path on MI355X.
 
   python bench.py --gpus N --steps K --warmup W
 
-Workload at N = 1 (BASELINE.json configs[1]): 4 synthetic canonical k=23 sets of
-10^7 k-mers each (seeded phylogeny family), resident in HBM as
-bucketed sorted keys; one step = the pair algebra of all 6 pairs (one
-ksh_pair_algebra_batch call: the pairs are independent, so their passes are enqueued back to
-back and one stream synchronisation returns all the sizes) -- for each pair
-(A, B): A&B, A\\B, B\\A with their bucket offsets and the three counts (what one
-KmerSetSet iteration asks for, lib/core/kmer_set_set.h:339-343), Diff = |A\\B| +
-|B\\A| derived from them.  Units = sum over pairs of (|A| + |B|) k-mers.
+What is timed is what the reference times around the KmerSetSet constructor
+(src/kmerset-multiple-compress.cc:96-101, lib/core/kmer_set_set.h:109-427): the inputs are
+KmerSetCompact containers already resident in HBM; one STEP = one whole ksh_kss_build -- decode
+of the inputs, sampled weight table, every merge iteration (Intersection + Sub + Sub), the SPSS
+re-encodes the convergence checks and the result need.  Mk-mers/s = N_proc / wall with
+N_proc = sum |S_i| + sum over iterations (|S_j| + |S_k|).
 
-N > 1 (one process per GPU, launched by torch.distributed.run): every rank runs
-the same-size batch on its own family (weak scaling), then the per-pair diff
-sizes are all-gathered over RCCL (the exchange step north_star names).
+Workload at N = 1: 64 synthetic canonical k=23 sets of 10^8 k-mers (the sets of BASELINE.json
+configs[3], the case north_star quotes the 1-GPU target on; 25.6 GB of resident keys), seeded
+phylogeny family generated on the device before anything is timed.
 
-Prints ONE JSON line on rank 0.  `roofline` is the write-pass merge kernel
-(k_tile_merge<KeyT, 1>): algorithmic bytes (|A| + |B| + |A u B|) * key_bytes per
-launch over its HIP-event duration, against the 8 TB/s HBM peak; `traffic` is filled
-from profiles/pmc_traffic.json when that file holds a PMC measurement (rocprofv3
---pmc FETCH_SIZE / WRITE_SIZE passes) of the same kernel on the same workload.
-`cpu_baseline` times the oracle's restatement of the reference's hash-set algebra on
-the host (rank 0, N = 1 only, bounded sample).  `spss` (outside the timed region) runs
-the whole KmerSetSet loop once on the same sets and reports the second half of the
-metric: bytes/k-mer after SPSS.
+N > 1 (one process per GPU, launched by torch.distributed.run): the SAME 64 sets, strong
+scaling: the owner-sharded build (ksh_kss_build_owned) -- every input set is decoded and kept
+by one rank, the 2 % sampled slices are all-gathered, the control loop runs replicated on the
+samples, a merge and the encodes of its results run on the rank that owns the node, RCCL on
+device buffers.
+
+Prints ONE JSON line on rank 0.
+  roofline     the loop's dominant kernel (k_adjacency, the neighbour probe of the SPSS encode):
+               algorithmic bytes = 5.3 B per k-mer (read key + write adjacency byte
+               + packed bases) x the k-mers of a launch, over its HIP-event duration on the
+               context's stream, against the 8 TB/s HBM peak; the probe-inclusive figure
+               (36 B per k-mer: the key + 8 neighbour lookups) is reported beside it; `traffic`
+               from profiles/pmc_adjacency.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes).
+  cpu_baseline the oracle's port of the same loop (first I iterations of a reduced family, same
+               N_proc on both sides), bucket-parallel threads as the reference has them, at
+               n_workers = all host cores and at 1 (rank 0, N = 1 only).
+  pair_merge   the pair-algebra kernel on configs[1] (4 x 10^7), the round-1 headline, as an
+               extra block.
 """
 import argparse
 import json
@@ -38,31 +45,39 @@ for p in (os.path.join(ROOT, "kmer-sets-compression_amd"), os.path.join(ROOT, "t
         sys.path.insert(0, p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s
+ENCODE_BYTES_PER_KMER = 5.3       # compulsory read s + 1 B adjacency + w/4 packed bases
+ENCODE_PROBE_BYTES_PER_KMER = 36  # s + 8 * s, the 8 neighbour lookups missing LDS
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--k", type=int, default=23)
     ap.add_argument("--bucket-bits", type=int, default=14)
-    ap.add_argument("--sets", type=int, default=4)
-    ap.add_argument("--size", type=float, default=1e7, help="k-mers per set")
-    ap.add_argument("--seed", type=int, default=2)
+    ap.add_argument("--sets", type=int, default=64)
+    ap.add_argument("--size", type=float, default=1e8, help="k-mers per set")
+    ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--max-iterations", type=int, default=-1)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-spss", action="store_true", help="skip the untimed KmerSetSet run")
-    ap.add_argument("--two-pass", action="store_true",
-                    help="use ksh_pair_plan + allocate + ksh_pair_write (exact-size outputs) "
-                         "instead of the one-call ksh_pair_algebra (upper-bound outputs)")
-    ap.add_argument("--per-pair-sync", action="store_true",
-                    help="one ksh_pair_algebra call (and one stream sync) per pair instead of one "
-                         "ksh_pair_algebra_batch call per step")
-    ap.add_argument("--cpu-baseline-seconds", type=float, default=12.0)
-    ap.add_argument("--time-every", type=int, default=5,
-                    help="HIP-event pair around every n-th merge launch of the timed region (an event "
-                         "pair idles the stream for ~10 us, so timing every launch would cost the "
-                         "throughput figure ~15%%)")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="skip the Size / XOR-Hash check of every Get(i) after the timed builds")
+    ap.add_argument("--no-pair-merge", action="store_true", help="skip the configs[1] pair-algebra block")
+    ap.add_argument("--cpu-sets", type=int, default=16)
+    ap.add_argument("--cpu-size", type=float, default=1e6)
+    ap.add_argument("--cpu-iterations", type=int, default=4)
+    ap.add_argument("--cpu-workers", type=int, default=0, help="0 = all host cores")
     args = ap.parse_args()
 
     import numpy as np
@@ -78,8 +93,8 @@ def main():
         raise SystemExit("WORLD_SIZE=%d does not match --gpus %d" % (world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the hot path has no CPU fallback")
-    # Rehearsal on a one-GPU box: KSH_BENCH_BACKEND=gloo puts every rank on cuda:0 and runs
-    # the collectives on CPU tensors (RCCL refuses two ranks on one device).
+    # Rehearsal on a one-GPU box: KSH_BENCH_BACKEND=gloo puts every rank on cuda:0 and runs the
+    # exchanges through host memory (RCCL refuses two ranks on one device).
     backend = os.environ.get("KSH_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank = 0
@@ -95,174 +110,212 @@ def main():
             dist.init_process_group(backend)
     coll_dev = torch.device("cuda", local_rank) if backend == "nccl" else torch.device("cpu")
 
-    from kmersets import capi, synth
+    from kmersets import capi, synth, synth_torch
 
     k, nbits, n_sets, size = args.k, args.bucket_bits, args.sets, int(args.size)
     g = capi.geom(k, nbits)
     ctx = capi.Context(local_rank)
     dev = ctx.device
+    ids = synth.sample_bucket_ids(nbits, seed=args.seed + 1)
 
-    # ---- inputs, resident in HBM before anything is timed
-    host_sets = synth.phylogeny_sets(k, n_sets, size, seed=args.seed + 1000 * rank)
-    sets = [capi.DeviceSet.from_kmers(g, s, dev) for s in host_sets]
-    pairs = [(i, j) for i in range(n_sets) for j in range(i + 1, n_sets)]
-    units_per_step = sum(sets[i].n_keys + sets[j].n_keys for i, j in pairs)
-
-    # two slots: the all-gather of step s travels while step s + 1 computes
-    diff_local = [torch.zeros(len(pairs), dtype=torch.int64, device=coll_dev) for _ in range(2)]
-    # pinned staging for the per-step sizes: the copy to the device is enqueued, not waited for (a
-    # slot is reused two steps later, after a batch call that ends with a stream synchronisation)
-    diff_host = [torch.zeros(len(pairs), dtype=torch.int64) for _ in range(2)]
-    if world > 1 and coll_dev.type == "cuda":
-        diff_host = [t.pin_memory() for t in diff_host]
-    diff_host_np = [t.numpy() for t in diff_host]
-    gathered = [[torch.zeros_like(diff_local[0]) for _ in range(world)] for _ in range(2)] if world > 1 else None
-    pending = [None]
-    step_no = [0]
-    algo_bytes = [0.0]
-
-    algebra = ctx.pair_algebra if args.two_pass else ctx.pair_algebra_onepass
-    kernel_kind = 0
-
-    def step(record):
-        diffs = []
-        if args.per_pair_sync or args.two_pass:
-            results = [algebra(sets[i], sets[j]) for (i, j) in pairs]
+    # ---- inputs: KmerSetCompact containers resident in HBM before anything is timed.  In a
+    # multi-GPU run a rank only builds the containers of the sets it owns (set i -> rank i % world).
+    t0 = time.perf_counter()
+    kmers = synth_torch.phylogeny_sets(k, n_sets, size, args.seed, dev)
+    sizes = [int(km.numel()) for km in kmers]
+    compacts = []
+    for i, km in enumerate(kmers):
+        if world > 1 and i % world != rank:
+            compacts.append(None)
         else:
-            results = ctx.pair_algebra_batch([(sets[i], sets[j]) for (i, j) in pairs])
-        if hasattr(results, "totals"):      # the batch result: sizes without touching the sets
-            sizes = [(int(t[1]), int(t[2])) for t in results.totals]
-        else:
-            sizes = [(amb.n_keys, bma.n_keys) for (_inter, amb, bma) in results]
-        for (i, j), (n_amb, n_bma) in zip(pairs, sizes):
-            diffs.append(n_amb + n_bma)
-            if record:
-                union = sets[i].n_keys + n_bma
-                algo_bytes[0] += (sets[i].n_keys + sets[j].n_keys + union) * g.key_bytes
-        if world > 1:
-            slot = step_no[0] & 1
-            step_no[0] += 1
-            diff_host_np[slot][:] = diffs
-            diff_local[slot].copy_(diff_host[slot], non_blocking=True)
-            work = dist.all_gather(gathered[slot], diff_local[slot], async_op=True)
-            if pending[0] is not None:
-                pending[0].wait()      # the previous step's exchange; this one overlaps the next step
-            pending[0] = work
-        return diffs
+            compacts.append(ctx.spss_encode(synth_torch.device_set(g, km), mode=0))
+        kmers[i] = None
+    del kmers
+    torch.cuda.synchronize()
+    t_inputs = time.perf_counter() - t0
+
+    def build():
+        if world == 1:
+            return capi.DeviceKmerSetSet(ctx, compacts, ids, max_iterations=args.max_iterations)
+        return capi.OwnedKmerSetSet(ctx, compacts, ids, dist, coll_dev, max_iterations=args.max_iterations)
 
     def fence():
         if world > 1:
-            if pending[0] is not None:
-                pending[0].wait()
-                pending[0] = None
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
-    ctx.enable_timing(max(1, args.time_every))
+    first_wall = None
+    for _ in range(max(0, args.warmup)):
+        fence()
+        w0 = time.perf_counter()
+        warm = build()
+        fence()
+        if first_wall is None:
+            first_wall = time.perf_counter() - w0
+        warm.close()
+    ctx.enable_timing(1)
     ctx.timing_reset()
     fence()
     t0 = time.perf_counter()
+    kss = None
     for _ in range(args.steps):
-        diffs = step(True)
+        if kss is not None:
+            kss.close()
+        kss = build()
     fence()
     elapsed = time.perf_counter() - t0
-    write_ms, write_launches = ctx.timing_read(kernel_kind)
-    count_ms, count_launches = ctx.timing_read(1)
+    timers = {name: (ctx.timing_read(kind), ctx.timing_units(kind))
+              for name, kind in (("k_adjacency", 3), ("k_ruler_walk", 4), ("k_emit", 5))}
     ctx.enable_timing(False)
 
+    st = kss.stats()
+    it, cp, imp = kss.trace()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        u = torch.tensor([units_per_step], dtype=torch.int64, device=coll_dev)
-        dist.all_reduce(u, op=dist.ReduceOp.SUM)
-        total_units_per_step = int(u.item())
-    else:
-        total_units_per_step = units_per_step
+    n_proc = st["n_processed"]
+    value = n_proc * args.steps / elapsed / 1e6
 
-    value = total_units_per_step * args.steps / elapsed / 1e6
+    verified = None
+    if not args.no_verify:
+        # the reference's own --check (src/kmerset-multiple-compress.cc:104-126) on the device: Size
+        # and XOR Hash of Get(i) against the decoded input, every i (every rank checks the sets it owns)
+        bad, checked = [], 0
+        for i, c in enumerate(compacts):
+            if c is None:
+                continue
+            want = ctx.spss_decode(c)
+            got = kss.get_size_and_hash(i)
+            checked += 1
+            if got != (want.n_keys, ctx.set_hash(want)):
+                bad.append(i)
+            del want
+        if world > 1:
+            b = torch.tensor([len(bad), checked], dtype=torch.int64, device=coll_dev)
+            dist.all_reduce(b)
+            n_bad, checked = int(b[0].item()), int(b[1].item())
+        else:
+            n_bad = len(bad)
+        verified = {"sets": checked, "mismatches": n_bad,
+                    "method": "Size and XOR Hash of Get(i) == those of the decoded input i, on the device, "
+                              "after the last timed build"}
+        if n_bad:
+            raise SystemExit("verification failed: %d of %d sets (rank %d: %s)" % (n_bad, checked, rank, bad))
 
+    total = sum(sizes)
+    spss = {
+        "bytes_per_kmer": (st["packed_bytes"] + st["length_bytes"]) / total,
+        "chars_per_kmer_before": st["initial_spss_weight"] / total,
+        "chars_per_kmer_after": st["final_spss_weight"] / total,
+        "nodes": st["nodes"], "iterations": int(it.shape[0]), "checkpoints": int(cp.shape[0]),
+        "note": "from the last timed build; bytes = sum over nodes of ceil(2 * Weight / 8) + StreamVByte-0124 "
+                "size of the lengths (SURVEY.md 8d, metric 2)",
+    }
+    if world > 1:
+        lb = torch.tensor([st["length_bytes"]], dtype=torch.int64, device=coll_dev)
+        dist.all_reduce(lb)       # a node's lengths live on the rank that holds its SPSS
+        spss["bytes_per_kmer"] = (st["packed_bytes"] + int(lb.item())) / total
+
+    # ---- pair-merge block (configs[1]; the round-1 headline, kept as an extra key)
+    pair_merge = None
+    if rank == 0 and world == 1 and not args.no_pair_merge:
+        kss.close()
+        kss = None
+        pm_sets = [synth_torch.device_set(g, km) for km in synth_torch.phylogeny_sets(k, 4, int(1e7), 2, dev)]
+        pairs = [(i, j) for i in range(4) for j in range(i + 1, 4)]
+        jobs = [(pm_sets[i], pm_sets[j]) for i, j in pairs]
+        for _ in range(3):
+            ctx.pair_algebra_batch(jobs)
+        ctx.enable_timing(1)
+        ctx.timing_reset()
+        torch.cuda.synchronize()
+        p0 = time.perf_counter()
+        pm_steps = 10
+        for _ in range(pm_steps):
+            res = ctx.pair_algebra_batch(jobs)
+        torch.cuda.synchronize()
+        pm_wall = time.perf_counter() - p0
+        wms, wl = ctx.timing_read(0)
+        cms, cl = ctx.timing_read(1)
+        ctx.enable_timing(False)
+        units = sum(a.n_keys + b.n_keys for a, b in jobs)
+        algo = sum((a.n_keys + b.n_keys + a.n_keys + int(t[2])) * g.key_bytes for (a, b), t in zip(jobs, res.totals))
+        pair_merge = {
+            "workload": "configs[1]: 4 canonical k=23 sets of 10^7 k-mers, all 6 pairs per step: A&B, A\\B, B\\A + counts",
+            "mkmers_per_s": units * pm_steps / pm_wall / 1e6, "ms_per_step": pm_wall / pm_steps * 1e3,
+            "write_pass_avg_launch_ms": wms / max(wl, 1), "count_pass_avg_launch_ms": cms / max(cl, 1),
+            "algorithmic_bytes_per_launch": algo,
+            "write_pass_frac_of_hbm_peak": algo / (wms / max(wl, 1) * 1e-3) / 1e9 / HBM_PEAK_GBS if wms > 0 else None,
+            "step_frac_of_hbm_peak": algo / (pm_wall / pm_steps) / 1e9 / HBM_PEAK_GBS,
+            "note": "kernel-level fraction = algorithmic bytes / write-pass launch; step-level = the same bytes "
+                    "over the whole step (count pass + plan + write pass + read-back)",
+        }
+        del pm_sets, jobs, res
+
+    # ---- CPU baseline: the oracle's port of the loop, threads as the reference has them
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle_lib as ol
 
-        # The reference's algebra for one merge (kmer_set_set.h:339-343) on hash-bucket
-        # sets: Intersection(j, k) [two by-value copies + two Sub], then j.Sub(n), k.Sub(n).
-        done_units, spent = 0, 0.0
-        used = []
-        # one more (untimed) batch whose three outputs per pair are compared with the oracle's by
-        # size and XOR hash (BASELINE config 2: counts and hashes bit-exact against the CPU path)
-        check_res = ctx.pair_algebra_batch([(sets[i], sets[j]) for (i, j) in pairs])
-        gpu_sig = [[(s_.n_keys, ctx.set_hash(s_)) for s_ in check_res[idx]] for idx in range(len(pairs))]
-        for (i, j) in pairs:
-            a = ol.Set.from_kmers(k, nbits, g.key_bytes, host_sets[i])
-            b = ol.Set.from_kmers(k, nbits, g.key_bytes, host_sets[j])
+        cs, csize, ci = args.cpu_sets, int(args.cpu_size), args.cpu_iterations
+        cores = args.cpu_workers or (os.cpu_count() or 1)
+        try:
+            cores = min(cores, len(os.sched_getaffinity(0)))
+        except AttributeError:
+            pass
+        host = synth.phylogeny_sets(k, cs, csize, seed=args.seed)
+        oc = [ol.Set.from_kmers(k, nbits, g.key_bytes, s).compact() for s in host]
+        runs = {}
+        for w in (cores, 1):
             c0 = time.perf_counter()
-            n = a.intersection(b)
-            a.sub_set(n)
-            b.sub_set(n)
-            spent += time.perf_counter() - c0
-            done_units += host_sets[i].size + host_sets[j].size
-            used.append((i, j))
-            assert a.size() + b.size() == diffs[pairs.index((i, j))]
-            cpu_sig = [(n.size(), n.hash()), (a.size(), a.hash()), (b.size(), b.hash())]
-            assert cpu_sig == gpu_sig[pairs.index((i, j))], "pair %s: GPU %s != oracle %s" % (
-                (i, j), gpu_sig[pairs.index((i, j))], cpu_sig)
-            if spent >= args.cpu_baseline_seconds:
-                break
+            okss = ol.KmerSetSet(oc, ids, max_iterations=ci, n_workers=w)
+            cw = time.perf_counter() - c0
+            runs[w] = (okss.stat(3) / cw / 1e6, cw, okss.stat(3), [tuple(r[:5]) for r in okss.iterations()])
+            del okss
+        # the GPU on the same sample: same merges, same N_proc
+        gc = [ctx.spss_encode(capi.DeviceSet.from_kmers(g, s, dev), mode=0) for s in host]
+        gk = capi.DeviceKmerSetSet(ctx, gc, ids, max_iterations=ci)
+        g_it = [tuple(int(x) for x in r) for r in gk.trace()[0]]
+        same = all(g_it == runs[w][3] and gk.stats()["n_processed"] == runs[w][2] for w in runs)
+        gk.close()
+        if not same:
+            raise SystemExit("CPU baseline sample: the oracle's merge sequence differs from the GPU's")
         cpu_baseline = {
-            "value": done_units / spent / 1e6,
-            "unit": "Mk-mers/s",
-            "cores": 1,
-            "kind": "port",
-            "sample": "oracle hash-set algebra (Intersection + 2 Sub) on pairs %s of the same "
-                      "workload, full size, set construction excluded, %.1f s of CPU" % (used, spent),
-            "checked": "sizes and XOR hashes of A&B, A\\B, B\\A of those pairs: GPU == oracle",
+            "value": runs[cores][0], "unit": "Mk-mers/s", "cores": cores, "kind": "port",
+            "cpu": cpu_model(),
+            "value_1_core": runs[1][0],
+            "sample": "oracle KmerSetSet (C++ port of lib/core/kmer_set_set.h:109-427 with the reference's "
+                      "bucket-parallel / pooled structure), %d sets of %d k-mers of the same family, first %d "
+                      "iterations, N_proc = %d on both sides; %.1f s at %d workers, %.1f s at 1"
+                      % (cs, csize, ci, runs[cores][2], runs[cores][1], cores, runs[1][1]),
+            "checked": "merge sequence (j, k, weight, sizes) and N_proc of the sample: GPU == oracle",
         }
-
-    spss = None
-    if rank == 0 and world == 1 and not args.no_spss:
-        compacts = [ctx.spss_encode(s, mode=0) for s in sets]
-        ids = synth.sample_bucket_ids(nbits, seed=args.seed + 1)
-        torch.cuda.synchronize()
-        l0 = time.perf_counter()
-        kss = capi.DeviceKmerSetSet(ctx, compacts, ids)
-        torch.cuda.synchronize()
-        lwall = time.perf_counter() - l0
-        st = kss.stats()
-        total = sum(s.n_keys for s in sets)
-        spss = {
-            "bytes_per_kmer": (st["packed_bytes"] + st["length_bytes"]) / total,
-            "chars_per_kmer_before": st["initial_spss_weight"] / total,
-            "chars_per_kmer_after": st["final_spss_weight"] / total,
-            "nodes": st["nodes"], "iterations": int(kss.trace()[0].shape[0]),
-            "loop_mkmers_per_s": st["n_processed"] / lwall / 1e6, "loop_wall_ms": lwall * 1e3,
-            "note": "whole KmerSetSet constructor on the same %d sets, one run, outside the timed "
-                    "region; bytes = sum over nodes of ceil(2 * Weight / 8) + StreamVByte-0124 size of the lengths" % n_sets,
-        }
-        kss.close()
 
     traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_adjacency.json")
     if rank == 0 and os.path.exists(pmc_file):
         pmc = json.load(open(pmc_file))
-        if pmc.get("kernel") == "k_tile_merge<KeyT, 1>" and pmc.get("kmers_per_set") == size \
-                and pmc.get("k") == k and pmc.get("sets") == n_sets:
-            # the counters were collected on batched launches; a per-pair launch moves a
-            # proportional share
-            per_launch_pairs = 1 if (args.per_pair_sync or args.two_pass) else len(pairs)
-            traffic = pmc["bytes_per_launch"] * per_launch_pairs / pmc.get("pairs_per_launch", 1)
-            traffic_src = "profiles/pmc_traffic.json"
+        if pmc.get("k") == k and pmc.get("bytes_per_kmer"):
+            traffic_per_kmer = pmc["bytes_per_kmer"]
+            traffic_src = "profiles/pmc_adjacency.json"
+        else:
+            traffic_per_kmer = None
+    else:
+        traffic_per_kmer = None
 
     if rank == 0:
-        # algo_bytes covers every launch of the timed region, write_ms the sampled ones
-        # one write-pass launch per pair, or one for the whole batch of a step
-        all_launches = args.steps * (len(pairs) if (args.per_pair_sync or args.two_pass) else 1)
-        bytes_per_launch = algo_bytes[0] / max(all_launches, 1)
-        avg_launch_ms = write_ms / max(write_launches, 1)
-        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if write_ms > 0 else 0.0
+        (adj_ms, adj_launches), adj_units = timers["k_adjacency"]
+        kmers_per_launch = adj_units / max(adj_launches, 1)
+        avg_launch_ms = adj_ms / max(adj_launches, 1)
+        bytes_per_launch = ENCODE_BYTES_PER_KMER * kmers_per_launch
+        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if adj_ms > 0 else 0.0
+        if traffic_per_kmer is not None:
+            traffic = traffic_per_kmer * kmers_per_launch
+        other = {}
+        for name in ("k_ruler_walk", "k_emit"):
+            (ms, n), units = timers[name]
+            other[name] = {"ms_total": ms, "launches": n, "ns_per_kmer": ms * 1e6 / max(units, 1)}
         out = {
             "metric": "Mk-mers/s processed in kmerset-multiple-compress; bytes/k-mer after SPSS",
             "value": value,
@@ -272,40 +325,55 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None,
             "dtype": "u32" if g.key_bytes == 4 else "u64",
             "data": "synthetic",
             "config": {
-                "workload": "configs[1]: %d canonical k=%d sets of %d k-mers (seeded phylogeny family), "
-                            "all %d pairs: A&B, A\\B, B\\A + counts per pair" % (n_sets, k, size, len(pairs)),
+                "workload": "%d canonical k=%d sets of %d k-mers (seeded phylogeny family), the whole KmerSetSet "
+                            "constructor per step: decode, weights, every merge, SPSS encodes (configs[3]'s sets; "
+                            "north_star's 1-GPU case)" % (n_sets, k, size),
                 "k": k, "n_bucket_bits": nbits, "key_bytes": g.key_bytes,
-                "sets_per_gpu": n_sets, "kmers_per_set": [s.n_keys for s in sets],
-                "pairs_per_step": len(pairs), "units_per_step": total_units_per_step,
-                "parallelism": "1 process per GPU, pairs sharded by rank, RCCL all-gather of "
-                               "per-pair diff sizes" if world > 1 else "1 GPU",
+                "sets": n_sets, "sum_input_kmers": total, "n_processed_per_step": n_proc,
+                "iterations": int(it.shape[0]), "nodes": st["nodes"],
+                "input_build_s": t_inputs, "first_build_wall_s": first_wall,
+                "sum_input_mkmers_per_s": total * args.steps / elapsed / 1e6,
+                "parallelism": "1 GPU" if world == 1 else
+                               "1 process per GPU, owner-sharded sets (set i on rank i %% %d), replicated control "
+                               "loop on all-gathered 2 %% samples, merges and encodes on the owner, RCCL "
+                               "all-gather / send-recv on device buffers" % world,
             },
+            "phase_seconds_last_build": st["phase_seconds"],
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_tile_merge<KeyT, 1> (write pass)",
-                "pairs_per_launch": 1 if (args.per_pair_sync or args.two_pass) else len(pairs),
+                "kernel": "k_adjacency (neighbour probe of the SPSS encode)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
-                "launches": int(all_launches),
-                "launches_timed": int(write_launches),
+                "launches": int(adj_launches),
                 "avg_launch_ms": avg_launch_ms,
+                "kmers_per_launch": kmers_per_launch,
+                "ns_per_kmer": adj_ms * 1e6 / max(adj_units, 1),
+                "algorithmic_bytes_per_kmer": ENCODE_BYTES_PER_KMER,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
-                "count_pass_avg_launch_ms": (count_ms / count_launches) if count_launches else None,
+                "probe_inclusive_bytes_per_kmer": ENCODE_PROBE_BYTES_PER_KMER,
+                "probe_inclusive_frac": achieved / HBM_PEAK_GBS * ENCODE_PROBE_BYTES_PER_KMER / ENCODE_BYTES_PER_KMER,
+                "share_of_timed_region": adj_ms * 1e-3 / elapsed,
+                "other_kernels": other,
             },
             "cpu_baseline": cpu_baseline,
             "spss": spss,
+            "verified": verified,
+            "pair_merge": pair_merge,
         }
         print(json.dumps(out))
+    if kss is not None:
+        kss.close()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
     ctx.close()
 

@@ -90,10 +90,14 @@ int ksh_ctx_reserve(ksh_ctx* ctx, size_t bytes);
  * launch.  ksh_ctx_timing_read synchronises the stream and returns the summed duration and
  * the number of timed launches since the last reset.
  * kinds: 0 = pair merge, write pass   1 = pair merge, count pass
- *        2 = sampled-bucket weight count pass */
+ *        2 = sampled-bucket weight count pass
+ *        3 = SPSS encode, neighbour probe (k_adjacency: the loop's dominant kernel)
+ *        4 = SPSS encode, chain ranking (k_ruler_walk)   5 = SPSS encode, base emit (k_emit)
+ * ksh_ctx_timing_units: the k-mers (kinds 3..5) the timed launches of a kind covered. */
 int ksh_ctx_enable_timing(ksh_ctx* ctx, int enable);
 int ksh_ctx_timing_reset(ksh_ctx* ctx);
 int ksh_ctx_timing_read(ksh_ctx* ctx, int kind, float* total_ms, int64_t* launches);
+int ksh_ctx_timing_units(ksh_ctx* ctx, int kind, int64_t* units);
 
 /* ---- KmerSet::Size / Hash  (lib/core/kmer_set.h:65-71, :224-244) --------------------- */
 /* XOR of all k-mer bit patterns in the set. */

@@ -516,6 +516,7 @@ int ksh_ctx_timing_reset(ksh_ctx* ctx) {
   for (int i = 0; i < kNumTimers; i++) {
     ctx->ev_spans[i].clear();
     ctx->timing_seen[i] = 0;
+    ctx->timing_units[i] = 0;
   }
   return KSH_OK;
 }
@@ -532,6 +533,13 @@ int ksh_ctx_timing_read(ksh_ctx* ctx, int kind, float* total_ms, int64_t* launch
   }
   *total_ms = float(sum);
   *launches = int64_t(ctx->ev_spans[kind].size());
+  return KSH_OK;
+}
+
+int ksh_ctx_timing_units(ksh_ctx* ctx, int kind, int64_t* units) {
+  if (!ctx || !units) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  if (kind < 0 || kind >= kNumTimers) return fail(KSH_INVALID_ARGUMENT, "no timer kind %d", kind);
+  *units = ctx->timing_units[kind];
   return KSH_OK;
 }
 

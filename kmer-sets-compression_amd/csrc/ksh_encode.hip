@@ -1103,10 +1103,13 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   int* flags = static_cast<int*>(arena_alloc(ctx, 16));  // [0] pointer-jumping progress, [1] self_rc
   if (!flags) return fail(KSH_INTERNAL, "scratch arena too small");
   KSH_HIP(hipMemsetAsync(flags, 0, 16, st));
-  if (directed)
-    hipLaunchKernelGGL((k_adjacency<KeyT, true>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr, flags + 1);
-  else
-    hipLaunchKernelGGL((k_adjacency<KeyT, false>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr, flags + 1);
+  {
+    Timer timer(ctx, 3, n);
+    if (directed)
+      hipLaunchKernelGGL((k_adjacency<KeyT, true>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr, flags + 1);
+    else
+      hipLaunchKernelGGL((k_adjacency<KeyT, false>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr, flags + 1);
+  }
   hipLaunchKernelGGL(k_links, dim3(nblk(n)), dim3(256), 0, st, p->nbr, n, p->link, p->info,
                      p->hcls);  // hcls doubles as the start-flag bytes until k_choose
   {
@@ -1114,8 +1117,11 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     const int64_t ns2 = 2 * n;
     const int64_t n_dense = 2 * ((n + kRulerEvery - 1) / kRulerEvery);
     unsigned long long* rinfo = reinterpret_cast<unsigned long long*>(p->c01);  // n_dense * 8 <= 8n
-    hipLaunchKernelGGL(k_ruler_walk, dim3(nblk(n_dense)), dim3(256), 0, st, p->link, ns2, n_dense, rinfo,
-                       p->info);
+    {
+      Timer timer(ctx, 4, n);
+      hipLaunchKernelGGL(k_ruler_walk, dim3(nblk(n_dense)), dim3(256), 0, st, p->link, ns2, n_dense, rinfo,
+                         p->info);
+    }
     hipLaunchKernelGGL(k_ruler_heads, dim3(nblk(n)), dim3(256), 0, st, p->link, p->hcls, n, p->info,
                        reinterpret_cast<unsigned long long*>(p->c23));  // c23: chain_info until k_choose is done
     int max_rounds = 2;
@@ -1273,8 +1279,11 @@ int encode_write_t(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens) {
     KSH_TRY(pool_alloc(ctx, need, &tmp));
     bytes = static_cast<uint8_t*>(tmp);
   }
-  hipLaunchKernelGGL((k_emit<KeyT>), dim3(nblk(n)), dim3(256), 0, st, set, p->head, p->pos, p->ori,
-                     reinterpret_cast<const UnitigPlace*>(p->c01), bytes);
+  {
+    Timer timer(ctx, 5, n);
+    hipLaunchKernelGGL((k_emit<KeyT>), dim3(nblk(n)), dim3(256), 0, st, set, p->head, p->pos, p->ori,
+                       reinterpret_cast<const UnitigPlace*>(p->c01), bytes);
+  }
   const int64_t n_words = (p->n_bases + 31) / 32;
   hipLaunchKernelGGL(k_pack, dim3(nblk(n_words)), dim3(256), 0, st, bytes, p->n_bases, n_words,
                      d_words);

@@ -34,7 +34,7 @@ int fail(int code, const char* fmt, ...);
     if (rc__ != KSH_OK) return rc__; \
   } while (0)
 
-constexpr int kNumTimers = 4;
+constexpr int kNumTimers = 8;
 
 }  // namespace ksh
 
@@ -100,7 +100,8 @@ struct ksh_ctx {
   // pair from a pool; ksh_ctx_timing_read sums them after a stream sync.
   bool timing = false;
   int timing_stride = 1;                                 // every n-th launch of a kind is timed
-  int64_t timing_seen[ksh::kNumTimers] = {0, 0, 0, 0};   // launches of each kind since the reset
+  int64_t timing_seen[ksh::kNumTimers] = {};    // launches of each kind since the reset
+  int64_t timing_units[ksh::kNumTimers] = {};   // units (keys / k-mers) of the timed launches of each kind
   std::vector<hipEvent_t> ev_pool;                       // all events ever created
   size_t ev_next = 0;                                    // next unused event in ev_pool
   std::vector<std::pair<size_t, size_t>> ev_spans[ksh::kNumTimers];  // (start, stop) indices
@@ -131,9 +132,13 @@ struct Timer {
   int kind;
   size_t i0 = 0;
   bool on = false;
-  Timer(ksh_ctx* c, int k) : ctx(c), kind(k) {
+  // units: what the launch processes (k-mers, keys), summed over the timed launches of the kind
+  Timer(ksh_ctx* c, int k, int64_t units = 0) : ctx(c), kind(k) {
     on = ctx->timing && (ctx->timing_seen[kind]++ % ctx->timing_stride) == 0;
-    if (on) (void)hipEventRecord(timer_event(ctx, &i0), ctx->stream);
+    if (on) {
+      ctx->timing_units[kind] += units;
+      (void)hipEventRecord(timer_event(ctx, &i0), ctx->stream);
+    }
   }
   ~Timer() {
     if (on) {

@@ -92,6 +92,7 @@ def lib():
         "ksh_ctx_enable_timing": (C.c_int, [vp, C.c_int]),
         "ksh_ctx_timing_reset": (C.c_int, [vp]),
         "ksh_ctx_timing_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(i64)]),
+        "ksh_ctx_timing_units": (C.c_int, [vp, C.c_int, C.POINTER(i64)]),
         "ksh_set_hash": (C.c_int, [vp, GP, SP, C.POINTER(C.c_uint64)]),
         "ksh_pair_plan": (C.c_int, [vp, GP, SP, SP, vp, vp, vp, C.POINTER(i64)]),
         "ksh_pair_write": (C.c_int, [vp, GP, SP, SP, vp, vp, vp]),
@@ -348,6 +349,12 @@ class Context:
         ms, n = C.c_float(), C.c_int64()
         check(lib().ksh_ctx_timing_read(self.h, kind, C.byref(ms), C.byref(n)))
         return ms.value, n.value
+
+    def timing_units(self, kind):
+        """k-mers (keys) covered by the timed launches of a kind since the last reset."""
+        n = C.c_int64()
+        check(lib().ksh_ctx_timing_units(self.h, kind, C.byref(n)))
+        return n.value
 
     # KmerSet::Hash / Size -------------------------------------------------------
     def set_hash(self, s):

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Round-2 evidence for the contract bench (the whole KmerSetSet constructor on 64 x 1e8, k = 23):
+#   1. the bench line                                    -> gpurun_out/r02/$TAG_bench.json
+#   2. the same command under rocprofv3 --kernel-trace --stats (one warm-up + one timed build)
+#   3. FETCH_SIZE and WRITE_SIZE passes (separate runs, --kernel-trace only) on the 16 x 1e8 loop,
+#      reduced per kernel by tools/pmc_kernel.py
+# usage: tools/collect_r02.sh TAG [bench args...]
+set -e -o pipefail
+TAG=${1:-r02}; shift || true
+R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+O=$R/gpurun_out/r02
+mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+python3 $R/bench.py "$@" > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
+cut -c1-600 $O/${TAG}_bench.json; echo
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o stats -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-verify --no-pair-merge > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_rocprof_stats.err
+echo stats done
+rocprofv3 --kernel-trace --output-format csv --pmc FETCH_SIZE -d $O/${TAG}_pmc_fetch -o fetch -- python3 $R/bench.py --sets 16 --steps 1 --warmup 0 --no-cpu-baseline --no-verify --no-pair-merge > $O/${TAG}_pmc_fetch.json 2> $O/${TAG}_pmc_fetch.err
+echo fetch done
+rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/${TAG}_pmc_write -o write -- python3 $R/bench.py --sets 16 --steps 1 --warmup 0 --no-cpu-baseline --no-verify --no-pair-merge > $O/${TAG}_pmc_write.json 2> $O/${TAG}_pmc_write.err
+echo write done
+F=$(find $O/${TAG}_pmc_fetch -name "*counter_collection.csv" | head -1)
+W=$(find $O/${TAG}_pmc_write -name "*counter_collection.csv" | head -1)
+for K in k_adjacency k_ruler_walk k_links k_emit k_choose; do
+  python3 $R/tools/pmc_kernel.py $F $W $K $O/${TAG}_pmc_$K.json
+done
+# keep the merged-back payload small: the per-dispatch CSVs are tens of MB
+S=$(find $O/${TAG}_stats -name "*kernel_stats.csv" | head -1)
+cp $S $O/${TAG}_kernel_stats.csv
+rm -rf $O/${TAG}_stats $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write
+ls -la $O

@@ -34,6 +34,8 @@
 #include "ksh_kmer.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <string>
 
 namespace ksh {
 
@@ -142,6 +144,567 @@ __global__ __launch_bounds__(256) void k_adjacency(DevSet<KeyT> set, uint32_t* _
   nbr[2 * t + 1] = cnt[1] == 0 ? kNone : (cnt[1] == 1 ? single[1] : kMulti);
 }
 
+
+// ---------------------------------------------------------------------------------- E1b
+// The neighbour probe of a canonical set, LDS-staged.  Of the 8 candidates of a k-mer x, the
+// forward ones (Next(x, .), Prev(x, .)) sit at addresses that ascend with x and are probed in
+// place (k_adj_fwd).  The other half goes through rx = rc(x) and lands anywhere in the set:
+// 3 cache-missing probes (6 dependent reads) per k-mer in k_adjacency, 64-byte lines fetched
+// for 4-byte answers.  Here those probes are made local instead:
+//   * every edge through a reverse complement is seen from both of its ends (x finds y iff y
+//     finds x, on the same side of both), so a k-mer does not need its OWN probes answered: it
+//     is enough that every probe leaves its mark at the TARGET, which sits in a sorted range
+//     that can be staged in LDS and written back coalesced;
+//   * the targets of x are fixed by rx: Next(rx, .) lies in bucket G = bits [2K-3, 2K-2-N] of
+//     rx, and the four Prev(rx, c) in the 16 sub-ranges of the set with the (N + 4)-bit
+//     prefixes [c][top base of rx][G].  So the k-mers are first dealt into 2^N groups by G
+//     (k_rc_hist / k_rc_scatter: LDS histograms, one scattered record per k-mer, the same shape
+//     as the SPSS decode's bucket scatter), and one workgroup per group (k_adj_rc) stages bucket
+//     G (then the 16 sub-ranges) with a slice index over it, lets the group's records look
+//     their targets up in LDS, marks the hits with compare-and-swap (none -> the single
+//     neighbour -> many) and stores the marks of the whole range: rc0[i] / rc1[i] = what
+//     reaches side 0 / side 1 of k-mer i through a reverse complement.  Ranges larger than the
+//     LDS window are staged in several batches.
+// record of x: key = [top base of rx][low 2K-2-N bits of rx] (2K - N bits, a KeyT), t = index of x.
+// G only depends on the low N + 2 bits of x (whole bases), i.e. on the key alone when the key has
+// that many bits: the histogram pass streams the keys without knowing their buckets.
+template <typename KeyT>
+struct __attribute__((aligned(8))) RcRecord {
+  KeyT key;
+  uint32_t t;
+};
+
+template <typename KeyT>
+__global__ __launch_bounds__(1024) void k_rc_hist(const KeyT* __restrict__ keys, int64_t n, int k, int key_bits,
+                                                   int nbits, int64_t per_row,
+                                                   uint32_t* __restrict__ hist_matrix) {
+  extern __shared__ uint32_t lds_hist[];
+  const int nb = 1 << nbits;
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) lds_hist[b] = 0u;
+  __syncthreads();
+  const int64_t t_begin = int64_t(blockIdx.x) * per_row;
+  const int64_t t_end = min(t_begin + per_row, n);
+  const int low_bits = key_bits - 2;
+  for (int64_t t = t_begin + threadIdx.x; t < t_end; t += blockDim.x) {
+    const uint64_t rx = revcomp(uint64_t(keys[t]), k);  // its top N + 2 bits are those of rc(x)
+    atomicAdd(&lds_hist[uint32_t(rx >> low_bits) & uint32_t(nb - 1)], 1u);
+  }
+  __syncthreads();
+  uint32_t* my_row = hist_matrix + int64_t(blockIdx.x) * nb;
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) my_row[b] = lds_hist[b];
+}
+
+// One thread per group: exclusive running sum down the workgroups' rows; totals[G] = column sum.
+__global__ __launch_bounds__(256) void k_rc_columns(uint32_t* __restrict__ hist_matrix, int64_t n_rows, int nb,
+                                                     int64_t* __restrict__ totals) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  uint32_t run = 0;
+  for (int64_t g = 0; g < n_rows; g++) {
+    uint32_t* cell = hist_matrix + g * nb + b;
+    const uint32_t c = *cell;
+    *cell = run;
+    run += c;
+  }
+  totals[b] = run;
+}
+
+// hist_matrix holds each row's exclusive base inside a group, goff the groups' starts.
+// The records of a 10^8-k-mer set are 800 MB written at random; scattered writes are absorbed by
+// the Infinity Cache only while their destination fits it, so the scatter runs in 2^round_bits
+// rounds, round r writing the groups whose top round_bits bits are r (a contiguous share of the
+// record array) and streaming the keys once more for it.
+template <typename KeyT>
+__global__ __launch_bounds__(1024) void k_rc_scatter(DevSet<KeyT> set, int nbits, int round_bits, int round,
+                                                      int64_t per_row,
+                                                      const uint32_t* __restrict__ hist_matrix,
+                                                      const int64_t* __restrict__ goff,
+                                                      RcRecord<KeyT>* __restrict__ rec) {
+  extern __shared__ uint32_t lds_hist[];  // all of the 64 KB a workgroup may have at N = 14: no static LDS here
+  const int nb = 1 << nbits;
+  const uint32_t* my_row = hist_matrix + int64_t(blockIdx.x) * nb;
+  for (int b = threadIdx.x; b < nb; b += blockDim.x) lds_hist[b] = uint32_t(goff[b]) + my_row[b];
+  const int64_t t_begin = int64_t(blockIdx.x) * per_row;
+  const int64_t t_end = min(t_begin + per_row, set.n);
+  __syncthreads();
+  if (t_begin >= t_end) return;
+  // the buckets this row's k-mers lie in (uniform addresses: every thread searches for itself)
+  const int64_t b_first = set.bucket_of(t_begin), b_last = set.bucket_of(t_end - 1);
+  const int k = set.k, low_bits = set.key_bits - 2;
+  const uint64_t low_mask = (uint64_t(1) << low_bits) - 1;
+  for (int64_t t = t_begin + threadIdx.x; t < t_end; t += blockDim.x) {
+    const uint64_t key = uint64_t(set.keys[t]);
+    // the group follows from the key alone (k_rc_hist): keys of other rounds stop here
+    const uint32_t grp = uint32_t(revcomp(key, k) >> low_bits) & uint32_t(nb - 1);
+    if (int(grp >> (nbits - round_bits)) != round) continue;
+    int64_t lo = b_first, hi = b_last;  // largest b in the row's span with off[b] <= t
+    while (lo < hi) {
+      const int64_t mid = (lo + hi + 1) >> 1;
+      if (set.off[mid] <= t) lo = mid; else hi = mid - 1;
+    }
+    const uint64_t rx = revcomp((uint64_t(lo) << set.key_bits) | key, k);
+    const uint32_t dst = atomicAdd(&lds_hist[grp], 1u);
+    RcRecord<KeyT> r;
+    r.key = KeyT(((rx >> (2 * k - 2)) << low_bits) | (rx & low_mask));
+    r.t = uint32_t(t);
+    rec[dst] = r;
+  }
+}
+
+// First index of the set whose k-mer is >= value (value may be 4^K: the set's end).
+template <typename KeyT>
+__device__ int64_t lower_bound_kmer(const DevSet<KeyT>& set, uint64_t value) {
+  const int64_t b = int64_t(value >> set.key_bits);
+  if (b >= set.n_buckets) return set.n;
+  const KeyT key = KeyT(value & set.key_mask());
+  int64_t lo = set.off[b], hi = set.off[b + 1];
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (set.keys[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+__device__ __forceinline__ void mark_hit(uint32_t* slot, uint32_t v) {
+  if (atomicCAS(slot, kNone, v) != kNone) *reinterpret_cast<volatile uint32_t*>(slot) = kMulti;
+}
+
+constexpr int kRcSegs = 16;
+constexpr int kRcThreads = 1024;
+
+// pb[32 * G + 2 * seg + which]: the index range of the set with the (N + 4)-bit prefix
+// [c][tb][G] (seg = 4 c + tb), for every group G: one thread per bound, all searches in flight
+// together instead of a chain of dependent loads at the head of every k_adj_rc workgroup.
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_rc_bounds(DevSet<KeyT> set, int nbits, int64_t* __restrict__ pb) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= (int64_t(2 * kRcSegs) << nbits)) return;
+  const uint64_t grp = uint64_t(i) >> 5, seg = (uint64_t(i) >> 1) & 15, which = uint64_t(i) & 1;
+  const uint64_t prefix = (seg << nbits) | grp;
+  pb[i] = lower_bound_kmer(set, (prefix + which) << (2 * set.k - 4 - nbits));
+}
+static_assert(kRcThreads / 64 == kRcSegs, "pass 1 stages one range per wave");
+struct RcBatch {
+  int64_t seg_lo[kRcSegs], seg_hi[kRcSegs];  // the pass's target ranges (indices of the set)
+  int64_t win_lo[kRcSegs];                   // the part of each that is staged in this batch ...
+  int win_len[kRcSegs];
+  int win_off[kRcSegs];                      // ... where it sits in the LDS window ...
+  int idx_off[kRcSegs];                      // ... and where its slice index sits
+  int idx_shift[kRcSegs];                    // slice of a key = (key & seg_mask) >> idx_shift
+  unsigned long long packed[kRcSegs];        // win_len | win_off << 16 | idx_off << 32 | idx_shift << 48: one read per look-up
+  int used;                                  // keys staged
+  int next_seg;                              // cursor: first range not yet fully staged ...
+  int64_t next_pos;                          // ... and how far it got
+};
+
+// One workgroup per group G.  Pass 0: range = bucket G, a record looks for the members of
+// Next(rx, .) and marks their side 0.  Pass 1: 16 ranges [c][tb][G], a record looks for its
+// canonical Prev(rx, c) in range (c, its tb) and marks side 1.
+// LDS: cap keys | cap marks | cap + 2 * kRcSegs slice bounds (u16).  A range's slice index has
+// the largest power of two <= its length many slices over the key bits the range's keys differ in.
+// A wave's life here is memory round trips, so each is taken once: a thread's records are read
+// into registers up front and serve both passes, the 32 range bounds of pass 1 are searched
+// while bucket G is being staged, every staging loop issues all its loads before the first LDS
+// store, and in pass 1 wave w stages, indexes and stores range w.
+template <typename KeyT>
+__global__ __launch_bounds__(kRcThreads) void k_adj_rc(DevSet<KeyT> set, int nbits,
+                                                        const int64_t* __restrict__ goff,
+                                                        const RcRecord<KeyT>* __restrict__ rec,
+                                                        const int64_t* __restrict__ pb, int cap,
+                                                        uint32_t* __restrict__ rc0, uint32_t* __restrict__ rc1) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  KeyT* skeys = reinterpret_cast<KeyT*>(lds_raw);
+  uint32_t* slots = reinterpret_cast<uint32_t*>(lds_raw + size_t(cap) * sizeof(KeyT));
+  uint16_t* sidx = reinterpret_cast<uint16_t*>(lds_raw + size_t(cap) * (sizeof(KeyT) + 4));
+  __shared__ RcBatch bt;
+  __shared__ int64_t prev_bounds[2 * kRcSegs];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t grp = blockIdx.x;
+  const int k = set.k, low_bits = set.key_bits - 2;
+  const uint64_t low_mask = (uint64_t(1) << low_bits) - 1;
+  const uint64_t kmask = kmer_mask(k);
+  const int64_t r0 = goff[grp], r1 = goff[grp + 1];
+  if (tid < 2 * kRcSegs) prev_bounds[tid] = pb[2 * kRcSegs * grp + tid];
+  for (int pass = 0; pass < 2; pass++) {
+    const int n_seg = pass == 0 ? 1 : kRcSegs;
+    // key bits that vary inside a range: all of them in bucket G, all but the top 4 in [c][tb][G]
+    const int seg_bits = pass == 0 ? set.key_bits : set.key_bits - 4;
+    const uint64_t seg_mask = seg_bits >= 64 ? ~uint64_t(0) : ((uint64_t(1) << seg_bits) - 1);
+    uint32_t* out = pass == 0 ? rc0 : rc1;
+    __syncthreads();
+    if (tid == 0) {
+      if (pass == 0) {
+        bt.seg_lo[0] = set.off[grp];
+        bt.seg_hi[0] = set.off[grp + 1];
+      } else {
+        for (int s2 = 0; s2 < kRcSegs; s2++) {
+          bt.seg_lo[s2] = prev_bounds[2 * s2];
+          bt.seg_hi[s2] = prev_bounds[2 * s2 + 1];
+        }
+      }
+      bt.next_seg = 0;
+      bt.next_pos = bt.seg_lo[0];
+    }
+    while (true) {
+      __syncthreads();
+      if (tid == 0) {
+        int used = 0, iused = 0, seg = bt.next_seg;
+        int64_t pos = bt.next_pos;
+        for (int s2 = 0; s2 < n_seg; s2++) {
+          bt.win_len[s2] = 0;
+          bt.packed[s2] = 0;
+        }
+        while (seg < n_seg) {
+          const int64_t avail = bt.seg_hi[seg] - pos;
+          const int take = int(avail < int64_t(cap - used) ? avail : int64_t(cap - used));
+          bt.win_lo[seg] = pos;
+          bt.win_len[seg] = take;
+          bt.win_off[seg] = used;
+          bt.idx_off[seg] = iused;
+          // slices: the largest power of two <= take, each at least 4 values wide
+          int lg = take >= 2 ? 31 - __builtin_clz(unsigned(take)) : 0;
+          if (lg > seg_bits - 2) lg = seg_bits - 2 > 0 ? seg_bits - 2 : 0;
+          bt.idx_shift[seg] = seg_bits - lg;
+          bt.packed[seg] = (unsigned long long)(take) | ((unsigned long long)(used) << 16) |
+                           ((unsigned long long)(iused) << 32) | ((unsigned long long)(seg_bits - lg) << 48);
+          iused += (1 << lg) + 1;
+          used += take;
+          pos += take;
+          if (pos < bt.seg_hi[seg]) break;  // the window is full
+          seg++;
+          if (seg < n_seg) pos = bt.seg_lo[seg];
+        }
+        bt.used = used;
+        bt.next_seg = seg;
+        bt.next_pos = pos;
+      }
+      __syncthreads();
+      if (bt.used == 0) break;  // every range of the pass has been staged and stored
+      // who stages what: pass 0, the whole workgroup its one range; pass 1, wave w range w
+      const int my_seg = pass == 0 ? 0 : wave;
+      const int my_id = pass == 0 ? tid : lane, my_step = pass == 0 ? kRcThreads : 64;
+      const int64_t my_lo = bt.win_lo[my_seg];
+      const int my_len = bt.win_len[my_seg], my_off = bt.win_off[my_seg];
+      for (int base = 0; base < my_len; base += 4 * my_step) {
+        KeyT v[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = base + u * my_step + my_id;
+          if (i < my_len) v[u] = set.keys[my_lo + i];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int i = base + u * my_step + my_id;
+          if (i < my_len) {
+            skeys[my_off + i] = v[u];
+            slots[my_off + i] = kNone;
+          }
+        }
+      }
+      __syncthreads();
+      // slice index: sidx[idx_off + j] = first position of the window whose slice is >= j
+      if (my_len > 0) {
+        const int ioff = bt.idx_off[my_seg], sh = bt.idx_shift[my_seg];
+        const int n_slices = 1 << (seg_bits - sh);
+        for (int i = my_id; i < my_len; i += my_step) {
+          const int cur = int((uint64_t(skeys[my_off + i]) & seg_mask) >> sh);
+          const int prev = i > 0 ? int((uint64_t(skeys[my_off + i - 1]) & seg_mask) >> sh) : -1;
+          for (int j = prev + 1; j <= cur; j++) sidx[ioff + j] = uint16_t(i);
+          if (i == my_len - 1)
+            for (int j = cur + 1; j <= n_slices; j++) sidx[ioff + j] = uint16_t(my_len);
+        }
+      }
+      __syncthreads();
+      // the record of the next turn is requested before this turn's look-ups
+      RcRecord<KeyT> nxt;
+      nxt.t = kNone;
+      if (r0 + tid < r1) nxt = rec[r0 + tid];
+#pragma unroll 1
+      for (int64_t r = r0 + tid; r < r1; r += kRcThreads) {
+        const RcRecord<KeyT> rr = nxt;
+        if (r + kRcThreads < r1) nxt = rec[r + kRcThreads];
+        const uint64_t low = uint64_t(rr.key) & low_mask;
+        const uint32_t mark = (rr.t << 1) | 1u;
+        if (pass == 0) {
+          const uint64_t gkey = low << 2;
+          const int sl = int(gkey >> bt.idx_shift[0]);
+          for (int i = sidx[sl], end = sidx[sl + 1]; i < end; i++) {
+            const uint64_t d = uint64_t(skeys[i]) - gkey;  // members: gkey .. gkey + 3
+            if (d < 4 && bt.win_lo[0] + i != int64_t(rr.t)) mark_hit(&slots[i], mark);
+          }
+        } else {
+          const uint64_t tb = uint64_t(rr.key) >> low_bits;
+          const uint64_t rx = (tb << (2 * k - 2)) | (uint64_t(grp) << low_bits) | low;
+          const uint64_t x = revcomp(rx, k);
+#pragma unroll
+          for (int c = 0; c < 4; c++) {
+            const unsigned long long pk = bt.packed[4 * c + int(tb)];
+            const int wlen = int(pk & 0xFFFF);
+            const uint64_t z = (uint64_t(c) << (2 * k - 2)) | (rx >> 2);  // Prev(rx, c)
+            const uint64_t rz = ((x << 2) & kmask) | uint64_t(3 - c);     // its reverse complement
+            if (wlen == 0 || rz < z || z == x) continue;  // not staged now; not canonical (cannot be in the set); x itself
+            const KeyT zkey = KeyT(z & set.key_mask());
+            const int off = int((pk >> 16) & 0xFFFF);
+            const uint16_t* ix = sidx + int((pk >> 32) & 0xFFFF) + int((uint64_t(zkey) & seg_mask) >> int(pk >> 48));
+            for (int i = ix[0], end = ix[1]; i < end; i++)
+              if (skeys[off + i] == zkey) mark_hit(&slots[off + i], mark);
+          }
+        }
+      }
+      __syncthreads();
+      for (int i = my_id; i < my_len; i += my_step) out[my_lo + i] = slots[my_off + i];
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------- E1c
+// The forward half, LDS-staged.  A workgroup owns kFwdChunk consecutive k-mers.  Their Next(x, .)
+// are ascending with x (same top base: one contiguous range of the set, about four times as many
+// keys as the chunk has k-mers) and so is each of their Prev(x, c) (a range of about a quarter of
+// the chunk): five ranges, staged with whole-line loads, searched in LDS.  k_fwd_bounds finds the
+// ten range bounds of every chunk beforehand, one thread per chunk boundary (the searches of all
+// chunks in flight together instead of ten dependent round trips at the head of every workgroup),
+// and leaves the chunk's first k-mer beside them: the buckets of the chunk's own k-mers and of
+// its five ranges follow from it, and their offsets are read into LDS together with the keys.
+// A chunk whose k-mers span two top bases, or whose range does not fit the window or spans too
+// many buckets, probes that part in global memory as k_adj_fwd does.
+constexpr int kFwdChunk = 512;
+constexpr int kFwdCapNext = 3072;  // keys: 4 x chunk with half to spare
+constexpr int kFwdCapPrev = 256;   // keys per c: chunk / 4 with as much to spare
+static_assert(kFwdCapPrev <= kFwdChunk && kFwdCapNext % kFwdChunk == 0, "staging shape");
+constexpr int kFwdSpan = 8;        // bucket offsets kept per range (and for the chunk itself)
+
+// bounds[kFwdBounds * c + ..] for chunk boundary t = c * kFwdChunk (c = 0 .. n_chunks):
+//   [0]     first index >= Next(x_t, 0)            (start of chunk c's Next range)
+//   [1..4]  first index >= Prev(x_t, cc)           (start of chunk c's Prev ranges)
+//   [5]     first index >  Next(x_{t-1}, 3)        (end of chunk c-1's Next range)
+//   [6..9]  first index >  Prev(x_{t-1}, cc)       (end of chunk c-1's Prev ranges)
+//   [10]    x_t, [11] x_{t-1}: Next(x, .) drops the top base, so the Next range of a chunk is one
+//           range only when its first and last k-mer agree on it
+constexpr int kFwdBounds = 12;
+
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_fwd_bounds(DevSet<KeyT> set, int64_t n_chunks,
+                                                     int64_t* __restrict__ bounds) {
+  const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (c > n_chunks) return;
+  const int k = set.k;
+  const int64_t t = c * kFwdChunk;
+  int64_t* out = bounds + kFwdBounds * c;
+  if (t < set.n) {
+    const uint64_t x = set.kmer(t);
+    out[0] = lower_bound_kmer(set, kmer_next(x, k, 0));
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++) out[1 + cc] = lower_bound_kmer(set, kmer_prev(x, k, cc));
+    out[10] = int64_t(x);
+  }
+  if (t > 0) {
+    const uint64_t y = set.kmer((t < set.n ? t : set.n) - 1);
+    out[5] = lower_bound_kmer(set, kmer_next(y, k, 3) + 1);
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++) out[6 + cc] = lower_bound_kmer(set, kmer_prev(y, k, cc) + 1);
+    out[11] = int64_t(y);
+  }
+}
+
+template <typename KeyT>
+__device__ __forceinline__ int lds_lower_bound(const KeyT* a, int lo, int hi, KeyT key) {
+  while (lo < hi) {
+    const int mid = (lo + hi) >> 1;
+    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(kFwdChunk) void k_adj_fwd_staged(DevSet<KeyT> set, const int64_t* __restrict__ bounds,
+                                                              const uint32_t* __restrict__ rc0,
+                                                              const uint32_t* __restrict__ rc1,
+                                                              uint32_t* __restrict__ nbr,
+                                                              int* __restrict__ self_rc) {
+  __shared__ KeyT s_next[kFwdCapNext];
+  __shared__ KeyT s_prev[4][kFwdCapPrev];
+  __shared__ int64_t s_b[2 * kFwdBounds];     // this boundary's and the next one's records
+  __shared__ int64_t s_boff[6][kFwdSpan + 1];  // bucket offsets: ranges 0..4 from their first bucket on; [5]: the chunk's own
+  const int tid = threadIdx.x;
+  const int64_t chunk = blockIdx.x;
+  const int64_t t = chunk * kFwdChunk + tid;
+  const int k = set.k;
+  if (tid < 2 * kFwdBounds) s_b[tid] = bounds[kFwdBounds * chunk + tid];
+  KeyT my_key = 0;
+  uint2 rc = make_uint2(kNone, kNone);
+  if (t < set.n) {
+    my_key = set.keys[t];
+    rc = make_uint2(rc0[t], rc1[t]);
+  }
+  __syncthreads();
+  const uint64_t x_first = uint64_t(s_b[10]), x_last = uint64_t(s_b[kFwdBounds + 11]);
+  // first bucket of: the five ranges, the chunk itself
+  int64_t fb[6];
+  fb[0] = int64_t(kmer_next(x_first, k, 0) >> set.key_bits);
+#pragma unroll
+  for (int cc = 0; cc < 4; cc++) fb[1 + cc] = int64_t(kmer_prev(x_first, k, cc) >> set.key_bits);
+  fb[5] = int64_t(x_first >> set.key_bits);
+  if (tid < 6 * (kFwdSpan + 1)) {
+    const int r = tid / (kFwdSpan + 1), j = tid % (kFwdSpan + 1);
+    const int64_t b = fb[r] + j;
+    s_boff[r][j] = b <= set.n_buckets ? set.off[b] : set.n;
+  }
+  // usable[r]: range r is staged (a range that wraps around a top base has hi < lo)
+  bool usable[5];
+  int len[5];
+  int64_t lo_of[5];
+#pragma unroll
+  for (int r = 0; r < 5; r++) {
+    lo_of[r] = s_b[r];
+    const int64_t l = s_b[kFwdBounds + 5 + r] - lo_of[r];
+    usable[r] = l >= 0 && l <= (r == 0 ? kFwdCapNext : kFwdCapPrev);
+    len[r] = usable[r] ? int(l) : 0;
+  }
+  if ((x_first >> (2 * k - 2)) != (x_last >> (2 * k - 2))) {
+    usable[0] = false;
+    len[0] = 0;
+  }
+  {
+    // every load of the staging before the first LDS store: one round trip, not ten
+    constexpr int kPer = kFwdCapNext / kFwdChunk;
+    KeyT vn[kPer], vp[4];
+#pragma unroll
+    for (int u = 0; u < kPer; u++)
+      if (tid + u * kFwdChunk < len[0]) vn[u] = set.keys[lo_of[0] + tid + u * kFwdChunk];
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++)
+      if (tid < len[1 + cc]) vp[cc] = set.keys[lo_of[1 + cc] + tid];
+#pragma unroll
+    for (int u = 0; u < kPer; u++)
+      if (tid + u * kFwdChunk < len[0]) s_next[tid + u * kFwdChunk] = vn[u];
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++)
+      if (tid < len[1 + cc]) s_prev[cc][tid] = vp[cc];
+  }
+  __syncthreads();
+  if (t >= set.n) return;
+  // my bucket: the chunk's first bucket, or one of the next few
+  int64_t my_b = fb[5];
+  {
+    int j = 0;
+    while (j < kFwdSpan && s_boff[5][j + 1] <= t) j++;
+    my_b += j;
+    if (j == kFwdSpan)
+      while (set.off[my_b + 1] <= t) my_b++;
+  }
+  const uint64_t x = (uint64_t(my_b) << set.key_bits) | uint64_t(my_key);
+  if (revcomp(x, k) == x) *self_rc = 1;
+  int cnt[2] = {0, 0};
+  uint32_t single[2] = {kNone, kNone};
+  // [blo, bhi) of bucket b, from the offsets kept for range r; false when b is beyond them
+  const auto bucket_range = [&](int r, int64_t b, int64_t* blo, int64_t* bhi) {
+    const int64_t j = b - fb[r];
+    if (j < 0 || j >= kFwdSpan) return false;
+    *blo = s_boff[r][j];
+    *bhi = s_boff[r][j + 1];
+    return true;
+  };
+  // side 1: Next(x, .), neighbour as is
+  {
+    const uint64_t g0 = kmer_next(x, k, 0);
+    int64_t blo, bhi;
+    if (usable[0] && bucket_range(0, int64_t(g0 >> set.key_bits), &blo, &bhi)) {
+      const KeyT gkey = KeyT(g0 & set.key_mask());
+      const int64_t hi0 = lo_of[0] + len[0];
+      const int lo = int((blo > lo_of[0] ? blo : lo_of[0]) - lo_of[0]);
+      const int hi = int((bhi < hi0 ? bhi : hi0) - lo_of[0]);
+      if (lo < hi) {
+        int i = lds_lower_bound(s_next, lo, hi, gkey);
+        for (; i < hi && uint64_t(s_next[i]) - uint64_t(gkey) < 4; i++) {
+          const int64_t idx = lo_of[0] + i;
+          if (idx == t) continue;
+          cnt[1]++;
+          single[1] = uint32_t(idx) << 1;
+        }
+      }
+    } else {
+      set.for_group4(g0, [&](int64_t idx) {
+        if (idx == t) return;
+        cnt[1]++;
+        single[1] = uint32_t(idx) << 1;
+      });
+    }
+  }
+  // side 0: Prev(x, c), neighbour as is
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const uint64_t z = kmer_prev(x, k, c);
+    if (revcomp(z, k) < z) continue;
+    if (z == x) continue;
+    int64_t idx = -1;
+    int64_t blo, bhi;
+    if (usable[1 + c] && bucket_range(1 + c, int64_t(z >> set.key_bits), &blo, &bhi)) {
+      const KeyT zkey = KeyT(z & set.key_mask());
+      const int64_t hi0 = lo_of[1 + c] + len[1 + c];
+      const int lo = int((blo > lo_of[1 + c] ? blo : lo_of[1 + c]) - lo_of[1 + c]);
+      const int hi = int((bhi < hi0 ? bhi : hi0) - lo_of[1 + c]);
+      if (lo < hi) {
+        const int i = lds_lower_bound(s_prev[c], lo, hi, zkey);
+        if (i < hi && s_prev[c][i] == zkey) idx = lo_of[1 + c] + i;
+      }
+    } else {
+      idx = set.find(z);
+    }
+    if (idx < 0) continue;
+    cnt[0]++;
+    single[0] = uint32_t(idx) << 1;
+  }
+  const uint32_t r[2] = {rc.x, rc.y};
+  uint32_t out[2];
+#pragma unroll
+  for (int side = 0; side < 2; side++) {
+    const int total = cnt[side] + (r[side] == kNone ? 0 : (r[side] == kMulti ? 2 : 1));
+    out[side] = total == 0 ? kNone : (total > 1 ? kMulti : (cnt[side] == 1 ? single[side] : r[side]));
+  }
+  reinterpret_cast<uint2*>(nbr)[t] = make_uint2(out[0], out[1]);
+}
+
+// The forward half of the probe, in place, and the verdict per side: rc0 / rc1 are what k_adj_rc
+// found to reach the k-mer's side 0 / side 1 through a reverse complement.
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_adj_fwd(DevSet<KeyT> set, const uint32_t* __restrict__ rc0,
+                                                  const uint32_t* __restrict__ rc1,
+                                                  uint32_t* __restrict__ nbr, int* __restrict__ self_rc) {
+  __shared__ int64_t s_bucket[2];
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t x = set.kmer_in_block(t, s_bucket);
+  if (t >= set.n) return;
+  const int k = set.k;
+  if (revcomp(x, k) == x) *self_rc = 1;
+  int cnt[2] = {0, 0};
+  uint32_t single[2] = {kNone, kNone};
+  // side 1: Next(x, .), neighbour as is
+  set.for_group4(kmer_next(x, k, 0), [&](int64_t idx) {
+    if (idx == t) return;
+    cnt[1]++;
+    single[1] = uint32_t(idx) << 1;
+  });
+  // side 0: Prev(x, c), neighbour as is
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const uint64_t z = kmer_prev(x, k, c);
+    if (revcomp(z, k) < z) continue;
+    if (z == x) continue;
+    const int64_t idx = set.find(z);
+    if (idx < 0) continue;
+    cnt[0]++;
+    single[0] = uint32_t(idx) << 1;
+  }
+  const uint32_t r[2] = {rc0[t], rc1[t]};
+  uint32_t out[2];
+#pragma unroll
+  for (int side = 0; side < 2; side++) {
+    const int total = cnt[side] + (r[side] == kNone ? 0 : (r[side] == kMulti ? 2 : 1));
+    out[side] = total == 0 ? kNone : (total > 1 ? kMulti : (cnt[side] == 1 ? single[side] : r[side]));
+  }
+  reinterpret_cast<uint2*>(nbr)[t] = make_uint2(out[0], out[1]);
+}
 
 // One thread per k-mer: both links; the chain-rank records of its two states start unset.
 __global__ __launch_bounds__(256) void k_links(const uint32_t* __restrict__ nbr, int64_t n,
@@ -1029,6 +1592,19 @@ struct EncPlan {
 };
 
 inline size_t al(size_t x) { return (x + 255) & ~size_t(255); }
+
+constexpr int64_t kRcRowsMax = 512;          // workgroups (histogram rows) of the rc partition
+constexpr int64_t kRcWindowBytes = 60 << 10;  // LDS window of k_adj_rc (keys + marks + slice index)
+
+// KSH_ADJACENCY=probe selects the round-1 kernel (every probe a search in global memory) for
+// A/B measurements; anything else: the LDS-staged form.
+inline bool staged_adjacency() {
+  static const bool on = [] {
+    const char* e = getenv("KSH_ADJACENCY");
+    return !(e && std::string(e) == "probe");
+  }();
+  return on;
+}
 inline unsigned nblk(int64_t n) { return unsigned(std::max<int64_t>(1, (n + 255) / 256)); }
 
 template <typename T>
@@ -1074,7 +1650,8 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   const size_t bytes = 2 * al(size_t(2 * n) * 4) + al(size_t(2 * n) * 8) + 5 * al(size_t(n) * 4) +
                        2 * al(size_t(n)) + 2 * al(size_t(n) * 8) + al(fine_entries * 4) + 4096;
   KSH_TRY(slot_reserve(ctx, kSlotEncode, bytes));
-  KSH_TRY(arena_reserve(ctx, size_t(n / 256 + 4096) * 8 * 2 + (1u << 16)));
+  KSH_TRY(arena_reserve(ctx, size_t(n / 256 + 4096) * 8 * 2 + (1u << 16) +
+                                 (nb <= (1 << 14) ? size_t(kRcRowsMax) * nb * 4 + size_t(nb + 1) * 16 + size_t(nb) * 256 + 8192 : 0)));
   arena_reset(ctx);
   char* at = ctx->slot[kSlotEncode];
   p->nbr = carve<uint32_t>(at, size_t(2 * n));
@@ -1105,10 +1682,66 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   KSH_HIP(hipMemsetAsync(flags, 0, 16, st));
   {
     Timer timer(ctx, 3, n);
-    if (directed)
+    const int nbits = g->n_bucket_bits;
+    if (directed) {
       hipLaunchKernelGGL((k_adjacency<KeyT, true>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr, flags + 1);
-    else
+    } else if (staged_adjacency() && nbits <= 14 && 2 * g->k >= nbits + 4 &&
+               key_bits(g) >= nbits + 2 + (nbits & 1)) {
+      // E1b: partition by rc-prefix, LDS-staged probe of the reverse-complement half, forward half
+      // in place.  The records live in the (still unused) chain-rank records, rc0 / rc1 in the link
+      // array, both written only by k_links afterwards.
+      const int64_t rows = std::max<int64_t>(1, std::min<int64_t>(kRcRowsMax, (n + 65535) / 65536));
+      const int64_t per_row = ((n + rows - 1) / rows + 1023) / 1024 * 1024;
+      uint32_t* hist = static_cast<uint32_t*>(arena_alloc(ctx, size_t(rows) * nb * 4));
+      int64_t* totals = static_cast<int64_t*>(arena_alloc(ctx, size_t(nb + 1) * 8));
+      int64_t* goff = static_cast<int64_t*>(arena_alloc(ctx, size_t(nb + 1) * 8));
+      if (!hist || !totals || !goff) return fail(KSH_INTERNAL, "scratch arena too small");
+      RcRecord<KeyT>* rec = reinterpret_cast<RcRecord<KeyT>*>(p->info);
+      uint32_t* rc0 = p->link;
+      uint32_t* rc1 = p->link + n;
+      const size_t hist_lds = size_t(nb) * 4;
+      hipLaunchKernelGGL((k_rc_hist<KeyT>), dim3(unsigned(rows)), dim3(1024), hist_lds, st,
+                         static_cast<const KeyT*>(sv->d_keys), n, g->k, key_bits(g), nbits, per_row, hist);
+      hipLaunchKernelGGL(k_rc_columns, dim3(unsigned((nb + 255) / 256)), dim3(256), 0, st, hist, rows, int(nb),
+                         totals);
+      KSH_TRY(scan_exclusive_i64(ctx, totals, goff, nb, goff + nb));
+      {
+        // one round unless KSH_RC_ROUNDS says otherwise (measured: more rounds only add passes over the keys)
+        int round_bits = 0;
+        if (const char* e = getenv("KSH_RC_ROUNDS")) {
+          round_bits = 0;
+          while ((1 << round_bits) < atoi(e) && round_bits < nbits) round_bits++;
+        }
+        for (int round = 0; round < (1 << round_bits); round++)
+          hipLaunchKernelGGL((k_rc_scatter<KeyT>), dim3(unsigned(rows)), dim3(1024), hist_lds, st, set, nbits,
+                             round_bits, round, per_row, hist, goff, rec);
+      }
+      // LDS window: a bucket with a quarter to spare (larger ranges are staged in batches)
+      const int cap = int(std::min<int64_t>((kRcWindowBytes - 4 * kRcSegs) / int64_t(sizeof(KeyT) + 6),
+                                            std::max<int64_t>(1024, (n / nb) * 5 / 4 + 256)));
+      const size_t rc_lds = size_t(cap) * (sizeof(KeyT) + 4) + size_t(cap + 2 * kRcSegs) * 2;
+      int64_t* pb = static_cast<int64_t*>(arena_alloc(ctx, size_t(nb) * 2 * kRcSegs * 8));
+      if (!pb) return fail(KSH_INTERNAL, "scratch arena too small");
+      hipLaunchKernelGGL((k_rc_bounds<KeyT>), dim3(nblk(nb * 2 * kRcSegs)), dim3(256), 0, st, set, nbits, pb);
+      hipLaunchKernelGGL((k_adj_rc<KeyT>), dim3(unsigned(nb)), dim3(kRcThreads), rc_lds, st, set, nbits, goff,
+                         rec, pb, cap, rc0, rc1);
+      static const bool fwd_probe = [] {
+        const char* e = getenv("KSH_FWD");
+        return e && std::string(e) == "probe";
+      }();
+      if (fwd_probe) {
+        hipLaunchKernelGGL((k_adj_fwd<KeyT>), dim3(nblk(n)), dim3(256), 0, st, set, rc0, rc1, p->nbr, flags + 1);
+      } else {
+        // the records are dead by now: the chunk bounds take their place
+        const int64_t n_chunks = (n + kFwdChunk - 1) / kFwdChunk;
+        int64_t* bounds = reinterpret_cast<int64_t*>(p->info);  // kFwdBounds * 8 bytes per 512 k-mers
+        hipLaunchKernelGGL((k_fwd_bounds<KeyT>), dim3(nblk(n_chunks + 1)), dim3(256), 0, st, set, n_chunks, bounds);
+        hipLaunchKernelGGL((k_adj_fwd_staged<KeyT>), dim3(unsigned(n_chunks)), dim3(kFwdChunk), 0, st, set, bounds,
+                           rc0, rc1, p->nbr, flags + 1);
+      }
+    } else {
       hipLaunchKernelGGL((k_adjacency<KeyT, false>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr, flags + 1);
+    }
   }
   hipLaunchKernelGGL(k_links, dim3(nblk(n)), dim3(256), 0, st, p->nbr, n, p->link, p->info,
                      p->hcls);  // hcls doubles as the start-flag bytes until k_choose

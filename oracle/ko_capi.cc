@@ -17,6 +17,7 @@
 #include "ko_kmer_counter.h"
 #include "ko_kmer_set.h"
 #include "ko_kmer_set_set.h"
+#include "ko_mt.h"
 #include "ko_spss.h"
 
 namespace {
@@ -74,6 +75,17 @@ SetH* wrap_set(ko::KmerSet<std::uint64_t>&& s) {
 #define KO_SET_CALL(h, expr) ((h)->wide() ? (h)->s64->expr : (h)->s32->expr)
 
 }  // namespace
+
+// The reference's n_workers > 1 branches (ko_mt.h), canonical sets: for bench.py's cpu_baseline.
+template <typename KeyT>
+static ko::KmerSetSet<KeyT>* build_mt(std::vector<ko::Compact> cs, const std::vector<int>& ids,
+                                      int max_iterations, int n_workers) {
+  ko::mt::KmerSetSetMT<KeyT> m(std::move(cs), ids, max_iterations, n_workers);
+  auto* k = new ko::KmerSetSet<KeyT>(std::move(m.children), std::move(m.compacts));
+  k->adopt_trace(std::move(m.iterations), std::move(m.checkpoints), m.n_processed, m.initial_total_size,
+                 m.final_total_size);
+  return k;
+}
 
 extern "C" {
 
@@ -379,6 +391,20 @@ void* ko_kss_build(void** compacts, int n, const int* bucket_ids, int n_ids, int
     h->k64.reset(new ko::KmerSetSet<std::uint64_t>(std::move(cs), ids, h->canon, max_iterations));
   else
     h->k32.reset(new ko::KmerSetSet<std::uint32_t>(std::move(cs), ids, h->canon, max_iterations));
+  return h;
+}
+void* ko_kss_build_mt(void** compacts, int n, const int* bucket_ids, int n_ids, int max_iterations,
+                      int n_workers) {
+  std::vector<ko::Compact> cs;
+  for (int i = 0; i < n; i++) cs.push_back(static_cast<CompactH*>(compacts[i])->c);
+  std::vector<int> ids(bucket_ids, bucket_ids + n_ids);
+  KssH* h = new KssH;
+  h->g = cs.empty() ? ko::Geom{} : cs[0].geom();
+  h->canon = true;
+  if (h->wide())
+    h->k64.reset(build_mt<std::uint64_t>(std::move(cs), ids, max_iterations, n_workers));
+  else
+    h->k32.reset(build_mt<std::uint32_t>(std::move(cs), ids, max_iterations, n_workers));
   return h;
 }
 void ko_kss_free(void* h) { delete static_cast<KssH*>(h); }

@@ -250,6 +250,10 @@ class KmerSet {
 
   std::size_t bucket_size(std::int64_t b) const { return buckets_[b].size(); }
 
+  // Bucket access for the multi-worker branches (ko_mt.h: ForEachBucket, kmer_set.h:260-282).
+  const FlatSet<KeyT>& bucket(std::int64_t b) const { return buckets_[b]; }
+  FlatSet<KeyT>& bucket(std::int64_t b) { return buckets_[b]; }
+
  private:
   Geom g_;
   std::vector<FlatSet<KeyT>> buckets_;

@@ -220,6 +220,16 @@ class KmerSetSet {
   KmerSetSet(AdjacencyList children, std::vector<Compact> compacts)
       : children_(std::move(children)), compacts_(std::move(compacts)) {}
 
+  // Result of the multi-worker constructor (ko_mt.h) behind the same accessors.
+  void adopt_trace(std::vector<IterationTrace> iterations, std::vector<CheckpointTrace> checkpoints,
+                   std::int64_t n_processed, std::int64_t initial_total_size, std::int64_t final_total_size) {
+    iterations_ = std::move(iterations);
+    checkpoints_ = std::move(checkpoints);
+    n_processed_ = n_processed;
+    initial_total_size_ = initial_total_size;
+    final_total_size_ = final_total_size;
+  }
+
   int size() const { return static_cast<int>(compacts_.size()); }
 
   KmerSet<KeyT> get(int i, bool canon) const {

@@ -113,6 +113,7 @@ def lib():
         "ko_counter_from_reads": (None, [vp, C.c_char_p, i64, i]),
         "ko_counter_to_set": (vp, [vp, i, i, C.POINTER(i64)]),
         "ko_kss_build": (vp, [C.POINTER(vp), i, i32p, i, i, i]),
+        "ko_kss_build_mt": (vp, [C.POINTER(vp), i, i32p, i, i, i]),
         "ko_kss_free": (None, [vp]),
         "ko_kss_size": (i, [vp]),
         "ko_kss_get": (vp, [vp, i]),
@@ -369,7 +370,10 @@ class Compact:
 
 class KmerSetSet:
     def __init__(self, compacts=None, bucket_ids=None, canonical=True, max_iterations=-1,
-                 handle=None, geom=None):
+                 handle=None, geom=None, n_workers=1):
+        """n_workers > 1: the reference's multi-worker branches (oracle/ko_mt.h; canonical sets only).
+        Node sets, merge sequence and N_proc equal the n_workers == 1 build; the SPSS strings may
+        not (thread interleaving decides the greedy matching in the reference as well)."""
         L = lib()
         if handle is not None:
             self.h = handle
@@ -378,7 +382,11 @@ class KmerSetSet:
         self.k, self.n, self.key_bytes = compacts[0].k, compacts[0].n, compacts[0].key_bytes
         arr = (C.c_void_p * len(compacts))(*[c.h for c in compacts])
         ids = np.ascontiguousarray(bucket_ids, dtype=np.int32)
-        self.h = L.ko_kss_build(arr, len(compacts), ids, ids.size, int(canonical), max_iterations)
+        if n_workers > 1:
+            assert canonical, "the multi-worker port covers canonical sets"
+            self.h = L.ko_kss_build_mt(arr, len(compacts), ids, ids.size, max_iterations, n_workers)
+        else:
+            self.h = L.ko_kss_build(arr, len(compacts), ids, ids.size, int(canonical), max_iterations)
 
     @classmethod
     def load(cls, directory, ext, k, n, key_bytes, canonical=True):

@@ -21,7 +21,13 @@ rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/${TAG}_pmc_w
 echo write done
 F=$(find $O/${TAG}_pmc_fetch -name "*counter_collection.csv" | head -1)
 W=$(find $O/${TAG}_pmc_write -name "*counter_collection.csv" | head -1)
-for K in k_adjacency k_ruler_walk k_links k_emit k_choose; do
+STAGE=k_rc_hist,k_rc_columns,k_rc_scatter,k_rc_bounds,k_adj_rc,k_fwd_bounds,k_adj_fwd_staged
+if grep -q "k_adj_fwd_staged" $F; then
+  python3 $R/tools/pmc_kernel.py $F $W $STAGE $O/${TAG}_pmc_adjacency_stage.json --units-from k_adj_fwd_staged
+else
+  python3 $R/tools/pmc_kernel.py $F $W k_adjacency $O/${TAG}_pmc_adjacency_stage.json
+fi
+for K in k_ruler_walk k_links k_emit k_choose; do
   python3 $R/tools/pmc_kernel.py $F $W $K $O/${TAG}_pmc_$K.json
 done
 # keep the merged-back payload small: the per-dispatch CSVs are tens of MB

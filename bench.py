@@ -59,6 +59,30 @@ def cpu_model():
     return "unknown"
 
 
+def host_cores():
+    """Cores this process may use: the CPU affinity mask, cut down to the cgroup's CPU quota when there is
+    one (a GPU box hands a job a share of its host, not the whole machine)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    n = min(n, max(1, int(int(txt[0]) / int(txt[1]) + 0.5)))
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+                    n = min(n, max(1, int(q / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return n
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,13 +143,15 @@ def main():
     ids = synth.sample_bucket_ids(nbits, seed=args.seed + 1)
 
     # ---- inputs: KmerSetCompact containers resident in HBM before anything is timed.  In a
-    # multi-GPU run a rank only builds the containers of the sets it owns (set i -> rank i % world).
+    # multi-GPU run a rank only builds the containers of the sets it owns (contiguous blocks:
+    # set i -> rank i * world // n_sets).
+    owners = capi.block_owners(n_sets, world)
     t0 = time.perf_counter()
     kmers = synth_torch.phylogeny_sets(k, n_sets, size, args.seed, dev)
     sizes = [int(km.numel()) for km in kmers]
     compacts = []
     for i, km in enumerate(kmers):
-        if world > 1 and i % world != rank:
+        if world > 1 and owners[i] != rank:
             compacts.append(None)
         else:
             compacts.append(ctx.spss_encode(synth_torch.device_set(g, km), mode=0))
@@ -134,10 +160,13 @@ def main():
     torch.cuda.synchronize()
     t_inputs = time.perf_counter() - t0
 
+    comm = capi.Comm(ctx, dist, coll_dev) if world > 1 else None     # one RCCL communicator for all builds
+
     def build():
         if world == 1:
             return capi.DeviceKmerSetSet(ctx, compacts, ids, max_iterations=args.max_iterations)
-        return capi.OwnedKmerSetSet(ctx, compacts, ids, dist, coll_dev, max_iterations=args.max_iterations)
+        return capi.OwnedKmerSetSet(ctx, compacts, ids, dist, coll_dev, max_iterations=args.max_iterations,
+                                    owners=owners, comm=comm)
 
     def fence():
         if world > 1:
@@ -176,6 +205,18 @@ def main():
         elapsed = float(t.item())
     n_proc = st["n_processed"]
     value = n_proc * args.steps / elapsed / 1e6
+    multi_gpu = None
+    if world > 1:
+        cs = kss.comm_stats()
+        v = torch.tensor([st["n_encodes"], st["n_encoded_kmers"], cs["p2p_sets"], cs["p2p_bytes_sent"],
+                          cs["gather_bytes"]], dtype=torch.int64, device=coll_dev)
+        parts = [torch.zeros_like(v) for _ in range(world)]
+        dist.all_gather(parts, v)
+        rows = [[int(x) for x in p.tolist()] for p in parts]
+        multi_gpu = {"transport": comm.kind, "encodes_per_rank": [r[0] for r in rows],
+                     "encoded_kmers_per_rank": [r[1] for r in rows], "sets_sent_per_rank": [r[2] for r in rows],
+                     "p2p_bytes_sent_per_rank": [r[3] for r in rows], "allgather_bytes_per_rank": [r[4] for r in rows],
+                     "note": "last timed build"}
 
     verified = None
     if not args.no_verify:
@@ -259,11 +300,10 @@ def main():
         import oracle_lib as ol
 
         cs, csize, ci = args.cpu_sets, int(args.cpu_size), args.cpu_iterations
-        cores = args.cpu_workers or (os.cpu_count() or 1)
-        try:
-            cores = min(cores, len(os.sched_getaffinity(0)))
-        except AttributeError:
-            pass
+        # the reference posts n_workers^2 chunks per parallel step, each with its own 2^N key buffers
+        # (spss.h:1896-1901): beyond a few dozen workers the chunk set-up dominates, so the "all cores"
+        # run is capped at 32 workers (measured on the 256-thread host: 256 workers are 27x SLOWER than 1)
+        cores = args.cpu_workers or min(host_cores(), 32)
         host = synth.phylogeny_sets(k, cs, csize, seed=args.seed)
         oc = [ol.Set.from_kmers(k, nbits, g.key_bytes, s).compact() for s in host]
         runs = {}
@@ -283,7 +323,7 @@ def main():
             raise SystemExit("CPU baseline sample: the oracle's merge sequence differs from the GPU's")
         cpu_baseline = {
             "value": runs[cores][0], "unit": "Mk-mers/s", "cores": cores, "kind": "port",
-            "cpu": cpu_model(),
+            "cpu": cpu_model(), "host_cores_available": host_cores(),
             "value_1_core": runs[1][0],
             "sample": "oracle KmerSetSet (C++ port of lib/core/kmer_set_set.h:109-427 with the reference's "
                       "bucket-parallel / pooled structure), %d sets of %d k-mers of the same family, first %d "
@@ -339,9 +379,9 @@ def main():
                 "input_build_s": t_inputs, "first_build_wall_s": first_wall,
                 "sum_input_mkmers_per_s": total * args.steps / elapsed / 1e6,
                 "parallelism": "1 GPU" if world == 1 else
-                               "1 process per GPU, owner-sharded sets (set i on rank i %% %d), replicated control "
-                               "loop on all-gathered 2 %% samples, merges and encodes on the owner, RCCL "
-                               "all-gather / send-recv on device buffers" % world,
+                               "1 process per GPU, owner-sharded sets (contiguous blocks of %d), replicated control "
+                               "loop on the all-gathered 2 %% samples, merges and encodes on the owner of j, %s "
+                               "all-gather / send-recv on device buffers" % (n_sets // world, comm.kind.upper()),
             },
             "phase_seconds_last_build": st["phase_seconds"],
             "roofline": {
@@ -367,11 +407,14 @@ def main():
             "cpu_baseline": cpu_baseline,
             "spss": spss,
             "verified": verified,
+            "multi_gpu": multi_gpu,
             "pair_merge": pair_merge,
         }
         print(json.dumps(out))
     if kss is not None:
         kss.close()
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -286,6 +286,53 @@ int ksh_kss_build_sharded(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* 
                           int32_t max_iterations, int32_t rank, int32_t world, ksh_allgather_i64 gather,
                           void* gather_user, ksh_kss** out);
 int ksh_kss_node_holder(const ksh_kss* k, int32_t i, int32_t* rank);
+
+/* ---- owner-sharded multi-GPU build --------------------------------------------------------
+ * One process per GPU; no rank holds every node (config 5: 256 sets of 5 * 10^8 48-bit keys are
+ * 1 TB decoded, 128 GB per GPU of an 8-GPU node).
+ *   * every input set is decoded and kept by ONE rank, its owner (owners[i]); a rank passes the
+ *     containers of the inputs it owns, the others' entries are ignored;
+ *   * what the loop's decisions read -- the 2 % sampled buckets of every node
+ *     (kmer_set_set.h:138-153) -- is all-gathered once for the inputs; after that every rank runs
+ *     the same control loop on its copy of the samples (arg-max :308-316, the merged pair's new
+ *     samples :349-363 = the same merge on the sampled buckets, the re-weighting :385-425) with no
+ *     exchange at all: the samples of a merge's three results ARE the merge of the samples;
+ *   * the full-size Intersection + Sub + Sub of iteration (j, k) (:339-343) runs on the owner of
+ *     j; if k lives elsewhere its keys travel there point to point (xGMI) and k's remainder stays
+ *     with j's owner, which also owns the new node;
+ *   * at the points where the loop reads SPSS weights (:287 and the end) every rank encodes the
+ *     stale nodes it owns and one all-gather of (n_strings, n_bases, size) per stale node puts
+ *     the sum on all ranks.
+ * Trace, checkpoints, DAG and every node's set and SPSS equal the single-GPU build's; a node's
+ * set and SPSS live on its owner only (ksh_kss_node_holder; ksh_kss_node answers
+ * KSH_FAILED_PRECONDITION elsewhere, ksh_kss_get when a reachable node lives elsewhere).
+ *
+ * Transport: RCCL, opened at run time (librccl.so), collectives enqueued on the context's stream
+ * with device buffers -- rank 0 draws the id, the caller carries its 128 bytes to the other ranks
+ * (MPI, torch.distributed, a file) -- or caller-supplied functions over device buffers, which
+ * return when the transfer is complete (rehearsals with several ranks on one GPU, where RCCL
+ * cannot run; the library drains its stream before calling them). */
+#define KSH_COMM_ID_BYTES 128
+typedef struct ksh_comm ksh_comm;
+typedef struct ksh_comm_fns {
+  void* user;
+  /* d_recv receives world * bytes, rank-major */
+  int (*allgather)(void* user, const void* d_send, void* d_recv, size_t bytes);
+  int (*send)(void* user, const void* d_buf, size_t bytes, int32_t peer);
+  int (*recv)(void* user, void* d_buf, size_t bytes, int32_t peer);
+} ksh_comm_fns;
+int ksh_comm_unique_id(unsigned char id[KSH_COMM_ID_BYTES]);
+int ksh_comm_create_rccl(ksh_ctx* ctx, int32_t rank, int32_t world, const unsigned char id[KSH_COMM_ID_BYTES],
+                         ksh_comm** out);
+int ksh_comm_create_custom(ksh_ctx* ctx, int32_t rank, int32_t world, const ksh_comm_fns* fns, ksh_comm** out);
+int ksh_comm_destroy(ksh_comm* comm);
+/* owners[i] in [0, world): the rank that holds input i.  inputs[i] is read on that rank only. */
+int ksh_kss_build_owned(ksh_ctx* ctx, ksh_comm* comm, const ksh_geom* g, const ksh_spss_view* inputs,
+                        int32_t n_inputs, const int32_t* owners, const int32_t* bucket_ids, int32_t n_ids,
+                        int canonical, int32_t max_iterations, ksh_kss** out);
+/* Bytes this rank sent / received point to point and the sets that travelled (the merged pairs whose
+ * members lived on different ranks), and the bytes it contributed to all-gathers. */
+int ksh_kss_comm_stats(const ksh_kss* k, int64_t stats[4]);
 /* SPSS encodes this process ran for the build, and the k-mers they covered (the sharded build's
  * balance; in a single-GPU build: how many encodes the deferral left). */
 int ksh_kss_encode_counts(const ksh_kss* k, int64_t* n_encodes, int64_t* n_encoded_kmers);

@@ -1,0 +1,212 @@
+// Transport of the multi-GPU build (one process per GPU): all-gather and point-to-point copies of
+// DEVICE buffers between the ranks.
+//
+//   * RCCL, the transport of a real node (xGMI between the GPUs): librccl is opened at run time
+//     (a host program that never builds across GPUs does not need it installed) and its
+//     collectives are enqueued on the context's stream -- no host bounce, no Python in the path.
+//   * caller-supplied functions, for rehearsals where RCCL cannot run (several ranks sharing one
+//     GPU: RCCL refuses two ranks on a device): the tests pass gloo through host memory.
+//
+// The reference has no counterpart (one process, shared memory, lib/core/kmer_set_set.h:109-427);
+// what the ranks exchange is what its pool threads share through memory: the sampled sets
+// (:138-153), the SPSS weights (:240-264) and the sets of a merged pair (:333-336).
+#include "ksh_internal.h"
+
+#include <dlfcn.h>
+
+#include <cstring>
+
+#include "ksh_comm.h"
+
+namespace {
+
+// The few RCCL entry points used, with the library's own C signatures (rccl.h of ROCm 7.2:
+// ncclUniqueId is 128 opaque bytes passed by value; ncclInt8 == 0).
+struct UniqueId {
+  char internal[128];
+};
+using comm_t = void*;
+using fn_get_unique_id = int (*)(UniqueId*);
+using fn_comm_init_rank = int (*)(comm_t*, int, UniqueId, int);
+using fn_comm_destroy = int (*)(comm_t);
+using fn_all_gather = int (*)(const void*, void*, size_t, int, comm_t, hipStream_t);
+using fn_send = int (*)(const void*, size_t, int, int, comm_t, hipStream_t);
+using fn_recv = int (*)(void*, size_t, int, int, comm_t, hipStream_t);
+using fn_error_string = const char* (*)(int);
+
+struct Rccl {
+  void* lib = nullptr;
+  fn_get_unique_id get_unique_id = nullptr;
+  fn_comm_init_rank comm_init_rank = nullptr;
+  fn_comm_destroy comm_destroy = nullptr;
+  fn_all_gather all_gather = nullptr;
+  fn_send send = nullptr;
+  fn_recv recv = nullptr;
+  fn_error_string error_string = nullptr;
+};
+
+int load_rccl(Rccl* r) {
+  static Rccl cached;
+  if (!cached.lib) {
+    // the copy already in the process (torch brings its own) before the system's
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+    void* lib = nullptr;
+    for (const char* nm : names)
+      if ((lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD))) break;
+    if (!lib)
+      for (const char* nm : names)
+        if ((lib = dlopen(nm, RTLD_NOW | RTLD_GLOBAL))) break;
+    if (!lib) return ksh::fail(KSH_INTERNAL, "librccl not found: %s", dlerror());
+    Rccl c;
+    c.lib = lib;
+    c.get_unique_id = reinterpret_cast<fn_get_unique_id>(dlsym(lib, "ncclGetUniqueId"));
+    c.comm_init_rank = reinterpret_cast<fn_comm_init_rank>(dlsym(lib, "ncclCommInitRank"));
+    c.comm_destroy = reinterpret_cast<fn_comm_destroy>(dlsym(lib, "ncclCommDestroy"));
+    c.all_gather = reinterpret_cast<fn_all_gather>(dlsym(lib, "ncclAllGather"));
+    c.send = reinterpret_cast<fn_send>(dlsym(lib, "ncclSend"));
+    c.recv = reinterpret_cast<fn_recv>(dlsym(lib, "ncclRecv"));
+    c.error_string = reinterpret_cast<fn_error_string>(dlsym(lib, "ncclGetErrorString"));
+    if (!c.get_unique_id || !c.comm_init_rank || !c.comm_destroy || !c.all_gather || !c.send || !c.recv)
+      return ksh::fail(KSH_INTERNAL, "librccl lacks an entry point this library needs");
+    cached = c;
+  }
+  *r = cached;
+  return KSH_OK;
+}
+
+}  // namespace
+
+struct ksh_comm {
+  ksh_ctx* ctx = nullptr;
+  int rank = 0, world = 1;
+  bool custom = false;
+  ksh_comm_fns fns{};
+  Rccl rccl;
+  comm_t nccl = nullptr;
+};
+
+namespace ksh {
+
+int comm_rank(const ksh_comm* c) { return c->rank; }
+int comm_world(const ksh_comm* c) { return c->world; }
+
+#define KSH_RCCL(c, expr)                                                                          \
+  do {                                                                                             \
+    int rc__ = (expr);                                                                             \
+    if (rc__ != 0)                                                                                 \
+      return ::ksh::fail(KSH_INTERNAL, "%s failed: %s", #expr,                                     \
+                         (c)->rccl.error_string ? (c)->rccl.error_string(rc__) : "RCCL error");    \
+  } while (0)
+
+// Every rank contributes `bytes` from d_send; d_recv receives world * bytes, rank-major.  RCCL:
+// enqueued on the context's stream.  Custom: the stream is drained first and the call returns
+// when the data is there.
+int comm_allgather(ksh_comm* c, const void* d_send, void* d_recv, size_t bytes) {
+  if (c->world == 1) {
+    if (d_send != d_recv && bytes)
+      KSH_HIP(hipMemcpyAsync(d_recv, d_send, bytes, hipMemcpyDeviceToDevice, c->ctx->stream));
+    return KSH_OK;
+  }
+  if (c->custom) {
+    KSH_HIP(hipStreamSynchronize(c->ctx->stream));
+    if (c->fns.allgather(c->fns.user, d_send, d_recv, bytes) != 0)
+      return fail(KSH_INTERNAL, "the caller's all-gather failed");
+    return KSH_OK;
+  }
+  KSH_RCCL(c, c->rccl.all_gather(d_send, d_recv, bytes, /* ncclInt8 */ 0, c->nccl, c->ctx->stream));
+  return KSH_OK;
+}
+
+int comm_send(ksh_comm* c, const void* d_buf, size_t bytes, int peer) {
+  if (bytes == 0) return KSH_OK;
+  if (c->custom) {
+    KSH_HIP(hipStreamSynchronize(c->ctx->stream));
+    if (c->fns.send(c->fns.user, d_buf, bytes, peer) != 0) return fail(KSH_INTERNAL, "the caller's send failed");
+    return KSH_OK;
+  }
+  KSH_RCCL(c, c->rccl.send(d_buf, bytes, 0, peer, c->nccl, c->ctx->stream));
+  return KSH_OK;
+}
+
+int comm_recv(ksh_comm* c, void* d_buf, size_t bytes, int peer) {
+  if (bytes == 0) return KSH_OK;
+  if (c->custom) {
+    KSH_HIP(hipStreamSynchronize(c->ctx->stream));
+    if (c->fns.recv(c->fns.user, d_buf, bytes, peer) != 0) return fail(KSH_INTERNAL, "the caller's recv failed");
+    return KSH_OK;
+  }
+  KSH_RCCL(c, c->rccl.recv(d_buf, bytes, 0, peer, c->nccl, c->ctx->stream));
+  return KSH_OK;
+}
+
+}  // namespace ksh
+
+using namespace ksh;
+
+extern "C" {
+
+int ksh_comm_unique_id(unsigned char id[KSH_COMM_ID_BYTES]) {
+  if (!id) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  Rccl r;
+  KSH_TRY(load_rccl(&r));
+  UniqueId u;
+  const int rc = r.get_unique_id(&u);
+  if (rc != 0) return fail(KSH_INTERNAL, "ncclGetUniqueId failed: %s", r.error_string ? r.error_string(rc) : "");
+  static_assert(sizeof(UniqueId) == KSH_COMM_ID_BYTES, "id size");
+  std::memcpy(id, u.internal, KSH_COMM_ID_BYTES);
+  return KSH_OK;
+}
+
+int ksh_comm_create_rccl(ksh_ctx* ctx, int32_t rank, int32_t world, const unsigned char id[KSH_COMM_ID_BYTES],
+                         ksh_comm** out) {
+  if (!ctx || !id || !out) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(KSH_INVALID_ARGUMENT, "bad rank / world");
+  *out = nullptr;
+  KSH_HIP(hipSetDevice(ctx->device));
+  ksh_comm* c = new ksh_comm;
+  c->ctx = ctx;
+  c->rank = rank;
+  c->world = world;
+  int rc = load_rccl(&c->rccl);
+  if (rc != KSH_OK) {
+    delete c;
+    return rc;
+  }
+  UniqueId u;
+  std::memcpy(u.internal, id, KSH_COMM_ID_BYTES);
+  const int nrc = c->rccl.comm_init_rank(&c->nccl, world, u, rank);
+  if (nrc != 0) {
+    const char* msg = c->rccl.error_string ? c->rccl.error_string(nrc) : "RCCL error";
+    delete c;
+    return fail(KSH_INTERNAL, "ncclCommInitRank failed: %s", msg);
+  }
+  *out = c;
+  return KSH_OK;
+}
+
+int ksh_comm_create_custom(ksh_ctx* ctx, int32_t rank, int32_t world, const ksh_comm_fns* fns, ksh_comm** out) {
+  if (!ctx || !out) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  if (world < 1 || rank < 0 || rank >= world) return fail(KSH_INVALID_ARGUMENT, "bad rank / world");
+  if (world > 1 && (!fns || !fns->allgather || !fns->send || !fns->recv))
+    return fail(KSH_INVALID_ARGUMENT, "a custom transport needs allgather, send and recv");
+  ksh_comm* c = new ksh_comm;
+  c->ctx = ctx;
+  c->rank = rank;
+  c->world = world;
+  c->custom = true;
+  if (fns) c->fns = *fns;
+  *out = c;
+  return KSH_OK;
+}
+
+int ksh_comm_destroy(ksh_comm* c) {
+  if (!c) return KSH_OK;
+  if (c->nccl) {
+    (void)hipStreamSynchronize(c->ctx->stream);
+    (void)c->rccl.comm_destroy(c->nccl);
+  }
+  delete c;
+  return KSH_OK;
+}
+
+}  // extern "C"

@@ -13,6 +13,7 @@
 //   * the three FromKmerSet re-encodes (:345-360) are ksh_spss_encode_*;
 //   * the weight table (:191-219,:385-425) is ksh_pair_weights.
 #include "ksh_internal.h"
+#include "ksh_comm.h"
 
 #include <cstring>
 #include <map>
@@ -58,6 +59,15 @@ struct ksh_kss {
   int rank = 0, world = 1;
   ksh_allgather_i64 gather = nullptr;
   void* gather_user = nullptr;
+  // owner-sharded build (ksh_kss_build_owned): a node's set and SPSS live on owner[node] only; every
+  // rank keeps the sampled buckets of every node (samples[i]: a set whose other buckets are empty)
+  ksh_comm* comm = nullptr;
+  bool owned = false;
+  std::vector<int> owner;
+  std::vector<KssSet> samples;
+  std::vector<bool> sample_pooled;   // false: the keys point into sample_block
+  char* sample_block = nullptr;      // the all-gathered samples of the inputs
+  int64_t p2p_bytes_sent = 0, p2p_bytes_received = 0, p2p_sets = 0, gather_bytes = 0;
 };
 
 namespace ksh {
@@ -234,6 +244,434 @@ static int pair_weights(ksh_kss* k, const std::vector<int32_t>& ids,
     if (w < 0) return fail(KSH_INTERNAL, "rank %zu did not report the weight of pair %zu", q / per, q);
     (*out)[q] = w;
   }
+  return KSH_OK;
+}
+
+static std::string serialize_children(const std::map<int, std::vector<int>>& a);
+
+// ---------------------------------------------------------------------------------- owner-sharded
+// sizes[b] = keys of bucket b if it is sampled, else 0 (the scan of it = the sample's offsets)
+__global__ __launch_bounds__(256) void k_sample_sizes(const int64_t* __restrict__ off, const uint8_t* __restrict__ flag,
+                                                       int64_t nb, int64_t* __restrict__ sizes) {
+  const int64_t b = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (b >= nb) return;
+  sizes[b] = flag[b] ? off[b + 1] - off[b] : 0;
+}
+
+// one workgroup per sampled bucket: its keys to their place in the sample
+__global__ __launch_bounds__(256) void k_sample_copy(const int64_t* __restrict__ off, const int64_t* __restrict__ off_s,
+                                                      const int32_t* __restrict__ ids, int key_bytes,
+                                                      const char* __restrict__ keys, char* __restrict__ keys_s) {
+  const int64_t b = ids[blockIdx.x];
+  const int64_t bytes = (off[b + 1] - off[b]) * key_bytes;
+  const char* src = keys + off[b] * key_bytes;
+  char* dst = keys_s + off_s[b] * key_bytes;
+  for (int64_t i = int64_t(threadIdx.x) * 4; i < bytes; i += 256 * 4)
+    *reinterpret_cast<uint32_t*>(dst + i) = *reinterpret_cast<const uint32_t*>(src + i);
+}
+
+static size_t a16(size_t x) { return (x + 15) & ~size_t(15); }
+
+// All-gather of `count` int64 per rank between host vectors, through device scratch.
+static int gather_i64(ksh_kss* k, const std::vector<int64_t>& send, std::vector<int64_t>* recv) {
+  ksh_ctx* ctx = k->ctx;
+  const size_t bytes = send.size() * 8;
+  recv->assign(send.size() * size_t(k->world), 0);
+  if (bytes == 0) return KSH_OK;
+  void *d_send = nullptr, *d_recv = nullptr;
+  KSH_TRY(pool_alloc(ctx, bytes, &d_send));
+  KSH_TRY(pool_alloc(ctx, bytes * size_t(k->world), &d_recv));
+  KSH_HIP(hipMemcpyAsync(d_send, send.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+  KSH_TRY(comm_allgather(k->comm, d_send, d_recv, bytes));
+  KSH_HIP(hipMemcpyAsync(recv->data(), d_recv, bytes * size_t(k->world), hipMemcpyDeviceToHost, ctx->stream));
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  pool_free(ctx, d_send);
+  pool_free(ctx, d_recv);
+  k->gather_bytes += int64_t(bytes);
+  return KSH_OK;
+}
+
+// The sampled buckets of a resident set as a set of their own (offsets over all 2^N buckets, the
+// others empty): GetSampledKmerSet (kmer_set_compact.h:120-203) as a slice.
+static int extract_sample(ksh_kss* k, const KssSet& full, const uint8_t* d_flag, const int32_t* d_ids, int32_t n_ids,
+                          int64_t* d_off_s, int64_t* n_keys) {
+  ksh_ctx* ctx = k->ctx;
+  const int64_t nb = n_buckets(&k->g);
+  hipLaunchKernelGGL(k_sample_sizes, dim3(unsigned((nb + 255) / 256)), dim3(256), 0, ctx->stream, full.off, d_flag, nb,
+                     d_off_s);
+  KSH_TRY(scan_exclusive_i64(ctx, d_off_s, d_off_s, nb, d_off_s + nb));
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, d_off_s + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  *n_keys = ctx->h_pinned[0];
+  (void)d_ids;
+  (void)n_ids;
+  return KSH_OK;
+}
+
+static int send_set(ksh_kss* k, const KssSet& s, int peer) {
+  const int64_t nb = n_buckets(&k->g);
+  KSH_TRY(comm_send(k->comm, s.off, size_t(nb + 1) * 8, peer));
+  KSH_TRY(comm_send(k->comm, s.keys, size_t(s.n) * k->g.key_bytes, peer));
+  k->p2p_bytes_sent += (nb + 1) * 8 + s.n * k->g.key_bytes;
+  k->p2p_sets++;
+  return KSH_OK;
+}
+
+static int recv_set(ksh_kss* k, int peer, KssSet* out) {
+  ksh_ctx* ctx = k->ctx;
+  const int64_t nb = n_buckets(&k->g);
+  KSH_TRY(alloc_offsets(ctx, &k->g, out));
+  KSH_TRY(comm_recv(k->comm, out->off, size_t(nb + 1) * 8, peer));
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, out->off + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  const int64_t n = ctx->h_pinned[0];
+  KSH_TRY(alloc_keys(ctx, &k->g, n, out));
+  KSH_TRY(comm_recv(k->comm, out->keys, size_t(n) * k->g.key_bytes, peer));
+  k->p2p_bytes_received += (nb + 1) * 8 + n * k->g.key_bytes;
+  return KSH_OK;
+}
+
+// Weight table over the samples (every rank computes all of it: 2 % of the data, no exchange).
+static int sample_weights(ksh_kss* k, const std::vector<int32_t>& ids, const std::vector<std::pair<int, int>>& pairs,
+                          std::vector<int64_t>* out) {
+  std::vector<ksh_set_view> views;
+  for (const KssSet& s : k->samples) views.push_back(view_of(s));
+  out->assign(pairs.size(), 0);
+  std::vector<int32_t> flat;
+  for (const auto& p : pairs) {
+    flat.push_back(p.first);
+    flat.push_back(p.second);
+  }
+  if (!pairs.empty())
+    KSH_TRY(ksh_pair_weights(k->ctx, &k->g, views.data(), int32_t(views.size()), ids.data(), int32_t(ids.size()),
+                             flat.data(), int32_t(pairs.size()), out->data()));
+  return KSH_OK;
+}
+
+static void free_sample(ksh_kss* k, size_t i) {
+  if (k->sample_pooled[i]) {
+    pool_free(k->ctx, k->samples[i].off);
+    pool_free(k->ctx, k->samples[i].keys);
+  }
+  k->samples[i] = KssSet{};
+  k->sample_pooled[i] = false;
+}
+
+// Encodes the stale nodes this rank owns; one all-gather tells every rank (n_strings, n_bases,
+// size) of every stale node.
+static int ensure_compacts_owned(ksh_kss* k) {
+  std::vector<size_t> stale;
+  for (size_t i = 0; i < k->compacts.size(); i++)
+    if (!k->compacts[i].valid) stale.push_back(i);
+  if (stale.empty()) return KSH_OK;
+  std::vector<int64_t> send(3 * stale.size(), -1), recv;
+  for (size_t q = 0; q < stale.size(); q++) {
+    const size_t i = stale[q];
+    KssCompact c;
+    c.holder = k->owner[i];
+    if (k->owner[i] == k->rank) {
+      KSH_TRY(encode_set(k->ctx, &k->g, k->sets[i], k->canonical, &c));
+      c.holder = k->rank;
+      k->n_encodes++;
+      k->n_encoded_kmers += k->sets[i].n;
+      send[3 * q] = c.n_strings;
+      send[3 * q + 1] = c.n_bases;
+      send[3 * q + 2] = c.size;
+    }
+    k->compacts[i] = c;
+  }
+  KSH_TRY(gather_i64(k, send, &recv));
+  for (size_t q = 0; q < stale.size(); q++) {
+    KssCompact& c = k->compacts[stale[q]];
+    const int64_t* from = recv.data() + size_t(c.holder) * send.size() + 3 * q;
+    if (from[0] < 0 || from[1] < 0 || from[2] < 0)
+      return fail(KSH_INTERNAL, "rank %d did not report node %zu", c.holder, stale[q]);
+    c.n_strings = from[0];
+    c.n_bases = from[1];
+    c.size = from[2];
+    c.valid = true;
+  }
+  return KSH_OK;
+}
+
+static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs, const int32_t* owners,
+                       const std::vector<int32_t>& ids, int32_t max_iterations) {
+  ksh_ctx* ctx = k->ctx;
+  const ksh_geom* g = &k->g;
+  const int64_t nb = n_buckets(g);
+  const int rank = k->rank, world = k->world;
+  k->owned = true;
+  k->owner.assign(owners, owners + n_inputs);
+
+  // ---- inputs: decoded by their owners only
+  for (int32_t i = 0; i < n_inputs; i++) {
+    KssCompact c;
+    c.holder = k->owner[size_t(i)];
+    k->sets.emplace_back();
+    if (c.holder == rank) {
+      if (!inputs[i].d_words && inputs[i].n_bases > 0)
+        return fail(KSH_INVALID_ARGUMENT, "rank %d owns input %d but was not given its container", rank, i);
+      c.words = const_cast<uint64_t*>(inputs[i].d_words);
+      c.lens = const_cast<uint32_t*>(inputs[i].d_lens);
+      c.n_strings = inputs[i].n_strings;
+      c.n_bases = inputs[i].n_bases;
+      c.owned = false;
+      KSH_TRY(ksh_spss_size(ctx, g, &inputs[i], &c.size));
+      PhaseTimer pt(k, 0);
+      KSH_TRY(decode_to_set(ctx, g, &inputs[i], k->canonical, &k->sets.back()));
+    }
+    k->compacts.push_back(c);
+  }
+  {
+    std::vector<int64_t> send(3 * size_t(n_inputs), -1), recv;
+    for (int32_t i = 0; i < n_inputs; i++)
+      if (k->owner[size_t(i)] == rank) {
+        send[3 * size_t(i)] = k->compacts[size_t(i)].n_strings;
+        send[3 * size_t(i) + 1] = k->compacts[size_t(i)].n_bases;
+        send[3 * size_t(i) + 2] = k->compacts[size_t(i)].size;
+      }
+    KSH_TRY(gather_i64(k, send, &recv));
+    for (int32_t i = 0; i < n_inputs; i++) {
+      const int64_t* from = recv.data() + size_t(k->owner[size_t(i)]) * send.size() + 3 * size_t(i);
+      k->compacts[size_t(i)].n_strings = from[0];
+      k->compacts[size_t(i)].n_bases = from[1];
+      k->compacts[size_t(i)].size = from[2];
+    }
+  }
+
+  // ---- samples of the inputs: extracted by the owners, all-gathered once
+  {
+    PhaseTimer pt(k, 1);
+    std::vector<uint8_t> flag(size_t(nb), 0);
+    for (int32_t b : ids) flag[size_t(b)] = 1;
+    uint8_t* d_flag = nullptr;
+    int32_t* d_ids = nullptr;
+    KSH_TRY(pool_alloc(ctx, size_t(nb), reinterpret_cast<void**>(&d_flag)));
+    KSH_TRY(pool_alloc(ctx, std::max<size_t>(ids.size() * 4, 16), reinterpret_cast<void**>(&d_ids)));
+    KSH_HIP(hipMemcpyAsync(d_flag, flag.data(), size_t(nb), hipMemcpyHostToDevice, ctx->stream));
+    KSH_HIP(hipMemcpyAsync(d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    // sample offsets of my inputs and their key counts
+    std::vector<int64_t*> my_off(size_t(n_inputs), nullptr);
+    std::vector<int64_t> my_n(size_t(n_inputs), -1), all_n;
+    for (int32_t i = 0; i < n_inputs; i++) {
+      if (k->owner[size_t(i)] != rank) continue;
+      KSH_TRY(pool_alloc(ctx, size_t(nb + 1) * 8, reinterpret_cast<void**>(&my_off[size_t(i)])));
+      KSH_TRY(extract_sample(k, k->sets[size_t(i)], d_flag, d_ids, int32_t(ids.size()), my_off[size_t(i)],
+                             &my_n[size_t(i)]));
+    }
+    KSH_TRY(gather_i64(k, my_n, &all_n));
+    std::vector<int64_t> n_of(size_t(n_inputs), 0);
+    for (int32_t i = 0; i < n_inputs; i++)
+      n_of[size_t(i)] = all_n[size_t(k->owner[size_t(i)]) * size_t(n_inputs) + size_t(i)];
+    // payload of a rank: its inputs in ascending order, each [offsets (nb + 1) x 8][keys, padded to 16]
+    std::vector<size_t> payload(size_t(world), 0), at_in_payload(size_t(n_inputs), 0);
+    for (int32_t i = 0; i < n_inputs; i++) {
+      size_t& p = payload[size_t(k->owner[size_t(i)])];
+      at_in_payload[size_t(i)] = p;
+      p += a16(size_t(nb + 1) * 8) + a16(size_t(n_of[size_t(i)]) * g->key_bytes + 16);
+    }
+    size_t slot = 16;
+    for (size_t p : payload) slot = std::max(slot, p);
+    char* d_send = nullptr;
+    KSH_TRY(pool_alloc(ctx, slot, reinterpret_cast<void**>(&d_send)));
+    KSH_HIP(hipMalloc(reinterpret_cast<void**>(&k->sample_block), slot * size_t(world)));
+    for (int32_t i = 0; i < n_inputs; i++) {
+      if (k->owner[size_t(i)] != rank) continue;
+      char* dst = d_send + at_in_payload[size_t(i)];
+      KSH_HIP(hipMemcpyAsync(dst, my_off[size_t(i)], size_t(nb + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+      if (!ids.empty())
+        hipLaunchKernelGGL(k_sample_copy, dim3(unsigned(ids.size())), dim3(256), 0, ctx->stream,
+                           k->sets[size_t(i)].off, my_off[size_t(i)], d_ids, g->key_bytes,
+                           static_cast<const char*>(k->sets[size_t(i)].keys), dst + a16(size_t(nb + 1) * 8));
+    }
+    KSH_TRY(comm_allgather(k->comm, d_send, k->sample_block, slot));
+    KSH_HIP(hipStreamSynchronize(ctx->stream));
+    k->gather_bytes += int64_t(slot);
+    for (int32_t i = 0; i < n_inputs; i++) {
+      char* base = k->sample_block + size_t(k->owner[size_t(i)]) * slot + at_in_payload[size_t(i)];
+      KssSet s;
+      s.off = reinterpret_cast<int64_t*>(base);
+      s.keys = base + a16(size_t(nb + 1) * 8);
+      s.n = n_of[size_t(i)];
+      k->samples.push_back(s);
+      k->sample_pooled.push_back(false);
+      if (my_off[size_t(i)]) pool_free(ctx, my_off[size_t(i)]);
+    }
+    pool_free(ctx, d_send);
+    pool_free(ctx, d_flag);
+    pool_free(ctx, d_ids);
+  }
+
+  std::map<std::pair<int, int>, int64_t> weights;
+  {
+    std::vector<std::pair<int, int>> pairs;
+    for (int i = 0; i < n_inputs; i++)
+      for (int j = i + 1; j < n_inputs; j++) pairs.emplace_back(i, j);
+    std::vector<int64_t> w;
+    {
+      PhaseTimer pt(k, 1);
+      KSH_TRY(sample_weights(k, ids, pairs, &w));
+    }
+    for (size_t i = 0; i < pairs.size(); i++) weights[pairs[i]] = w[i];
+    k->initial_weights = w;
+  }
+
+  int64_t total_size = 0;
+  for (const KssCompact& c : k->compacts) total_size += c.size;
+  k->initial_total_size = total_size;
+
+  const auto total_spss_weight_now = [&](int64_t* total) {
+    PhaseTimer pt(k, 3);
+    KSH_TRY(ensure_compacts_owned(k));
+    *total = 0;
+    for (const KssCompact& c : k->compacts) *total += c.n_bases;
+    return KSH_OK;
+  };
+  int64_t total_spss_weight = 0;
+  KSH_TRY(total_spss_weight_now(&total_spss_weight));
+  k->initial_spss_weight = total_spss_weight;
+
+  const int interval = int(k->compacts.size() / 8 + 1);
+  const float improvement_threshold = 0.1 * interval / k->compacts.size();
+
+  // rows of the trace are known where the merge ran: {j, k, weight, original_size, size_diff};
+  // the executing rank of every iteration is the same on all ranks
+  std::vector<int64_t> my_rows;
+  std::vector<int> executor;
+
+  for (int i = 0;; i++) {
+    if (max_iterations >= 0 && i >= max_iterations) break;
+    if (i > 0 && i % interval == 0) {
+      int64_t updated = 0;
+      KSH_TRY(total_spss_weight_now(&updated));
+      const float improvement = static_cast<float>(total_spss_weight - updated) / total_spss_weight;
+      const bool stop = improvement <= improvement_threshold;
+      k->checkpoints.insert(k->checkpoints.end(), {int64_t(i), total_spss_weight, updated, int64_t(stop)});
+      k->improvements.push_back(improvement);
+      if (stop) break;
+      total_spss_weight = updated;
+    }
+    const int n = int(k->compacts.size());
+    int64_t weight = 0;
+    int j = -1, kk = -1;
+    for (const auto& p : weights) {
+      if (p.second > weight) {
+        j = p.first.first;
+        kk = p.first.second;
+        weight = p.second;
+      }
+    }
+    if (weight == 0) break;
+
+    // the merge on the samples: every rank, its own copy
+    {
+      PhaseTimer pt(k, 1);
+      const ksh_set_view vj = view_of(k->samples[size_t(j)]), vk = view_of(k->samples[size_t(kk)]);
+      KssSet sn, sj, sk;
+      KSH_TRY(alloc_offsets(ctx, g, &sn));
+      KSH_TRY(alloc_offsets(ctx, g, &sj));
+      KSH_TRY(alloc_offsets(ctx, g, &sk));
+      int64_t totals[3];
+      KSH_TRY(ksh_pair_plan(ctx, g, &vj, &vk, sn.off, sj.off, sk.off, totals));
+      KSH_TRY(alloc_keys(ctx, g, totals[0], &sn));
+      KSH_TRY(alloc_keys(ctx, g, totals[1], &sj));
+      KSH_TRY(alloc_keys(ctx, g, totals[2], &sk));
+      KSH_TRY(ksh_pair_write(ctx, g, &vj, &vk, sn.keys, sj.keys, sk.keys));
+      free_sample(k, size_t(j));
+      free_sample(k, size_t(kk));
+      k->samples[size_t(j)] = sj;
+      k->samples[size_t(kk)] = sk;
+      k->sample_pooled[size_t(j)] = k->sample_pooled[size_t(kk)] = true;
+      k->samples.push_back(sn);
+      k->sample_pooled.push_back(true);
+    }
+
+    // the merge on the sets: the owner of j, with k's keys pulled in when they live elsewhere
+    const int ex = k->owner[size_t(j)], src = k->owner[size_t(kk)];
+    executor.push_back(ex);
+    my_rows.insert(my_rows.end(), {int64_t(j), int64_t(kk), weight, -1, 0});
+    k->sets.emplace_back();
+    if (rank == ex) {
+      PhaseTimer pt(k, 2);
+      KssSet pulled;
+      if (src != ex) KSH_TRY(recv_set(k, src, &pulled));
+      const KssSet& set_k = src != ex ? pulled : k->sets[size_t(kk)];
+      const ksh_set_view vj = view_of(k->sets[size_t(j)]), vk = view_of(set_k);
+      const int64_t original_size = vj.n_keys + vk.n_keys;
+      KssSet sn, sj, sk;
+      KSH_TRY(alloc_offsets(ctx, g, &sn));
+      KSH_TRY(alloc_offsets(ctx, g, &sj));
+      KSH_TRY(alloc_offsets(ctx, g, &sk));
+      int64_t totals[3];
+      KSH_TRY(ksh_pair_plan(ctx, g, &vj, &vk, sn.off, sj.off, sk.off, totals));
+      KSH_TRY(alloc_keys(ctx, g, totals[0], &sn));
+      KSH_TRY(alloc_keys(ctx, g, totals[1], &sj));
+      KSH_TRY(alloc_keys(ctx, g, totals[2], &sk));
+      KSH_TRY(ksh_pair_write(ctx, g, &vj, &vk, sn.keys, sj.keys, sk.keys));
+      if (src != ex) free_set(ctx, &pulled); else free_set(ctx, &k->sets[size_t(kk)]);
+      free_set(ctx, &k->sets[size_t(j)]);
+      k->sets[size_t(j)] = sj;
+      k->sets[size_t(kk)] = sk;
+      k->sets[size_t(n)] = sn;
+      int64_t* row = my_rows.data() + my_rows.size() - 5;
+      row[3] = original_size;
+      row[4] = sn.n + sj.n + sk.n - original_size;
+    } else if (rank == src) {
+      PhaseTimer pt(k, 2);
+      KSH_TRY(send_set(k, k->sets[size_t(kk)], ex));
+      KSH_HIP(hipStreamSynchronize(ctx->stream));  // the keys have left before their buffer is reused
+      free_set(ctx, &k->sets[size_t(kk)]);
+    }
+    for (int node : {j, kk}) {
+      free_compact(ctx, &k->compacts[size_t(node)]);
+      k->compacts[size_t(node)].valid = false;
+      k->compacts[size_t(node)].holder = ex;
+    }
+    KssCompact cn;
+    cn.valid = false;
+    cn.holder = ex;
+    k->compacts.push_back(cn);
+    k->owner[size_t(kk)] = ex;
+    k->owner.push_back(ex);
+    k->children[j].push_back(n);
+    k->children[kk].push_back(n);
+
+    {
+      std::vector<std::pair<int, int>> pairs;
+      for (int l = 0; l < n; l++) {
+        if (j == l) continue;
+        pairs.emplace_back(std::min(j, l), std::max(j, l));
+      }
+      for (int l = 0; l < n; l++) {
+        if (kk == l) continue;
+        pairs.emplace_back(std::min(kk, l), std::max(kk, l));
+      }
+      for (int l = 0; l < n; l++) pairs.emplace_back(l, n);
+      std::vector<int64_t> w;
+      {
+        PhaseTimer pt(k, 1);
+        KSH_TRY(sample_weights(k, ids, pairs, &w));
+      }
+      for (size_t q = 0; q < pairs.size(); q++) weights[pairs[q]] = w[q];
+    }
+  }
+  KSH_TRY(total_spss_weight_now(&k->final_spss_weight));
+
+  // the trace: every row from the rank that ran its merge
+  {
+    std::vector<int64_t> all;
+    KSH_TRY(gather_i64(k, my_rows, &all));
+    k->n_processed = k->initial_total_size;
+    for (size_t t = 0; t < executor.size(); t++) {
+      const int64_t* row = all.data() + size_t(executor[t]) * my_rows.size() + 5 * t;
+      k->trace.insert(k->trace.end(), row, row + 5);
+      total_size += row[4];
+      k->n_processed += row[3];
+    }
+  }
+  k->final_total_size = total_size;
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  k->meta = serialize_children(k->children);
   return KSH_OK;
 }
 
@@ -453,6 +891,44 @@ int ksh_kss_build_sharded(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* 
   return KSH_OK;
 }
 
+int ksh_kss_build_owned(ksh_ctx* ctx, ksh_comm* comm, const ksh_geom* g, const ksh_spss_view* inputs,
+                        int32_t n_inputs, const int32_t* owners, const int32_t* bucket_ids, int32_t n_ids,
+                        int canonical_flag, int32_t max_iterations, ksh_kss** out) {
+  if (!ctx || !comm || !out || (n_inputs > 0 && (!inputs || !owners))) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  *out = nullptr;
+  KSH_TRY(check_geom(g));
+  if (n_inputs < 0 || n_ids < 0) return fail(KSH_INVALID_ARGUMENT, "negative count");
+  const int world = comm_world(comm);
+  for (int32_t i = 0; i < n_inputs; i++)
+    if (owners[i] < 0 || owners[i] >= world) return fail(KSH_INVALID_ARGUMENT, "owners[%d] = %d is no rank", i, owners[i]);
+  KSH_HIP(hipSetDevice(ctx->device));
+  ksh_kss* k = new ksh_kss;
+  k->ctx = ctx;
+  k->g = *g;
+  k->canonical = canonical_flag;
+  k->rank = comm_rank(comm);
+  k->world = world;
+  k->comm = comm;
+  std::vector<int32_t> ids(bucket_ids, bucket_ids + n_ids);
+  int rc = KSH_OK;
+  if (n_inputs > 0) rc = build_owned(k, inputs, n_inputs, owners, ids, max_iterations);
+  if (rc != KSH_OK) {
+    ksh_kss_destroy(k);
+    return rc;
+  }
+  *out = k;
+  return KSH_OK;
+}
+
+int ksh_kss_comm_stats(const ksh_kss* k, int64_t stats[4]) {
+  if (!k || !stats) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  stats[0] = k->p2p_bytes_sent;
+  stats[1] = k->p2p_bytes_received;
+  stats[2] = k->p2p_sets;
+  stats[3] = k->gather_bytes;
+  return KSH_OK;
+}
+
 int ksh_kss_encode_counts(const ksh_kss* k, int64_t* n_encodes, int64_t* n_encoded_kmers) {
   if (!k || !n_encodes || !n_encoded_kmers) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
   *n_encodes = k->n_encodes;
@@ -479,6 +955,12 @@ int ksh_kss_destroy(ksh_kss* k) {
   (void)hipStreamSynchronize(k->ctx->stream);
   for (KssSet& s : k->sets) free_set(k->ctx, &s);
   for (KssCompact& c : k->compacts) free_compact(k->ctx, &c);
+  for (size_t i = 0; i < k->samples.size(); i++)
+    if (k->sample_pooled[i]) {
+      pool_free(k->ctx, k->samples[i].off);
+      pool_free(k->ctx, k->samples[i].keys);
+    }
+  if (k->sample_block) (void)hipFree(k->sample_block);
   delete k;
   return KSH_OK;
 }
@@ -499,7 +981,11 @@ int ksh_kss_node(const ksh_kss* k, int32_t i, ksh_spss_view* compact, ksh_set_vi
       return fail(KSH_FAILED_PRECONDITION, "the SPSS of node %d is held by rank %d", i, c.holder);
     *compact = view_of(c);
   }
-  if (set) *set = view_of(k->sets[i]);
+  if (set) {
+    if (k->owned && k->owner[size_t(i)] != k->rank)
+      return fail(KSH_FAILED_PRECONDITION, "the set of node %d lives on rank %d", i, k->owner[size_t(i)]);
+    *set = view_of(k->sets[i]);
+  }
   if (size) *size = k->compacts[i].size;
   return KSH_OK;
 }
@@ -578,6 +1064,11 @@ int ksh_kss_get(const ksh_kss* k, int32_t i, int64_t** d_offsets, void** d_keys,
   while (!queue.empty()) {
     const int current = queue.front();
     queue.pop();
+    if (k->owned && k->owner[size_t(current)] != k->rank) {
+      free_set(ctx, &acc);
+      return fail(KSH_FAILED_PRECONDITION, "node %d, reachable from %d, lives on rank %d", current, i,
+                  k->owner[size_t(current)]);
+    }
     const ksh_set_view va = view_of(acc), vb = view_of(k->sets[current]);
     KssSet next;
     KSH_TRY(alloc_offsets(ctx, g, &next));

@@ -40,6 +40,14 @@ class SpssView(C.Structure):
 
 
 GATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_int64), C.c_int64, C.POINTER(C.c_int64))
+COMM_ALLGATHER_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t)
+COMM_P2P_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32)
+KSH_COMM_ID_BYTES = 128
+
+
+class CommFns(C.Structure):
+    _fields_ = [("user", C.c_void_p), ("allgather", COMM_ALLGATHER_FN), ("send", COMM_P2P_FN),
+                ("recv", COMM_P2P_FN)]
 
 
 class PairJob(C.Structure):
@@ -125,6 +133,13 @@ def lib():
         "ksh_kss_build_sharded": (C.c_int, [vp, GP, C.POINTER(SpssView), i32, C.POINTER(i32), i32, C.c_int,
                                             i32, i32, i32, GATHER_FN, vp, C.POINTER(vp)]),
         "ksh_kss_node_holder": (C.c_int, [vp, i32, C.POINTER(i32)]),
+        "ksh_comm_unique_id": (C.c_int, [C.c_char_p]),
+        "ksh_comm_create_rccl": (C.c_int, [vp, i32, i32, C.c_char_p, C.POINTER(vp)]),
+        "ksh_comm_create_custom": (C.c_int, [vp, i32, i32, C.POINTER(CommFns), C.POINTER(vp)]),
+        "ksh_comm_destroy": (C.c_int, [vp]),
+        "ksh_kss_build_owned": (C.c_int, [vp, vp, GP, C.POINTER(SpssView), i32, C.POINTER(i32), C.POINTER(i32), i32,
+                                          C.c_int, i32, C.POINTER(vp)]),
+        "ksh_kss_comm_stats": (C.c_int, [vp, C.POINTER(i64)]),
         "ksh_kss_encode_counts": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
         "ksh_kss_phase_seconds": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "ksh_kss_destroy": (C.c_int, [vp]),
@@ -772,3 +787,167 @@ class DeviceKmerSetSet:
             dev = self.ctx.device.index
             lib().ksh_free(dev, d_off)
             lib().ksh_free(dev, d_keys)
+
+
+class Comm:
+    """ksh_comm: the transport of the owner-sharded build.  backend "nccl": RCCL inside the library on
+    device buffers (rank 0 draws the id, torch.distributed carries its 128 bytes to the others);
+    anything else: the caller-supplied functions, here gloo through host memory (rehearsals with
+    several ranks on one GPU, where RCCL cannot run)."""
+
+    def __init__(self, ctx, dist, coll_dev):
+        import torch
+
+        self.ctx, self.dist = ctx, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        h = C.c_void_p()
+        if dist.get_backend() == "nccl":
+            buf = C.create_string_buffer(KSH_COMM_ID_BYTES)
+            if self.rank == 0:
+                check(lib().ksh_comm_unique_id(buf))
+            t = torch.tensor(list(buf.raw), dtype=torch.uint8, device=coll_dev)
+            dist.broadcast(t, 0)
+            raw = bytes(t.cpu().tolist())
+            check(lib().ksh_comm_create_rccl(ctx.h, self.rank, self.world, raw, C.byref(h)))
+            self.kind = "rccl"
+        else:
+            dev = ctx.device.index
+
+            def d2h(ptr, n):
+                a = np.empty(n, dtype=np.uint8)
+                if n:
+                    check(lib().ksh_memcpy_d2h(dev, a.ctypes.data_as(C.c_void_p), ptr, n))
+                return torch.from_numpy(a)
+
+            def h2d(ptr, t):
+                a = t.numpy()
+                if a.size:
+                    check(lib().ksh_memcpy_h2d(dev, ptr, a.ctypes.data_as(C.c_void_p), a.size))
+
+            def guarded(f):
+                def g(*args):
+                    try:
+                        f(*args)
+                        return 0
+                    except Exception:  # a Python exception must not unwind through the C frames
+                        import traceback
+
+                        traceback.print_exc()
+                        return 1
+                return g
+
+            @guarded
+            def allgather(_u, d_send, d_recv, n):
+                mine = d2h(d_send, n)
+                parts = [torch.empty_like(mine) for _ in range(self.world)]
+                dist.all_gather(parts, mine)
+                h2d(d_recv, torch.cat(parts))
+
+            @guarded
+            def send(_u, d_buf, n, peer):
+                dist.send(d2h(d_buf, n), peer)
+
+            @guarded
+            def recv(_u, d_buf, n, peer):
+                t = torch.empty(n, dtype=torch.uint8)
+                dist.recv(t, peer)
+                h2d(d_buf, t)
+
+            self._keep = (COMM_ALLGATHER_FN(allgather), COMM_P2P_FN(send), COMM_P2P_FN(recv))
+            self._fns = CommFns(None, *self._keep)
+            check(lib().ksh_comm_create_custom(ctx.h, self.rank, self.world, C.byref(self._fns), C.byref(h)))
+            self.kind = "custom"
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().ksh_comm_destroy(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+def block_owners(n_sets, world):
+    """Input i lives on rank i * world // n_sets: contiguous blocks (neighbours in the input order are
+    the likeliest to merge first)."""
+    return [i * world // n_sets for i in range(n_sets)]
+
+
+class OwnedKmerSetSet(DeviceKmerSetSet):
+    """ksh_kss_build_owned: the multi-GPU KmerSetSet in which a node's set and SPSS live on one rank.
+    compacts[i] is the input's DeviceSpss on its owner and None elsewhere."""
+
+    def __init__(self, ctx, compacts, bucket_ids, dist, coll_dev, canonical=True, max_iterations=-1, owners=None,
+                 comm=None):
+        self.ctx, self.dist, self.coll_dev = ctx, dist, coll_dev
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        self.owners = list(owners) if owners is not None else block_owners(len(compacts), self.world)
+        mine = [c for c in compacts if c is not None]
+        if not mine:
+            raise ValueError("rank %d owns no input" % self.rank)
+        self.g, self.inputs = mine[0].g, list(compacts)
+        for i, c in enumerate(compacts):
+            if (c is not None) != (self.owners[i] == self.rank):
+                raise ValueError("input %d: the container must be given on its owner (rank %d) only" % (i, self.owners[i]))
+        views = (SpssView * len(compacts))(*[c.view() if c is not None else SpssView(None, None, 0, 0) for c in compacts])
+        own = np.ascontiguousarray(self.owners, dtype=np.int32)
+        ids = np.ascontiguousarray(bucket_ids, dtype=np.int32)
+        self._own_comm = comm is None
+        self.comm = comm if comm is not None else Comm(ctx, dist, coll_dev)
+        h = C.c_void_p()
+        check(lib().ksh_kss_build_owned(ctx.h, self.comm.h, C.byref(self.g), views, len(compacts),
+                                        own.ctypes.data_as(C.POINTER(C.c_int32)),
+                                        ids.ctypes.data_as(C.POINTER(C.c_int32)), ids.size, int(canonical),
+                                        max_iterations, C.byref(h)))
+        self.h = h
+        self._table = None
+
+    def close(self):
+        DeviceKmerSetSet.close(self)
+        if getattr(self, "_own_comm", False) and getattr(self, "comm", None) is not None:
+            self.comm.close()
+            self.comm = None
+
+    __del__ = close
+
+    def comm_stats(self):
+        st = (C.c_int64 * 4)()
+        check(lib().ksh_kss_comm_stats(self.h, st))
+        return dict(zip(["p2p_bytes_sent", "p2p_bytes_received", "p2p_sets", "gather_bytes"], [int(x) for x in st]))
+
+    def node_table(self):
+        """(size, XOR hash) of every node, from the ranks that hold them (one all-gather)."""
+        import torch
+
+        if self._table is None:
+            n = self.size()
+            mine = np.zeros((n, 2), dtype=np.int64)
+            for i in range(n):
+                if self.node_holder(i) != self.rank:
+                    continue
+                v = SetView()
+                check(lib().ksh_kss_node(self.h, i, None, C.byref(v), None))
+                hsh = C.c_uint64()
+                check(lib().ksh_set_hash(self.ctx.h, C.byref(self.g), C.byref(v), C.byref(hsh)))
+                mine[i] = (v.n_keys, np.uint64(hsh.value).astype(np.int64))
+            t = torch.from_numpy(mine).to(self.coll_dev)
+            self.dist.all_reduce(t)          # every node is reported by exactly one rank
+            self._table = t.cpu().numpy()
+        return self._table
+
+    def get_size_and_hash(self, i):
+        """(Size, Hash) of Get(i): the nodes reachable from i are pairwise disjoint (every merge splits a
+        set into its remainder and the new child), so the size is their sum and the hash their XOR."""
+        tab = self.node_table()
+        seen, todo = set(), [i]
+        while todo:
+            cur = todo.pop()
+            if cur in seen:
+                continue
+            seen.add(cur)
+            todo.extend(self.children(cur))
+        size, hsh = 0, 0
+        for node in seen:
+            size += int(tab[node, 0])
+            hsh ^= int(np.int64(tab[node, 1]).astype(np.uint64))
+        return size, hsh

@@ -126,3 +126,70 @@ def test_sharded_build(gpu, world):
     res = json.loads(line)
     assert res["ok"] and res["iterations"] > 0
     assert sum(res["encodes_per_rank"]) > 0 and min(res["encodes_per_rank"]) > 0   # the encodes were shared
+
+
+@pytest.mark.parametrize("world,shape,layout", [(2, ("15", "14", "2", "8", "20000", "3"), "block"),
+                                                (3, ("23", "14", "4", "8", "30000", "5"), "striped"),
+                                                (2, ("31", "14", "8", "6", "20000", "7"), "striped")])
+def test_owned_build(gpu, world, shape, layout):
+    """ksh_kss_build_owned with `world` processes (all on this GPU; gloo through host memory as the
+    transport): every input decoded by its owner only, the control loop replicated on the all-gathered
+    samples, merges on the owner of j with k's keys sent across.  Trace, checkpoints, DAG, sizes ==
+    the oracle's on every rank; every node's set and SPSS == the oracle's on the one rank that owns it
+    and unreadable elsewhere (tests/dist_owned_worker.py does the checks).  "striped" puts siblings on
+    different ranks, so the merges do pull sets across."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29551 + world + int(shape[0])),
+           os.path.join(here, "dist_owned_worker.py"), *shape, layout]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert res["ok"] and res["iterations"] > 0
+    assert sum(res["nodes_per_rank"]) == res["nodes"]
+    assert res["bytes_sent"] == res["bytes_received"]
+    if layout == "striped":
+        assert sum(res["sets_sent_per_rank"]) > 0          # sets did travel
+    assert sum(res["encodes_per_rank"]) > 0
+
+
+def test_owned_build_rccl_one_rank(gpu):
+    """The RCCL transport itself, as far as one GPU allows: a one-rank communicator (librccl opened at
+    run time, ncclCommInitRank, the all-gathers on the context's stream) behind ksh_kss_build_owned ==
+    ksh_kss_build on the same inputs."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import os, sys, numpy as np, torch, torch.distributed as dist\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "from kmersets import capi, synth\n"
+        "os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29577')\n"
+        "os.environ.setdefault('RANK', '0'); os.environ.setdefault('WORLD_SIZE', '1')\n"
+        "torch.cuda.set_device(0)\n"
+        "dist.init_process_group('nccl', device_id=torch.device('cuda', 0))\n"
+        "ctx = capi.Context(0); g = capi.geom(23, 14)\n"
+        "sets = synth.phylogeny_sets(23, 6, 40000, seed=11); ids = synth.sample_bucket_ids(14, seed=12)\n"
+        "comp = [ctx.spss_encode(capi.DeviceSet.from_kmers(g, s, ctx.device)) for s in sets]\n"
+        "a = capi.DeviceKmerSetSet(ctx, comp, ids)\n"
+        "b = capi.OwnedKmerSetSet(ctx, comp, ids, dist, torch.device('cuda', 0))\n"
+        "assert b.comm.kind == 'rccl'\n"
+        "assert all(np.array_equal(x, y) for x, y in zip(a.trace(), b.trace()))\n"
+        "assert a.meta() == b.meta() and a.size() == b.size()\n"
+        "sa, sb = a.stats(), b.stats()\n"
+        "assert all(sa[k] == sb[k] for k in ('n_processed', 'final_spss_weight', 'packed_bytes', 'length_bytes', 'nodes'))\n"
+        "assert all(a.node_strings(i) == b.node_strings(i) for i in range(a.size()))\n"
+        "assert all(b.get_size_and_hash(i) == a.get_size_and_hash(i) for i in range(6))\n"
+        "a.close(); b.close(); dist.destroy_process_group(); print('rccl one-rank ok')\n"
+    ) % (os.path.join(here, "..", "kmer-sets-compression_amd"), here)
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

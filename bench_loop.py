@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
 """bench_loop.py -- the whole KmerSetSet loop on one GPU (BASELINE configs[2] shape).
 
-Not the driver's contract bench (that is bench.py, configs[1]); this one times what
-kmerset-multiple-compress times around the KmerSetSet constructor
-(src/kmerset-multiple-compress.cc:96-101): inputs are KmerSetCompact containers
-already resident in HBM, the timed region is ksh_kss_build (decode of the inputs,
-weight table, every merge iteration with its three re-encodes).
+The same timed region as the driver's contract bench (bench.py, which runs the 64 x 10^8 case), with
+knobs for other shapes: what kmerset-multiple-compress times around the KmerSetSet constructor
+(src/kmerset-multiple-compress.cc:96-101): inputs are KmerSetCompact containers already resident
+in HBM, the timed region is ksh_kss_build (decode of the inputs, weight table, every merge
+iteration, and the SPSS encodes of the nodes that are stale when the loop reads weights: the
+three re-encodes of a merge are deferred to the convergence checks and the end).
 Mk-mers/s = N_proc / wall with N_proc as SURVEY.md 8(d) defines it.
 """
 import argparse

@@ -70,6 +70,8 @@ const char* ksh_last_error(void);
 int ksh_device_count(int* count);
 int ksh_malloc(int device, size_t bytes, void** d_ptr);
 int ksh_free(int device, void* d_ptr);
+/* The three copies wait for the whole device first (hipDeviceSynchronize): they are ordered after
+ * everything enqueued on any context's stream, blocking or not, and done when they return. */
 int ksh_memcpy_h2d(int device, void* d_dst, const void* src, size_t bytes);
 int ksh_memcpy_d2h(int device, void* dst, const void* d_src, size_t bytes);
 int ksh_memcpy_d2d(int device, void* d_dst, const void* d_src, size_t bytes);
@@ -102,6 +104,15 @@ int ksh_ctx_timing_units(ksh_ctx* ctx, int kind, int64_t* units);
 /* ---- KmerSet::Size / Hash  (lib/core/kmer_set.h:65-71, :224-244) --------------------- */
 /* XOR of all k-mer bit patterns in the set. */
 int ksh_set_hash(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* s, uint64_t* hash);
+
+/* ---- KmerSet::Contains / Find  (lib/core/kmer_set.h:99-105, :116-161) ------------------------
+ * contains: d_found[i] = 1 if the 2K-bit pattern d_kmers[i] is in the set, else 0 (batched: one
+ * launch for n queries; enqueued on the context's stream).
+ * kmers: every k-mer of the set as its full 2K-bit pattern, ascending, into d_kmers[n_keys] --
+ * KmerSet::Find(n_workers); a Find with a host predicate filters this one download. */
+int ksh_set_contains(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* s, const uint64_t* d_kmers, int64_t n,
+                     uint8_t* d_found);
+int ksh_set_kmers(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* s, uint64_t* d_kmers);
 
 /* ---- set algebra  (lib/core/kmer_set.h:164-187, :286-305; the loop needs
  *      A&B, A\B and B\A of one pair, lib/core/kmer_set_set.h:339-343) ------------------ */

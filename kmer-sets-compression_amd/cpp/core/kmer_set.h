@@ -8,9 +8,10 @@
 //   Add(other) / Sub(other)              ksh_set_union_* / ksh_pair_plan + ksh_pair_write
 //   free Add / Sub / Intersection        the same (Intersection is NOT lhs.Sub(Sub(lhs, rhs)):
 //                                        one merge emits it directly)
-// Single-k-mer Add / Remove / Contains and Find(pred) exist for the callers that build
-// or inspect a set on the host (kmerset-build, tests); they go through a pending list /
-// a lazily downloaded sorted copy.  n_workers stays in the signatures and is ignored.
+// Single-k-mer Add / Remove go through a pending list (flushed by the next bulk call);
+// Contains asks the device (ksh_set_contains; the batched overload takes many k-mers in one
+// launch); Find needs the k-mers on the host for its host predicate: they are expanded on the
+// device (ksh_set_kmers) and downloaded once.  n_workers stays in the signatures and is ignored.
 // KeyType keeps its meaning for the host-side accessors; on the device keys are 4 bytes
 // when 2K - N <= 32, else 8.
 #ifndef KSC_CORE_KMER_SET_H_
@@ -93,9 +94,22 @@ class KmerSet {
     host_valid_ = false;
   }
 
-  bool Contains(const Kmer<K>& kmer) const {
-    const std::vector<std::uint64_t>& h = HostBits();
-    return std::binary_search(h.begin(), h.end(), kmer.Bits());
+  bool Contains(const Kmer<K>& kmer) const { return Contains(std::vector<Kmer<K>>{kmer})[0]; }
+
+  // Batched membership: one launch for all queries, nothing of the set leaves the device.
+  std::vector<bool> Contains(const std::vector<Kmer<K>>& kmers) const {
+    std::vector<std::uint64_t> bits;
+    bits.reserve(kmers.size());
+    for (const Kmer<K>& kmer : kmers) bits.push_back(kmer.Bits());
+    const ksc::DeviceBuffer d_q = ksc::DeviceBuffer::FromHost(bits);
+    ksc::DeviceBuffer d_f(bits.size());
+    const ksh_geom g = Geom();
+    const ksh_set_view v = View();
+    ksc::Check(ksh_set_contains(ksc::Ctx(), &g, &v, static_cast<const std::uint64_t*>(d_q.get()),
+                                static_cast<std::int64_t>(bits.size()), static_cast<std::uint8_t*>(d_f.get())));
+    ksc::Check(ksh_ctx_sync(ksc::Ctx()));
+    const std::vector<std::uint8_t> f = d_f.ToHost<std::uint8_t>(bits.size());
+    return std::vector<bool>(f.begin(), f.end());
   }
 
   void Reserve(std::int64_t) {}
@@ -190,23 +204,16 @@ class KmerSet {
     return ksh_set_view{static_cast<const std::int64_t*>(offsets_.get()), keys_.get(), n_};
   }
 
-  // Ascending bit patterns of all k-mers (downloaded once, cached).
+  // Ascending bit patterns of all k-mers: expanded on the device, downloaded once, cached.
   const std::vector<std::uint64_t>& HostBits() const {
     Flush();
     if (!host_valid_) {
-      const std::vector<std::int64_t> off = offsets_.ToHost<std::int64_t>(kBucketsNum + 1);
-      host_.assign(static_cast<std::size_t>(n_), 0);
-      if (kDeviceKeyBytes == 4) {
-        const std::vector<std::uint32_t> keys = keys_.ToHost<std::uint32_t>(static_cast<std::size_t>(n_));
-        for (int b = 0; b < kBucketsNum; b++)
-          for (std::int64_t i = off[b]; i < off[b + 1]; i++)
-            host_[i] = (std::uint64_t(b) << kKeyBits) | keys[i];
-      } else {
-        const std::vector<std::uint64_t> keys = keys_.ToHost<std::uint64_t>(static_cast<std::size_t>(n_));
-        for (int b = 0; b < kBucketsNum; b++)
-          for (std::int64_t i = off[b]; i < off[b + 1]; i++)
-            host_[i] = (std::uint64_t(b) << kKeyBits) | keys[i];
-      }
+      ksc::DeviceBuffer d_bits(static_cast<std::size_t>(n_) * 8);
+      const ksh_geom g = Geom();
+      const ksh_set_view v{static_cast<const std::int64_t*>(offsets_.get()), keys_.get(), n_};
+      ksc::Check(ksh_set_kmers(ksc::Ctx(), &g, &v, static_cast<std::uint64_t*>(d_bits.get())));
+      ksc::Check(ksh_ctx_sync(ksc::Ctx()));
+      host_ = d_bits.ToHost<std::uint64_t>(static_cast<std::size_t>(n_));
       host_valid_ = true;
     }
     return host_;

@@ -8,12 +8,15 @@
 #ifndef KSC_CORE_KMER_SET_SET_H_
 #define KSC_CORE_KMER_SET_SET_H_
 
+#include <algorithm>
+#include <atomic>
 #include <cstdint>
 #include <filesystem>
 #include <map>
 #include <queue>
 #include <sstream>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -164,15 +167,36 @@ class KmerSetSet {
       ksc::Status status = ksc::WriteLines((dir / ("meta." + extension)).string(), compressor, v);
       if (!status.ok()) return status;
     }
-    int fail_count = 0;
+    // One writer per worker, a node's file per task (kmer_set_set.h:497-519): each writer thread has
+    // its own device context (ksc::Ctx() is per thread), spells its node's lines on the GPU and feeds
+    // its own file or compressor pipe, so the (de)compressor processes of different nodes overlap.
+    // After a sharded construction a node's file is written by the rank that holds it (the inputs,
+    // held everywhere, by rank 0).
+    std::vector<std::size_t> mine;
     for (std::size_t i = 0; i < kmer_sets_compact_.size(); i++) {
-      // after a sharded construction a node's file is written by the rank that holds it (the
-      // inputs, held everywhere, by rank 0)
       const int holder = Holder(static_cast<int>(i));
-      if (holder >= 0 ? holder != my_rank_ : my_rank_ != 0) continue;
-      const ksc::Status status = kmer_sets_compact_[i].Dump(
-          (dir / (std::to_string(i) + "." + extension)).string(), compressor, n_workers);
-      if (!status.ok()) fail_count += 1;
+      if (holder >= 0 ? holder == my_rank_ : my_rank_ == 0) mine.push_back(i);
+    }
+    std::atomic<std::size_t> next{0};
+    std::atomic<int> fail_count{0};
+    const auto writer = [&] {
+      for (std::size_t q = next++; q < mine.size(); q = next++) {
+        const std::size_t i = mine[q];
+        ksc::Status status = ksc::InternalError("exception");
+        try {
+          status = kmer_sets_compact_[i].Dump((dir / (std::to_string(i) + "." + extension)).string(), compressor, 1);
+        } catch (...) {
+        }
+        if (!status.ok()) fail_count += 1;
+      }
+    };
+    const int n_threads = std::max(1, std::min<int>(n_workers, static_cast<int>(mine.size())));
+    if (n_threads == 1) {
+      writer();
+    } else {
+      std::vector<std::thread> pool;
+      for (int w = 0; w < n_threads; w++) pool.emplace_back(writer);
+      for (std::thread& t : pool) t.join();
     }
     if (fail_count > 0) return ksc::InternalError("failed to write " + std::to_string(fail_count) + " files");
     return ksc::OkStatus();

@@ -1,6 +1,7 @@
 // Context, errors, device plumbing, prefix sum and the XOR-hash reduction.
 // gfx950 only; wavefront = 64.
 #include "ksh_internal.h"
+#include "ksh_kmer.h"
 #include "ksh_scan.h"
 
 #include <algorithm>
@@ -374,6 +375,29 @@ __global__ __launch_bounds__(256) void k_xor_buckets(const int64_t* __restrict__
 
 using namespace ksh;
 
+namespace ksh {
+
+// KmerSet::Contains (kmer_set.h:99-105), batched: one thread per query, a search in its bucket.
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_contains(DevSet<KeyT> set, const uint64_t* __restrict__ kmers, int64_t n,
+                                                   uint8_t* __restrict__ found) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t z = kmers[i];
+  found[i] = (z >> set.key_bits) < uint64_t(set.n_buckets) && set.find(z) >= 0 ? 1 : 0;
+}
+
+// KmerSet::Find(n_workers) (kmer_set.h:157-161): every k-mer as its full 2K-bit pattern, ascending.
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_expand_kmers(DevSet<KeyT> set, uint64_t* __restrict__ out) {
+  __shared__ int64_t s_bucket[2];
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const uint64_t x = set.kmer_in_block(t, s_bucket);
+  if (t < set.n) out[t] = x;
+}
+
+}  // namespace ksh
+
 extern "C" {
 
 int ksh_version(void) { return 1; }
@@ -409,19 +433,28 @@ int ksh_free(int device, void* d_ptr) {
 
 int ksh_memcpy_h2d(int device, void* d_dst, const void* src, size_t bytes) {
   KSH_HIP(hipSetDevice(device));
-  if (bytes) KSH_HIP(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+  if (bytes) {
+    KSH_HIP(hipDeviceSynchronize());  // whatever stream produced / still reads the buffer: a context's stream need not be a blocking one
+    KSH_HIP(hipMemcpy(d_dst, src, bytes, hipMemcpyHostToDevice));
+  }
   return KSH_OK;
 }
 
 int ksh_memcpy_d2h(int device, void* dst, const void* d_src, size_t bytes) {
   KSH_HIP(hipSetDevice(device));
-  if (bytes) KSH_HIP(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+  if (bytes) {
+    KSH_HIP(hipDeviceSynchronize());  // whatever stream produced / still reads the buffer: a context's stream need not be a blocking one
+    KSH_HIP(hipMemcpy(dst, d_src, bytes, hipMemcpyDeviceToHost));
+  }
   return KSH_OK;
 }
 
 int ksh_memcpy_d2d(int device, void* d_dst, const void* d_src, size_t bytes) {
   KSH_HIP(hipSetDevice(device));
-  if (bytes) KSH_HIP(hipMemcpy(d_dst, d_src, bytes, hipMemcpyDeviceToDevice));
+  if (bytes) {
+    KSH_HIP(hipDeviceSynchronize());  // whatever stream produced / still reads the buffer: a context's stream need not be a blocking one
+    KSH_HIP(hipMemcpy(d_dst, d_src, bytes, hipMemcpyDeviceToDevice));
+  }
   return KSH_OK;
 }
 
@@ -536,6 +569,44 @@ int ksh_ctx_timing_read(ksh_ctx* ctx, int kind, float* total_ms, int64_t* launch
   return KSH_OK;
 }
 
+int ksh_set_contains(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* s, const uint64_t* d_kmers, int64_t n,
+                     uint8_t* d_found) {
+  if (!ctx || !s || (n > 0 && (!d_kmers || !d_found))) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  KSH_TRY(check_geom(g));
+  KSH_TRY(check_view(s, "s"));
+  if (n <= 0) return KSH_OK;
+  KSH_HIP(hipSetDevice(ctx->device));
+  const unsigned blocks = unsigned((n + 255) / 256);
+  if (g->key_bytes == 4) {
+    DevSet<uint32_t> set{s->d_offsets, static_cast<const uint32_t*>(s->d_keys), n_buckets(g), s->n_keys, g->k, key_bits(g)};
+    hipLaunchKernelGGL(k_contains<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream, set, d_kmers, n, d_found);
+  } else {
+    DevSet<uint64_t> set{s->d_offsets, static_cast<const uint64_t*>(s->d_keys), n_buckets(g), s->n_keys, g->k, key_bits(g)};
+    hipLaunchKernelGGL(k_contains<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream, set, d_kmers, n, d_found);
+  }
+  KSH_HIP(hipGetLastError());
+  return KSH_OK;
+}
+
+int ksh_set_kmers(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* s, uint64_t* d_kmers) {
+  if (!ctx || !s) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  KSH_TRY(check_geom(g));
+  KSH_TRY(check_view(s, "s"));
+  if (s->n_keys == 0) return KSH_OK;
+  if (!d_kmers) return fail(KSH_INVALID_ARGUMENT, "NULL output");
+  KSH_HIP(hipSetDevice(ctx->device));
+  const unsigned blocks = unsigned((s->n_keys + 255) / 256);
+  if (g->key_bytes == 4) {
+    DevSet<uint32_t> set{s->d_offsets, static_cast<const uint32_t*>(s->d_keys), n_buckets(g), s->n_keys, g->k, key_bits(g)};
+    hipLaunchKernelGGL(k_expand_kmers<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream, set, d_kmers);
+  } else {
+    DevSet<uint64_t> set{s->d_offsets, static_cast<const uint64_t*>(s->d_keys), n_buckets(g), s->n_keys, g->k, key_bits(g)};
+    hipLaunchKernelGGL(k_expand_kmers<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream, set, d_kmers);
+  }
+  KSH_HIP(hipGetLastError());
+  return KSH_OK;
+}
+
 int ksh_ctx_timing_units(ksh_ctx* ctx, int kind, int64_t* units) {
   if (!ctx || !units) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
   if (kind < 0 || kind >= kNumTimers) return fail(KSH_INVALID_ARGUMENT, "no timer kind %d", kind);
@@ -546,9 +617,11 @@ int ksh_ctx_timing_units(ksh_ctx* ctx, int kind, int64_t* units) {
 int ksh_set_hash(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* s, uint64_t* hash) {
   if (!ctx || !s || !hash) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
   KSH_TRY(check_geom(g));
+  KSH_TRY(check_view(s, "s"));  // the key reduction reads 16-byte vectors
   KSH_HIP(hipSetDevice(ctx->device));
   arena_reset(ctx);
   unsigned long long* d_acc = static_cast<unsigned long long*>(arena_alloc(ctx, 8));
+  if (!d_acc) return fail(KSH_INTERNAL, "scratch arena too small");
   KSH_HIP(hipMemsetAsync(d_acc, 0, 8, ctx->stream));
   const int64_t nb = n_buckets(g);
   if (s->n_keys > 0) {

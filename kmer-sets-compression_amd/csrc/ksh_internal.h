@@ -121,6 +121,7 @@ void pool_free(ksh_ctx* ctx, void* p);
 void pool_trim(ksh_ctx* ctx);
 
 int check_geom(const ksh_geom* g);
+int check_view(const ksh_set_view* v, const char* name);  // ksh_pair.hip
 inline int64_t n_buckets(const ksh_geom* g) { return int64_t(1) << g->n_bucket_bits; }
 inline int key_bits(const ksh_geom* g) { return 2 * g->k - g->n_bucket_bits; }
 

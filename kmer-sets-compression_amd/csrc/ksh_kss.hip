@@ -174,6 +174,8 @@ static int ensure_compacts(ksh_kss* k) {
                    [&](size_t a, size_t b) { return k->sets[stale[a]].n > k->sets[stale[b]].n; });
   std::vector<int64_t> load(size_t(k->world), 0);
   std::vector<int> holder_of(stale.size(), 0);
+  int local_rc = KSH_OK;
+  std::string local_msg;
   for (size_t q : order) {
     int best = 0;
     for (int r = 1; r < k->world; r++)
@@ -185,20 +187,27 @@ static int ensure_compacts(ksh_kss* k) {
     const size_t i = stale[q];
     const int holder = holder_of[q];
     KssCompact c;
-    if (holder == k->rank) {
-      KSH_TRY(encode_set(k->ctx, &k->g, k->sets[i], k->canonical, &c));
-      k->n_encodes++;
-      k->n_encoded_kmers += k->sets[i].n;
-      send[2 * q] = c.n_strings;
-      send[2 * q + 1] = c.n_bases;
-    } else {
-      c.size = k->sets[i].n;
+    if (holder == k->rank && local_rc == KSH_OK) {
+      // a failure here must not keep this rank from the all-gather the others are heading for:
+      // its slots stay -1 and every rank returns an error after the exchange
+      local_rc = encode_set(k->ctx, &k->g, k->sets[i], k->canonical, &c);
+      if (local_rc == KSH_OK) {
+        k->n_encodes++;
+        k->n_encoded_kmers += k->sets[i].n;
+        send[2 * q] = c.n_strings;
+        send[2 * q + 1] = c.n_bases;
+      } else {
+        local_msg = ksh_last_error();
+        c = KssCompact{};
+      }
     }
+    if (holder != k->rank) c.size = k->sets[i].n;
     c.holder = holder;
     k->compacts[i] = c;
   }
   if (k->gather(k->gather_user, send.data(), int64_t(send.size()), recv.data()) != 0)
     return fail(KSH_INTERNAL, "the all-gather callback of the sharded build failed");
+  if (local_rc != KSH_OK) return fail(local_rc, "%s", local_msg.c_str());
   for (size_t q = 0; q < stale.size(); q++) {
     KssCompact& c = k->compacts[stale[q]];
     const int64_t* from = recv.data() + size_t(c.holder) * send.size() + 2 * q;
@@ -231,14 +240,21 @@ static int pair_weights(ksh_kss* k, const std::vector<int32_t>& ids,
     flat.push_back(pairs[q].first);
     flat.push_back(pairs[q].second);
   }
-  if (hi > lo)
-    KSH_TRY(ksh_pair_weights(k->ctx, &k->g, views.data(), int32_t(views.size()), ids.data(),
-                             int32_t(ids.size()), flat.data(), int32_t(hi - lo), out->data() + lo));
-  if (!shard) return KSH_OK;
+  int local_rc = KSH_OK;
+  std::string local_msg;
+  if (hi > lo) {
+    local_rc = ksh_pair_weights(k->ctx, &k->g, views.data(), int32_t(views.size()), ids.data(),
+                                int32_t(ids.size()), flat.data(), int32_t(hi - lo), out->data() + lo);
+    if (local_rc != KSH_OK) local_msg = ksh_last_error();
+  }
+  if (!shard) return local_rc == KSH_OK ? KSH_OK : fail(local_rc, "%s", local_msg.c_str());
+  // (a rank that failed still takes part in the exchange: its slots stay -1)
   std::vector<int64_t> send(per, -1), recv(per * size_t(k->world), -1);
-  for (size_t q = lo; q < hi; q++) send[q - lo] = (*out)[q];
+  if (local_rc == KSH_OK)
+    for (size_t q = lo; q < hi; q++) send[q - lo] = (*out)[q];
   if (k->gather(k->gather_user, send.data(), int64_t(per), recv.data()) != 0)
     return fail(KSH_INTERNAL, "the all-gather callback of the sharded build failed");
+  if (local_rc != KSH_OK) return fail(local_rc, "%s", local_msg.c_str());
   for (size_t q = 0; q < pairs.size(); q++) {
     const int64_t w = recv[(q / per) * per + q % per];
     if (w < 0) return fail(KSH_INTERNAL, "rank %zu did not report the weight of pair %zu", q / per, q);
@@ -365,22 +381,31 @@ static int ensure_compacts_owned(ksh_kss* k) {
     if (!k->compacts[i].valid) stale.push_back(i);
   if (stale.empty()) return KSH_OK;
   std::vector<int64_t> send(3 * stale.size(), -1), recv;
+  int local_rc = KSH_OK;
+  std::string local_msg;
   for (size_t q = 0; q < stale.size(); q++) {
     const size_t i = stale[q];
     KssCompact c;
     c.holder = k->owner[i];
-    if (k->owner[i] == k->rank) {
-      KSH_TRY(encode_set(k->ctx, &k->g, k->sets[i], k->canonical, &c));
+    if (k->owner[i] == k->rank && local_rc == KSH_OK) {
+      // a failure must not keep this rank from the all-gather: its slots stay -1, every rank errors out after it
+      local_rc = encode_set(k->ctx, &k->g, k->sets[i], k->canonical, &c);
+      if (local_rc == KSH_OK) {
+        k->n_encodes++;
+        k->n_encoded_kmers += k->sets[i].n;
+        send[3 * q] = c.n_strings;
+        send[3 * q + 1] = c.n_bases;
+        send[3 * q + 2] = c.size;
+      } else {
+        local_msg = ksh_last_error();
+        c = KssCompact{};
+      }
       c.holder = k->rank;
-      k->n_encodes++;
-      k->n_encoded_kmers += k->sets[i].n;
-      send[3 * q] = c.n_strings;
-      send[3 * q + 1] = c.n_bases;
-      send[3 * q + 2] = c.size;
     }
     k->compacts[i] = c;
   }
   KSH_TRY(gather_i64(k, send, &recv));
+  if (local_rc != KSH_OK) return fail(local_rc, "%s", local_msg.c_str());
   for (size_t q = 0; q < stale.size(); q++) {
     KssCompact& c = k->compacts[stale[q]];
     const int64_t* from = recv.data() + size_t(c.holder) * send.size() + 3 * q;

@@ -102,6 +102,8 @@ def lib():
         "ksh_ctx_timing_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(i64)]),
         "ksh_ctx_timing_units": (C.c_int, [vp, C.c_int, C.POINTER(i64)]),
         "ksh_set_hash": (C.c_int, [vp, GP, SP, C.POINTER(C.c_uint64)]),
+        "ksh_set_contains": (C.c_int, [vp, GP, SP, vp, i64, vp]),
+        "ksh_set_kmers": (C.c_int, [vp, GP, SP, vp]),
         "ksh_pair_plan": (C.c_int, [vp, GP, SP, SP, vp, vp, vp, C.POINTER(i64)]),
         "ksh_pair_write": (C.c_int, [vp, GP, SP, SP, vp, vp, vp]),
         "ksh_set_diff": (C.c_int, [vp, GP, SP, SP, C.POINTER(i64)]),
@@ -377,6 +379,26 @@ class Context:
         v = s.view()
         check(lib().ksh_set_hash(self.h, C.byref(s.g), C.byref(v), C.byref(out)))
         return out.value
+
+    # KmerSet::Contains / Find -----------------------------------------------------------
+    def set_contains(self, s, kmers):
+        """bool array: which of the 2K-bit patterns `kmers` are in the set (one launch)."""
+        import torch
+
+        q = torch.from_numpy(np.ascontiguousarray(kmers, dtype=np.uint64).view(np.int64).copy()).to(self.device)
+        out = torch.zeros(max(q.numel(), 1), dtype=torch.uint8, device=self.device)
+        v = s.view()
+        check(lib().ksh_set_contains(self.h, C.byref(s.g), C.byref(v), q.data_ptr(), q.numel(), out.data_ptr()))
+        return out[: q.numel()].cpu().numpy().astype(bool)
+
+    def set_kmers(self, s):
+        """All k-mers of the set as uint64 bit patterns, ascending (expanded on the device)."""
+        import torch
+
+        out = torch.empty(max(s.n_keys, 1), dtype=torch.int64, device=self.device)
+        v = s.view()
+        check(lib().ksh_set_kmers(self.h, C.byref(s.g), C.byref(v), out.data_ptr()))
+        return out[: s.n_keys].cpu().numpy().view(np.uint64)
 
     # Intersection / Sub -----------------------------------------------------------
     def pair_plan(self, a, b, out_i, out_amb, out_bma):

@@ -1,0 +1,94 @@
+"""BASELINE.json's configurations at their FULL sizes, through size-independent properties (the oracle
+finishes such sizes in hours, so it checks the same code at small sizes in the other files):
+
+* configs[2]: 16 canonical k=23 sets of 10^8 k-mers, the whole KmerSetSet loop on one GPU;
+* the same at k=31 (64-bit keys), 8 sets of 5 * 10^8: configs[4]'s geometry at what one GPU's share is.
+
+Checked: Size and XOR Hash of Get(i) == those of the decoded input for every i (the reference's own
+--check, src/kmerset-multiple-compress.cc:104-126); DAG invariants (every merge adds one node and two
+child links, children have larger indices, the reachable nodes of an input are pairwise disjoint and
+their sizes add up); the trace's sizes are consistent with the nodes; total SPSS weight never grows at
+a checkpoint that continues; two builds of the same inputs agree in every number (bytes/k-mer included).
+"""
+import numpy as np
+import pytest
+
+from kmersets import capi, synth, synth_torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx(gpu):
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _loop_properties(ctx, k, n_sets, size, seed):
+    import torch
+
+    g = capi.geom(k, 14)
+    kmers = synth_torch.phylogeny_sets(k, n_sets, size, seed, ctx.device)
+    sizes = [int(x.numel()) for x in kmers]
+    compacts = []
+    for i in range(n_sets):
+        compacts.append(ctx.spss_encode(synth_torch.device_set(g, kmers[i]), mode=0))
+        kmers[i] = None
+    del kmers
+    torch.cuda.empty_cache()
+    ids = synth.sample_bucket_ids(14, seed=seed + 1)
+    results = []
+    for _ in range(2):
+        kss = capi.DeviceKmerSetSet(ctx, compacts, ids)
+        st = kss.stats()
+        it, cp, imp = kss.trace()
+        n_nodes = kss.size()
+        # ---- DAG
+        assert n_nodes == n_sets + len(it) and st["nodes"] == n_nodes
+        children = [kss.children(i) for i in range(n_nodes)]
+        assert sum(len(c) for c in children) == 2 * len(it)
+        for t, (j, kk, weight, original, diff) in enumerate(it.tolist()):
+            new = n_sets + t
+            assert j < kk < new and weight > 0
+            assert new in children[j] and new in children[kk]
+        assert all(c > i for i, cs in enumerate(children) for c in cs)
+        node_sizes = [kss.node_size(i) for i in range(n_nodes)]
+        assert sum(node_sizes) == st["final_total_size"]
+        assert st["initial_total_size"] == sum(sizes)
+        assert st["initial_total_size"] + int(it[:, 4].sum()) == st["final_total_size"]
+        assert st["n_processed"] == sum(sizes) + int(it[:, 3].sum())
+        # ---- Get(i) == input i (Size, XOR Hash), and the reachable nodes add up
+        for i in range(n_sets):
+            want = ctx.spss_decode(compacts[i])
+            assert want.n_keys == sizes[i]
+            assert kss.get_size_and_hash(i) == (want.n_keys, ctx.set_hash(want)), i
+            del want
+            seen, todo = set(), [i]
+            while todo:
+                cur = todo.pop()
+                if cur not in seen:
+                    seen.add(cur)
+                    todo.extend(children[cur])
+            assert sum(node_sizes[x] for x in seen) == sizes[i]
+        # ---- checkpoints: a checkpoint that lets the loop go on saw the weight shrink
+        for (iteration, previous, updated, stopped), improvement in zip(cp.tolist(), imp.tolist()):
+            assert stopped or updated < previous
+            assert abs(improvement - (previous - updated) / previous) < 1e-6
+        assert st["final_spss_weight"] <= st["initial_spss_weight"]
+        results.append((st["n_processed"], st["final_spss_weight"], st["packed_bytes"], st["length_bytes"], n_nodes,
+                        it.tolist(), cp.tolist()))
+        kss.close()
+    assert results[0] == results[1]          # deterministic: bytes/k-mer equal across two builds
+    return results[0]
+
+
+def test_config3_16x1e8_k23(ctx):
+    n_proc, weight, packed, lens, nodes, it, cp = _loop_properties(ctx, 23, 16, int(1e8), seed=3)
+    assert len(it) >= 8 and nodes > 16
+    assert (packed + lens) / (16 * 1e8) < 0.26          # below the 2 bits per k-mer of the unmerged sets
+
+
+def test_k31_8x5e8(ctx):
+    n_proc, weight, packed, lens, nodes, it, cp = _loop_properties(ctx, 31, 8, int(5e8), seed=5)
+    assert len(it) >= 4 and nodes > 8

@@ -106,6 +106,32 @@ def test_pair_algebra_vs_oracle(ctx, geom):
     check_algebra(ctx, k, n, kb, ua, ub)
 
 
+@pytest.mark.parametrize("geom", GEOMS)
+def test_contains_and_find_vs_oracle(ctx, geom):
+    """KmerSet::Contains (batched) and Find(n_workers) through the C ABI (ksh_set_contains,
+    ksh_set_kmers) against the oracle's hash-bucket set: members, near misses (a member's four
+    Next / Prev candidates, as the unitig walk asks), values in empty buckets, and the empty set."""
+    k, n, kb = geom
+    size = 150 if k == 5 else 20000
+    kmers = synth.phylogeny_sets(k, 2, size, seed=k + 40)[0]
+    d = dev_set(ctx, k, n, kmers)
+    o = ol.Set.from_kmers(k, n, kb, kmers)
+    mask = np.uint64((1 << (2 * k)) - 1)
+    some = kmers[:: max(1, kmers.size // 500)]
+    nexts = np.concatenate([((some << np.uint64(2)) & mask) | np.uint64(c) for c in range(4)])
+    prevs = np.concatenate([(some >> np.uint64(2)) | (np.uint64(c) << np.uint64(2 * k - 2)) for c in range(4)])
+    rnd = synth.mix64(np.arange(2000, dtype=np.uint64) + np.uint64(k)) & mask
+    queries = np.concatenate([some, nexts, prevs, rnd, np.array([0, int(mask)], dtype=np.uint64)])
+    got = ctx.set_contains(d, queries)
+    want = np.array([bool(o.contains(int(q))) for q in queries])
+    assert np.array_equal(got, want)
+    assert got[: some.size].all() and not got.all()
+    assert np.array_equal(ctx.set_kmers(d), o.kmers())
+    empty = dev_set(ctx, k, n, np.zeros(0, dtype=np.uint64))
+    assert not ctx.set_contains(empty, queries[:50]).any() and ctx.set_kmers(empty).size == 0
+    assert ctx.set_contains(d, np.zeros(0, dtype=np.uint64)).size == 0
+
+
 @pytest.mark.parametrize("geom", [(23, 14, 4), (31, 14, 8)])
 def test_pair_algebra_edge_cases(ctx, geom):
     k, n, kb = geom
@@ -169,12 +195,12 @@ def test_pair_weights_vs_oracle(ctx):
 
 
 def test_config2_properties(ctx):
-    """BASELINE config 2 (4 x 10^7 canonical k=23 sets, all 6 pairs) through
-    size-independent properties; sized down by KMERSETS_TEST_SCALE if set."""
+    """BASELINE config 2 at its full size (4 x 10^7 canonical k=23 sets, all 6 pairs) through
+    size-independent properties; KMERSETS_TEST_SIZE sizes it down."""
     import torch
 
     k, n = 23, 14
-    size = int(float(os.environ.get("KMERSETS_TEST_SIZE", "2e6")))
+    size = int(float(os.environ.get("KMERSETS_TEST_SIZE", "1e7")))
     sets = synth.phylogeny_sets(k, 4, size, seed=2)
     d = [dev_set(ctx, k, n, s) for s in sets]
     hashes = [ctx.set_hash(x) for x in d]

@@ -114,6 +114,14 @@ int ksh_set_contains(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* s, con
                      uint8_t* d_found);
 int ksh_set_kmers(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* s, uint64_t* d_kmers);
 
+/* ---- ParallelDisjointSet  (lib/core/parallel_disjoint_set.h:15-111) ---------------------------
+ * The wait-free union-find the path cover's loop detection runs on (spss.h:1541-1625), as an entry
+ * of its own: n nodes, m pairs (d_x[i], d_y[i]) united concurrently (one thread per pair, 64-bit
+ * compare-and-swap on rank << 32 | parent), then d_root[i] = Find(i).  WHICH node represents a
+ * component depends on the interleaving, as in the reference with n_workers > 1; the partition
+ * does not.  Synchronises the stream. */
+int ksh_dsu_components(ksh_ctx* ctx, int64_t n, const int32_t* d_x, const int32_t* d_y, int64_t m, int32_t* d_root);
+
 /* ---- set algebra  (lib/core/kmer_set.h:164-187, :286-305; the loop needs
  *      A&B, A\B and B\A of one pair, lib/core/kmer_set_set.h:339-343) ------------------ */
 /* Pass 1.  Counts |A & B| per bucket and derives the bucket offsets of the three

@@ -1,6 +1,7 @@
 // Context, errors, device plumbing, prefix sum and the XOR-hash reduction.
 // gfx950 only; wavefront = 64.
 #include "ksh_internal.h"
+#include "ksh_dsu.h"
 #include "ksh_kmer.h"
 #include "ksh_scan.h"
 
@@ -387,6 +388,20 @@ __global__ __launch_bounds__(256) void k_contains(DevSet<KeyT> set, const uint64
   found[i] = (z >> set.key_bits) < uint64_t(set.n_buckets) && set.find(z) >= 0 ? 1 : 0;
 }
 
+__global__ __launch_bounds__(256) void k_dsu_reset(unsigned long long* __restrict__ a, int64_t n) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) a[i] = (unsigned long long)i;
+}
+__global__ __launch_bounds__(256) void k_dsu_unite_pairs(DevDsu dsu, const int32_t* __restrict__ x,
+                                                          const int32_t* __restrict__ y, int64_t m) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < m) dsu.unite(uint32_t(x[i]), uint32_t(y[i]));
+}
+__global__ __launch_bounds__(256) void k_dsu_roots(DevDsu dsu, int64_t n, int32_t* __restrict__ root) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n) root[i] = int32_t(dsu.find(uint32_t(i)));
+}
+
 // KmerSet::Find(n_workers) (kmer_set.h:157-161): every k-mer as its full 2K-bit pattern, ascending.
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_expand_kmers(DevSet<KeyT> set, uint64_t* __restrict__ out) {
@@ -566,6 +581,24 @@ int ksh_ctx_timing_read(ksh_ctx* ctx, int kind, float* total_ms, int64_t* launch
   }
   *total_ms = float(sum);
   *launches = int64_t(ctx->ev_spans[kind].size());
+  return KSH_OK;
+}
+
+int ksh_dsu_components(ksh_ctx* ctx, int64_t n, const int32_t* d_x, const int32_t* d_y, int64_t m, int32_t* d_root) {
+  if (!ctx || (n > 0 && !d_root) || (m > 0 && (!d_x || !d_y))) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  if (n < 0 || m < 0 || n > int64_t(0x7FFFFFF0)) return fail(KSH_INVALID_ARGUMENT, "bad node / pair count");
+  if (n == 0) return KSH_OK;
+  KSH_HIP(hipSetDevice(ctx->device));
+  void* words = nullptr;
+  KSH_TRY(pool_alloc(ctx, size_t(n) * 8, &words));
+  DevDsu dsu{static_cast<unsigned long long*>(words)};
+  hipLaunchKernelGGL(k_dsu_reset, dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, dsu.a, n);
+  if (m > 0)
+    hipLaunchKernelGGL(k_dsu_unite_pairs, dim3(unsigned((m + 255) / 256)), dim3(256), 0, ctx->stream, dsu, d_x, d_y, m);
+  hipLaunchKernelGGL(k_dsu_roots, dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, dsu, n, d_root);
+  KSH_HIP(hipGetLastError());
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  pool_free(ctx, words);
   return KSH_OK;
 }
 

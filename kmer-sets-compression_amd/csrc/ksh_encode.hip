@@ -24,13 +24,15 @@
 //   k_edges       <= 4 edges per unitig side, in the reference's enumeration order
 //   k_match_*     lexicographically-first maximal matching by rounds of mutual minima
 //                 == the sequential greedy sweep of spss.h:1445-1499
-//   k_cover_mark / k_loop_cut    loops of the path cover, cut where the reference's
-//                 union-by-rank root says (spss.h:1541-1647)
-//   k_string_*    stitch order and orientation (spss.h:1649-1829)
+//   k_dsu_* / k_loop_cut    loops of the path cover: components by parallel union-find, a loop cut
+//                 where the reference's union-by-rank root says (spss.h:1541-1647)
+//   k_walk_* / k_string_*    walks over the path cover ranked by pointer jumping; stitch order and
+//                 orientation (spss.h:1649-1829)
 //   k_emit / k_pack   bases -> 2-bit words, len - K per string
 //
 // All of it is integer gather/scatter work bounded by HBM random-access rate; no MFMA.
 #include "ksh_internal.h"
+#include "ksh_dsu.h"
 #include "ksh_kmer.h"
 
 #include <algorithm>
@@ -1241,22 +1243,41 @@ __global__ __launch_bounds__(64) void k_match_slow(const uint32_t* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------- E6
-__global__ __launch_bounds__(256) void k_cover_mark(const uint32_t* __restrict__ mate, int64_t n_u,
-                                                     uint8_t* __restrict__ visited) {
+// Loops of the path cover, the reference's way (spss.h:1541-1625): every chosen edge united in a
+// ParallelDisjointSet, a component with no node that misses an edge is a loop.  (Round 1 walked
+// every open path from its ends with one thread per path; a set with bubbles stitches 10^5..10^6
+// unitigs into one path.)
+__global__ __launch_bounds__(256) void k_dsu_init(unsigned long long* __restrict__ a, int64_t n_u) {
+  const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (u < n_u) a[u] = (unsigned long long)u;
+}
+
+// One thread per vertex v = 2u + side with an edge; the edge {v, mate[v]} is united once, by its
+// smaller vertex (the reference unites it from both ends, :1551-1566; the second call finds both
+// in one component already).
+__global__ __launch_bounds__(256) void k_dsu_unite_mates(DevDsu dsu, const uint32_t* __restrict__ mate,
+                                                          int64_t n_vertices) {
+  const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (v >= n_vertices) return;
+  const uint32_t w = mate[v];
+  if (w == kNone || w < uint32_t(v)) return;
+  dsu.unite(uint32_t(v >> 1), w >> 1);
+}
+
+// has_terminal[root] = 1 for every component with a node that misses an edge (:1584-1612)
+__global__ __launch_bounds__(256) void k_dsu_mark_terminals(DevDsu dsu, const uint32_t* __restrict__ mate, int64_t n_u,
+                                                             uint8_t* __restrict__ has_terminal) {
   const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (u >= n_u) return;
-  const bool hl = mate[2 * u] != kNone, hr = mate[2 * u + 1] != kNone;
-  if (hl && hr) return;
-  uint32_t cur = uint32_t(u);
-  bool going_right = !hl;
-  int64_t steps = 0;
-  while (true) {
-    visited[cur] = 1;
-    const uint32_t w = mate[2 * int64_t(cur) + (going_right ? 1 : 0)];
-    if (w == kNone || steps++ > n_u) break;
-    cur = w >> 1;
-    going_right = (w & 1) == 0;
-  }
+  if (mate[2 * u] == kNone || mate[2 * u + 1] == kNone) has_terminal[dsu.find(uint32_t(u))] = 1;
+}
+
+// visited[u] = 1: u lies on an open path; 0: on a loop
+__global__ __launch_bounds__(256) void k_dsu_open_paths(DevDsu dsu, const uint8_t* __restrict__ has_terminal,
+                                                         int64_t n_u, uint8_t* __restrict__ visited) {
+  const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (u >= n_u) return;
+  visited[u] = has_terminal[dsu.find(uint32_t(u))];
 }
 
 // One thread per loop of the path cover (the loop's smallest unitig).  Replays the
@@ -1371,12 +1392,54 @@ __global__ __launch_bounds__(64) void k_loop_cut(uint32_t* __restrict__ mate, in
 }
 
 // ---------------------------------------------------------------------------------- E7
+// Walks over the path cover, ranked instead of walked.  A walk is a sequence of states
+// S = 2u + going_right: it leaves unitig u through its right side (going_right) or its left one,
+// and the state after S is mate[S] ^ 1 (arrive through side w & 1 of unitig w >> 1, go on through
+// the other side).  Every state carries one word  done:1 | next:31 | weight:32 :
+//   not done: weight = k-mers of the unitigs from S up to, not including, state `next`;
+//   done:     weight = k-mers from S to the end of its walk, `next` = the walk's last state.
+// A state without a successor starts done (next = itself).  A round replaces (next, weight) of every
+// unfinished state by those of two hops (k_walk_jump); whatever snapshot of the successor's word a
+// thread reads satisfies the invariant, so the rounds need no double buffering; log2(longest path)
+// rounds.  After the loop cut there are no loops left, so every state finishes.
+// From the two states of a unitig everything the stitch needs follows without walking
+// (spss.h:1649-1829): the path's two end unitigs, the k-mers before it in either direction.
+constexpr unsigned long long kWalkDone = 1ull << 63;
+__device__ __forceinline__ unsigned long long make_walk(bool done, uint32_t next, uint32_t weight) {
+  return (done ? kWalkDone : 0) | ((unsigned long long)(next & 0x7FFFFFFFu) << 32) | weight;
+}
+__device__ __forceinline__ uint32_t walk_next(unsigned long long w) { return uint32_t(w >> 32) & 0x7FFFFFFFu; }
+__device__ __forceinline__ uint32_t walk_weight(unsigned long long w) { return uint32_t(w); }
+
+__global__ __launch_bounds__(256) void k_walk_init(const uint32_t* __restrict__ mate, const uint32_t* __restrict__ u_len,
+                                                    int64_t n_states, unsigned long long* __restrict__ walk) {
+  const int64_t s = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (s >= n_states) return;
+  const uint32_t w = mate[s];
+  walk[s] = w == kNone ? make_walk(true, uint32_t(s), u_len[s >> 1]) : make_walk(false, w ^ 1u, u_len[s >> 1]);
+}
+
+__global__ __launch_bounds__(256) void k_walk_jump(int64_t n_states, unsigned long long* __restrict__ walk,
+                                                    int* __restrict__ changed) {
+  const int64_t s = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (s >= n_states) return;
+  const unsigned long long mine = walk[s];
+  if (mine & kWalkDone) return;
+  const unsigned long long theirs =
+      __hip_atomic_load(&walk[walk_next(mine)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __hip_atomic_store(&walk[s],
+                     make_walk((theirs & kWalkDone) != 0, walk_next(theirs), walk_weight(mine) + walk_weight(theirs)),
+                     __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  *changed = 1;
+}
+
 // scls[u]: 0 = kept walk from a left terminal, 1 = kept walk from a right terminal,
 //          2 = isolated unitig, 0xFF = not the start of an output string.
 // directed: a string starts at every node without an incoming edge and runs forward
 // (spss.h:931-1011); isolated unitigs are class 0 like the others.
 __global__ __launch_bounds__(256) void k_string_starts(const uint32_t* __restrict__ mate,
                                                         const uint32_t* __restrict__ u_len,
+                                                        const unsigned long long* __restrict__ walk,
                                                         int64_t n_u, bool directed,
                                                         uint8_t* __restrict__ scls,
                                                         int64_t* __restrict__ s_nk) {
@@ -1387,31 +1450,17 @@ __global__ __launch_bounds__(256) void k_string_starts(const uint32_t* __restric
   int64_t nk = 0;
   if (directed) {
     if (!hl) {
-      uint32_t cur = uint32_t(u);
-      int64_t steps = 0;
-      while (true) {
-        nk += u_len[cur];
-        const uint32_t w = mate[2 * int64_t(cur) + 1];
-        if (w == kNone || steps++ > n_u) break;
-        cur = w >> 1;
-      }
+      nk = walk_weight(walk[2 * u + 1]);
       cls = 0;
     }
   } else if (!hl && !hr) {
     cls = 2;
     nk = u_len[u];
   } else if (!hl || !hr) {
-    uint32_t cur = uint32_t(u);
-    bool going_right = !hl;
-    int64_t steps = 0;
-    while (true) {
-      nk += u_len[cur];
-      const uint32_t w = mate[2 * int64_t(cur) + (going_right ? 1 : 0)];
-      if (w == kNone || steps++ > n_u) break;
-      cur = w >> 1;
-      going_right = (w & 1) == 0;
-    }
-    if (uint32_t(u) <= cur) cls = hl ? 1 : 0;  // path.front().first > path.back().first -> skipped
+    const unsigned long long w = walk[2 * u + (hl ? 0 : 1)];  // no left edge: the walk goes right
+    nk = walk_weight(w);
+    const uint32_t far_end = walk_next(w) >> 1;
+    if (uint32_t(u) <= far_end) cls = hl ? 1 : 0;  // path.front().first > path.back().first -> skipped
   }
   scls[u] = cls;
   s_nk[u] = nk;
@@ -1435,12 +1484,12 @@ __global__ __launch_bounds__(256) void k_string_counts(const uint8_t* __restrict
   }
 }
 
-__global__ __launch_bounds__(256) void k_string_assign(
-    const uint32_t* __restrict__ mate, const uint32_t* __restrict__ u_len, int64_t n_u,
-    const uint8_t* __restrict__ scls, const int64_t* __restrict__ c01,
+// The string of every start: its id (the reference's push order), its length.
+__global__ __launch_bounds__(256) void k_string_ids(
+    int64_t n_u, const uint8_t* __restrict__ scls, const int64_t* __restrict__ c01,
     const int64_t* __restrict__ c2, const int64_t* __restrict__ s_nk, int64_t base1, int64_t base2,
-    bool one_sequence, int k, uint32_t* __restrict__ u_sid, uint32_t* __restrict__ u_koff,
-    uint8_t* __restrict__ u_flip, uint32_t* __restrict__ lens, int64_t* __restrict__ str_bases) {
+    bool one_sequence, int k, uint32_t* __restrict__ sid_at, uint32_t* __restrict__ lens,
+    int64_t* __restrict__ str_bases) {
   const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (u >= n_u) return;
   const uint8_t c = scls[u];
@@ -1449,24 +1498,36 @@ __global__ __launch_bounds__(256) void k_string_assign(
   if (one_sequence || c == 0) sid = c01[u] & 0xFFFFFFFF;
   else if (c == 1) sid = base1 + (c01[u] >> 32);
   else sid = base2 + c2[u];
+  sid_at[u] = uint32_t(sid);
   lens[sid] = uint32_t(s_nk[u] - 1);
   str_bases[sid] = s_nk[u] + k - 1;
-  uint32_t cur = uint32_t(u);
-  // fast = false spells an isolated unitig through FindPath(i, false), i.e. reverse-complemented
-  bool going_right = c == 2 ? !one_sequence : c != 1;
-  uint32_t koff = 0;
-  int64_t steps = 0;
-  while (true) {
-    u_sid[cur] = uint32_t(sid);
-    u_koff[cur] = koff;
-    u_flip[cur] = going_right ? 0 : 1;
-    koff += u_len[cur];
-    if (c == 2) break;
-    const uint32_t w = mate[2 * int64_t(cur) + (going_right ? 1 : 0)];
-    if (w == kNone || steps++ > n_u) break;
-    cur = w >> 1;
-    going_right = (w & 1) == 0;
+}
+
+// Every unitig finds its string, its place in it and its orientation from its own two states: going
+// right it ends at e_r, going left at e_l; the string starts at whichever of the two is a start
+// (scls), runs towards the other one, and the k-mers before this unitig are those of the walk from
+// it BACK to the start, minus its own.
+__global__ __launch_bounds__(256) void k_string_assign(
+    const uint32_t* __restrict__ u_len, const unsigned long long* __restrict__ walk, int64_t n_u,
+    const uint8_t* __restrict__ scls, const uint32_t* __restrict__ sid_at, bool one_sequence,
+    uint32_t* __restrict__ u_sid, uint32_t* __restrict__ u_koff, uint8_t* __restrict__ u_flip) {
+  const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (u >= n_u) return;
+  const unsigned long long wr = walk[2 * u + 1], wl = walk[2 * u];
+  const uint32_t e_r = walk_next(wr) >> 1, e_l = walk_next(wl) >> 1;
+  if (e_r == uint32_t(u) && e_l == uint32_t(u)) {  // a string of its own
+    u_sid[u] = sid_at[u];
+    u_koff[u] = 0;
+    // fast = false spells an isolated unitig through FindPath(i, false), i.e. reverse-complemented
+    u_flip[u] = (scls[u] == 2 && one_sequence) ? 1 : 0;
+    return;
   }
+  // the start is the end that carries a class; a walk that starts at the left end passes u going right
+  const bool from_left = scls[e_l] != 0xFF;
+  const uint32_t start = from_left ? e_l : e_r;
+  u_sid[u] = sid_at[start];
+  u_koff[u] = (from_left ? walk_weight(wl) : walk_weight(wr)) - u_len[u];
+  u_flip[u] = from_left ? 0 : 1;
 }
 
 // GetUnitigsCanonical output: every unitig is its own string.
@@ -1852,14 +1913,34 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
         if (*reinterpret_cast<int*>(ctx->h_pinned) == 0) break;
         if (p->rounds > 100000) return fail(KSH_INTERNAL, "matching did not converge");
       }
-      // the path extension of fast = false never closes a loop; the greedy matching can
-      KSH_HIP(hipMemsetAsync(p->visited, 0, size_t(n_u), st));
+      // the path extension of fast = false never closes a loop; the greedy matching can:
+      // components of the chosen edges (parallel union-find), the ones without a terminal are loops
+      DevDsu dsu{reinterpret_cast<unsigned long long*>(p->sc01)};  // sc01 is only filled by k_string_counts
+      uint8_t* has_terminal = p->scls;                             // scls only by k_string_starts
+      hipLaunchKernelGGL(k_dsu_init, dim3(nblk(n_u)), dim3(256), 0, st, dsu.a, n_u);
+      hipLaunchKernelGGL(k_dsu_unite_mates, dim3(nblk(2 * n_u)), dim3(256), 0, st, dsu, p->mate, 2 * n_u);
+      KSH_HIP(hipMemsetAsync(has_terminal, 0, size_t(n_u), st));
+      hipLaunchKernelGGL(k_dsu_mark_terminals, dim3(nblk(n_u)), dim3(256), 0, st, dsu, p->mate, n_u, has_terminal);
+      hipLaunchKernelGGL(k_dsu_open_paths, dim3(nblk(n_u)), dim3(256), 0, st, dsu, has_terminal, n_u, p->visited);
       KSH_HIP(hipMemsetAsync(p->sc_used, 0, 8, st));
-      hipLaunchKernelGGL(k_cover_mark, dim3(nblk(n_u)), dim3(256), 0, st, p->mate, n_u, p->visited);
       hipLaunchKernelGGL(k_loop_cut, dim3(unsigned((n_u + 63) / 64)), dim3(64), 0, st, p->mate, n_u,
                          directed, p->visited, p->sc_nodes, p->sc_parent, p->sc_rank, p->sc_used);
     }
-    hipLaunchKernelGGL(k_string_starts, dim3(nblk(n_u)), dim3(256), 0, st, p->mate, p->u_len, n_u,
+    // the walks over the (now loop-free) path cover, by pointer jumping; the words reuse the
+    // matching's priorities, the string ids of the starts its candidates
+    unsigned long long* walk = p->best_prio;
+    uint32_t* sid_at = p->best_w;
+    hipLaunchKernelGGL(k_walk_init, dim3(nblk(2 * n_u)), dim3(256), 0, st, p->mate, p->u_len, 2 * n_u, walk);
+    for (int round = 0;; round += 4) {
+      KSH_HIP(hipMemsetAsync(p->any_live, 0, sizeof(int), st));
+      for (int b = 0; b < 4; b++)
+        hipLaunchKernelGGL(k_walk_jump, dim3(nblk(2 * n_u)), dim3(256), 0, st, 2 * n_u, walk, p->any_live);
+      KSH_HIP(hipMemcpyAsync(ctx->h_pinned, p->any_live, sizeof(int), hipMemcpyDeviceToHost, st));
+      KSH_HIP(hipStreamSynchronize(st));
+      if (*reinterpret_cast<int*>(ctx->h_pinned) == 0) break;
+      if (round > 64) return fail(KSH_INTERNAL, "the path cover still holds a loop");
+    }
+    hipLaunchKernelGGL(k_string_starts, dim3(nblk(n_u)), dim3(256), 0, st, p->mate, p->u_len, walk, n_u,
                        directed, p->scls, p->s_nk);
     hipLaunchKernelGGL(k_string_counts, dim3(nblk(n_u)), dim3(256), 0, st, p->scls, n_u, slow, p->sc01,
                        p->sc2);
@@ -1872,9 +1953,10 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     const int64_t s0 = ctx->h_pinned[0] & 0xFFFFFFFF, s1 = ctx->h_pinned[0] >> 32,
                   s2 = ctx->h_pinned[1];
     ns = s0 + s1 + s2;
-    hipLaunchKernelGGL(k_string_assign, dim3(nblk(n_u)), dim3(256), 0, st, p->mate, p->u_len, n_u,
-                       p->scls, p->sc01, p->sc2, p->s_nk, s0, s0 + s1, slow, g->k, p->u_sid, p->u_koff,
-                       p->u_flip, p->lens, p->str_start);
+    hipLaunchKernelGGL(k_string_ids, dim3(nblk(n_u)), dim3(256), 0, st, n_u, p->scls, p->sc01, p->sc2, p->s_nk, s0,
+                       s0 + s1, slow, g->k, sid_at, p->lens, p->str_start);
+    hipLaunchKernelGGL(k_string_assign, dim3(nblk(n_u)), dim3(256), 0, st, p->u_len, walk, n_u, p->scls, sid_at,
+                       slow, p->u_sid, p->u_koff, p->u_flip);
   }
   // string starts in bases
   arena_reset(ctx);

@@ -102,6 +102,7 @@ def lib():
         "ksh_ctx_timing_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(i64)]),
         "ksh_ctx_timing_units": (C.c_int, [vp, C.c_int, C.POINTER(i64)]),
         "ksh_set_hash": (C.c_int, [vp, GP, SP, C.POINTER(C.c_uint64)]),
+        "ksh_dsu_components": (C.c_int, [vp, i64, vp, vp, i64, vp]),
         "ksh_set_contains": (C.c_int, [vp, GP, SP, vp, i64, vp]),
         "ksh_set_kmers": (C.c_int, [vp, GP, SP, vp]),
         "ksh_pair_plan": (C.c_int, [vp, GP, SP, SP, vp, vp, vp, C.POINTER(i64)]),
@@ -379,6 +380,18 @@ class Context:
         v = s.view()
         check(lib().ksh_set_hash(self.h, C.byref(s.g), C.byref(v), C.byref(out)))
         return out.value
+
+    # ParallelDisjointSet ----------------------------------------------------------------
+    def dsu_components(self, n, xs, ys):
+        """Unites the pairs (xs[i], ys[i]) over n nodes concurrently; returns Find(i) for every node."""
+        import torch
+
+        x = torch.from_numpy(np.ascontiguousarray(xs, dtype=np.int32)).to(self.device)
+        y = torch.from_numpy(np.ascontiguousarray(ys, dtype=np.int32)).to(self.device)
+        root = torch.empty(max(n, 1), dtype=torch.int32, device=self.device)
+        check(lib().ksh_dsu_components(self.h, n, x.data_ptr() if x.numel() else None,
+                                       y.data_ptr() if y.numel() else None, x.numel(), root.data_ptr()))
+        return root[:n].cpu().numpy()
 
     # KmerSet::Contains / Find -----------------------------------------------------------
     def set_contains(self, s, kmers):

@@ -104,6 +104,19 @@ def phylogeny_sets(k, n_sets, size, seed, rate=0.002):
             for g in phylogeny_genomes(n_sets, size + k - 1, seed, rate)]
 
 
+def genome_with_tips(k, size, seed, every=400):
+    """Canonical k-mers of a random genome plus one-k-mer tips (the k-mer at every `every`-th position
+    gets a second successor ending in T where the genome goes on with A, C or G): the greedy path cover
+    takes the genome's own edge first, so the unitigs between the tips are stitched into long strings."""
+    bases = random_genome(size + k - 1, 0x5EED0000 + seed)
+    fwd = kmers_of_bases(bases, k)
+    pos = np.arange(0, fwd.size - 1, every)
+    keep = bases[pos + k] != 3
+    mask = U((1 << (2 * k)) - 1)
+    tips = ((fwd[pos[keep]] << U(2)) & mask) | U(3)
+    return np.unique(canonical(np.concatenate([fwd, tips]), k))
+
+
 def uniform_pair(k, size, shared_fraction, seed):
     """Two sorted canonical k-mer sets of about `size` keys, `shared_fraction` in common."""
     n_shared = int(size * shared_fraction)

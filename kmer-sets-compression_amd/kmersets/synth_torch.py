@@ -85,6 +85,26 @@ def phylogeny_sets(k, n_sets, size, seed, device, rate=0.002):
     return [canonical_set_of_bases(g, k) for g in genomes[:n_sets]]
 
 
+def genome_with_tips(k, size, seed, device, every=400):
+    """Canonical k-mers of a random genome plus one-k-mer tips: the k-mer at every `every`-th position
+    gets a second successor ending in T where the genome continues with A, C or G.  The greedy path
+    cover (spss.h:1445-1499) tries a node's right edges in base order, so the genome's own edge wins
+    and the unitigs between tips are stitched into one long string (same sets as synth.genome_with_tips)."""
+    bases = random_genome(size + k - 1, 0x5EED0000 + seed, device)
+    n = bases.numel() - k + 1
+    fwd = torch.zeros(n, dtype=torch.int64, device=device)
+    for j in range(k):
+        fwd = (fwd << 2) | bases[j:j + n]
+    pos = torch.arange(0, n - 1, every, dtype=torch.int64, device=device)
+    keep = bases[pos + k] != 3
+    mask = (1 << (2 * k)) - 1
+    tips = ((fwd[pos[keep]] << 2) & mask) | 3
+    allk = torch.cat([fwd, tips])
+    allk = torch.minimum(allk, revcomp(allk, k))
+    allk, _ = torch.sort(allk)
+    return torch.unique_consecutive(allk)
+
+
 def device_set(g, kmers):
     """Sorted int64 k-mers on device -> capi.DeviceSet (bucketed keys), no host round trip."""
     nb = 1 << g.n_bucket_bits

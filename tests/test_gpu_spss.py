@@ -287,3 +287,48 @@ def test_text_form_rejects_bad_input(ctx):
         with pytest.raises(capi.KshError) as e:
             ctx.spss_from_text(g, t)
         assert e.value.code == 3
+
+
+def test_parallel_disjoint_set_vs_oracle(ctx):
+    """ksh_dsu_components (the device ParallelDisjointSet) gives the partition of the oracle's serial
+    union-find (test/parallel_disjoint_set.cc:14-118: same partition, any representatives): random
+    graphs from very sparse to one giant component, a long chain, a ring, self pairs, no pairs."""
+    rng = np.random.default_rng(5)
+    cases = [(1000, rng.integers(0, 1000, 300), rng.integers(0, 1000, 300)),
+             (50000, rng.integers(0, 50000, 20000), rng.integers(0, 50000, 20000)),
+             (50000, rng.integers(0, 50000, 200000), rng.integers(0, 50000, 200000)),
+             (200000, np.arange(199999), np.arange(1, 200000)),                        # one chain
+             (4096, np.arange(4096), (np.arange(4096) + 1) % 4096),                    # a ring
+             (100, np.arange(100), np.arange(100)),                                    # self pairs
+             (77, np.zeros(0, dtype=np.int64), np.zeros(0, dtype=np.int64))]
+    for n, xs, ys in cases:
+        got = ctx.dsu_components(n, xs, ys)
+        d = ol.lib().ko_dsu_new(n)
+        for a, b in zip(xs.tolist(), ys.tolist()):
+            ol.lib().ko_dsu_unite(d, a, b)
+        want = np.array([ol.lib().ko_dsu_find(d, i) for i in range(n)])
+        ol.lib().ko_dsu_free(d)
+        assert np.array_equal(got[got], got)                         # representatives are roots
+        # same partition: the map got-root -> want-root is a bijection on components
+        fwd, bwd = {}, {}
+        for g_, w_ in zip(got.tolist(), want.tolist()):
+            assert fwd.setdefault(g_, w_) == w_ and bwd.setdefault(w_, g_) == g_
+
+
+def test_encode_branching_sets(ctx):
+    """Sets whose unitig graph branches at every few hundred k-mers -- a genome with one-k-mer tips, and
+    the union of two diverged genomes (a bubble per substitution) -- so that the path cover has
+    thousands of multi-unitig strings, competing edges at every junction and both orientations of
+    every walk: the strings are the oracle's, in order (walks ranked by pointer jumping, loops found
+    by the parallel union-find)."""
+    k, n, kb = 23, 14, 4
+    tips = synth.genome_with_tips(k, 150000, seed=7, every=150)
+    a, b = synth.phylogeny_sets(k, 2, 60000, seed=77, rate=0.004)
+    for name, kmers in (("tips", tips), ("bubbles", np.union1d(a, b))):
+        d = capi.DeviceSet.from_kmers(capi.geom(k, n), kmers, ctx.device)
+        for mode in (0, 2):
+            sp = ctx.spss_encode(d, mode=mode)
+            st = ctx.spss_encode_stats()
+            o = ol.Set.from_kmers(k, n, kb, kmers)
+            assert sp.to_strings() == (o.spss() if mode == 0 else o.spss_slow()), (name, mode)
+            assert st["unitigs"] > 700 and st["strings"] < st["unitigs"]

@@ -70,3 +70,73 @@ def test_split_range_matches_reference_rule():
                 assert all(a[1] == b[0] for a, b in zip(chunks, chunks[1:]))
                 sizes = [b - a for a, b in chunks]
                 assert max(sizes) - min(sizes) <= 1 and sizes == sorted(sizes)
+
+
+def _owned_worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from kmersets import owned_model
+
+        k, n, kb = 15, 14, 2
+        key_bits = 2 * k - n
+        sets = synth.phylogeny_sets(k, 8, 6000, seed=21)
+        ids = synth.sample_bucket_ids(n, seed=22)
+        # striped owners: siblings on different ranks, so most merges pull a set across
+        owners = [i % world for i in range(len(sets))]
+        mine = [s if owners[i] == rank else None for i, s in enumerate(sets)]
+
+        def spss_weight(kmers):
+            return ol.Set.from_kmers(k, n, kb, kmers).compact().weight()
+
+        res = owned_model.build_owned(mine, owners, key_bits, ids, spss_weight, dist)
+        okss = ol.KmerSetSet([ol.Set.from_kmers(k, n, kb, s).compact() for s in sets], ids)
+        assert [tuple(int(x) for x in r) for r in okss.iterations()] == [tuple(r) for r in res["trace"]]
+        ocp, _ = okss.checkpoints()
+        assert [tuple(int(x) for x in r) for r in ocp] == [(a, b, c, int(d)) for a, b, c, d in res["checkpoints"]]
+        assert len(res["owner"]) == okss.size()
+        held = 0
+        for i in range(okss.size()):
+            if res["owner"][i] == rank:
+                assert np.array_equal(res["sets"][i], okss.node(i).to_set().kmers()), i
+                held += 1
+            else:
+                assert res["sets"][i] is None
+        tot = torch.tensor([held, res["sets_received"]], dtype=torch.int64)
+        dist.all_reduce(tot)
+        assert int(tot[0]) == okss.size() and int(tot[1]) > 0
+        with open(os.path.join(out_dir, "owned_%d.txt" % rank), "w") as f:
+            f.write("ok %d" % len(res["trace"]))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_owned_schedule_world2_gloo(tmp_path):
+    """The owner-sharded build's schedule (kmersets/owned_model.py mirrors csrc/ksh_kss.hip build_owned)
+    with world_size 2 over gloo: control loop on the all-gathered samples only, merges on the owner of
+    j with k sent across, SPSS weights exchanged at the checks -- trace, checkpoints and every node's
+    set equal the oracle's single-process KmerSetSet, every node lives on exactly one rank."""
+    port = 29600 + os.getpid() % 200
+    mp.spawn(_owned_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert open(os.path.join(str(tmp_path), "owned_%d.txt" % r)).read().startswith("ok")
+
+
+def test_multi_worker_oracle_matches_single_worker():
+    """oracle/ko_mt.h (the reference's n_workers > 1 branches, bench.py's cpu_baseline) against the
+    n_workers == 1 oracle: merge sequence, N_proc, every node's set, Get(i)."""
+    k, n, kb = 23, 14, 4
+    sets = synth.phylogeny_sets(k, 6, 30000, seed=31)
+    ids = synth.sample_bucket_ids(n, seed=32)
+    oc = [ol.Set.from_kmers(k, n, kb, s).compact() for s in sets]
+    one = ol.KmerSetSet(oc, ids, max_iterations=4)
+    many = ol.KmerSetSet(oc, ids, max_iterations=4, n_workers=4)
+    assert np.array_equal(one.iterations(), many.iterations()) and one.stat(3) == many.stat(3)
+    assert one.size() == many.size() and one.meta() == many.meta()
+    for i in range(one.size()):
+        assert np.array_equal(one.node(i).to_set().kmers(), many.node(i).to_set().kmers())
+        strings = many.node(i).strings()          # an SPSS of the same set: every k-mer once
+        assert sum(len(x) - k + 1 for x in strings) == one.node(i).size()
+    for i in range(len(sets)):
+        assert np.array_equal(many.get(i).kmers(), sets[i])

@@ -253,6 +253,167 @@ __global__ __launch_bounds__(1024) void k_rc_scatter(DevSet<KeyT> set, int nbits
   }
 }
 
+// ---- the scatter in two levels, for large sets --------------------------------------------------
+// k_rc_scatter writes one record per k-mer to a random one of 2^N groups: 10^8 scattered 8-byte
+// stores, 2.9 ms, as slow as the memory system is at it.  Here every store instruction writes
+// runs instead.  Level 1 (k_rc_scatter_l1, the same persistent rows and histogram rows): a row
+// takes its k-mers tile by tile, sorts a tile by SUPER-GROUP (the top kSgBits of G) in LDS and
+// appends each super-group's run to the row's share of that super-group -- known exactly from the
+// histogram rows, so no atomics and the same order every run.  Level 2 (k_rc_scatter_l2): a tile
+// of the intermediate array lies in one super-group (two at a seam), is sorted by group in LDS, a
+// group's run is appended where one atomicAdd per (tile, group) says.  The order of the records
+// inside a group is not deterministic; nothing downstream depends on it.
+constexpr int kSgBits = 7;
+constexpr int kL1Threads = 1024;
+constexpr int kL2Threads = 256;
+constexpr int kL2Per = 8;
+constexpr int kL2Tile = kL2Threads * kL2Per;
+
+template <typename KeyT, int kPer>
+__global__ __launch_bounds__(kL1Threads) void k_rc_scatter_l1(DevSet<KeyT> set, int nbits, int64_t per_row,
+                                                               const uint32_t* __restrict__ hist_matrix,
+                                                               const int64_t* __restrict__ goff,
+                                                               RcRecord<KeyT>* __restrict__ tmp_rec,
+                                                               uint16_t* __restrict__ tmp_g) {
+  constexpr int kTile = kL1Threads * kPer;
+  constexpr int kSg = 1 << kSgBits;
+  __shared__ RcRecord<KeyT> s_rec[kTile];
+  __shared__ uint16_t s_g[kTile];
+  __shared__ uint32_t s_cur[kSg], s_cnt[kSg], s_lbase[kSg + 1];
+  const int tid = threadIdx.x;
+  const int nb = 1 << nbits, lo_bits = nbits - kSgBits;
+  const uint32_t* my_row = hist_matrix + int64_t(blockIdx.x) * nb;
+  if (tid < kSg) {
+    // where this row's share of super-group tid starts: the groups before it inside the super-group are
+    // full, plus what the rows before this one put into each of its groups
+    uint32_t at = uint32_t(goff[int64_t(tid) << lo_bits]);
+    for (int gi = 0; gi < (1 << lo_bits); gi++) at += my_row[(tid << lo_bits) + gi];
+    // (my_row holds, per group, the records of the rows before this one; the records of EARLIER groups of
+    // the super-group that belong to LATER rows do not precede us in the intermediate array's layout
+    // [super-group][row][tile order], so the share's start is the sum above)
+    s_cur[tid] = at;
+    s_cnt[tid] = 0;
+  }
+  const int64_t t_begin = int64_t(blockIdx.x) * per_row;
+  const int64_t t_end = min(t_begin + per_row, set.n);
+  __syncthreads();
+  if (t_begin >= t_end) return;
+  const int64_t b_first = set.bucket_of(t_begin), b_last = set.bucket_of(t_end - 1);
+  const int k = set.k, low_bits = set.key_bits - 2;
+  const uint64_t low_mask = (uint64_t(1) << low_bits) - 1;
+  for (int64_t t0 = t_begin; t0 < t_end; t0 += kTile) {
+    const int tile_n = int(min<int64_t>(kTile, t_end - t0));
+    RcRecord<KeyT> mine[kPer];
+    uint32_t grp[kPer], rank[kPer];
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+      const int64_t t = t0 + tid + j * kL1Threads;
+      grp[j] = 0xFFFFFFFFu;
+      if (t >= t_end) continue;
+      const uint64_t key = uint64_t(set.keys[t]);
+      int64_t lo = b_first, hi = b_last;
+      while (lo < hi) {
+        const int64_t mid = (lo + hi + 1) >> 1;
+        if (set.off[mid] <= t) lo = mid; else hi = mid - 1;
+      }
+      const uint64_t rx = revcomp((uint64_t(lo) << set.key_bits) | key, k);
+      grp[j] = uint32_t(rx >> low_bits) & uint32_t(nb - 1);
+      mine[j].key = KeyT(((rx >> (2 * k - 2)) << low_bits) | (rx & low_mask));
+      mine[j].t = uint32_t(t);
+      rank[j] = atomicAdd(&s_cnt[grp[j] >> lo_bits], 1u);
+    }
+    __syncthreads();
+    if (tid < kSg) {
+      uint32_t before = 0;
+      for (int b = 0; b < tid; b++) before += s_cnt[b];
+      s_lbase[tid] = before;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kPer; j++) {
+      if (grp[j] == 0xFFFFFFFFu) continue;
+      const uint32_t pos = s_lbase[grp[j] >> lo_bits] + rank[j];
+      s_rec[pos] = mine[j];
+      s_g[pos] = uint16_t(grp[j]);
+    }
+    __syncthreads();
+    for (int i = tid; i < tile_n; i += kL1Threads) {
+      const uint32_t sg = uint32_t(s_g[i]) >> lo_bits;
+      const uint32_t dst = s_cur[sg] + (uint32_t(i) - s_lbase[sg]);
+      tmp_rec[dst] = s_rec[i];
+      tmp_g[dst] = s_g[i];
+    }
+    __syncthreads();
+    if (tid < kSg) {
+      s_cur[tid] += s_cnt[tid];
+      s_cnt[tid] = 0;
+    }
+    __syncthreads();
+  }
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(kL2Threads) void k_rc_scatter_l2(int64_t n, int nbits, const int64_t* __restrict__ goff,
+                                                               const RcRecord<KeyT>* __restrict__ tmp_rec,
+                                                               const uint16_t* __restrict__ tmp_g,
+                                                               uint32_t* __restrict__ cursor,
+                                                               RcRecord<KeyT>* __restrict__ rec) {
+  constexpr int kBins = 2 << kSgBits;  // two super-groups' worth of groups when a super-group has 2^kSgBits groups
+  __shared__ RcRecord<KeyT> s_rec[kL2Tile];
+  __shared__ uint16_t s_bin[kL2Tile];
+  __shared__ uint32_t s_cnt[kBins], s_lbase[kBins], s_gbase[kBins];
+  __shared__ uint32_t s_first;
+  const int tid = threadIdx.x;
+  const int lo_bits = nbits - kSgBits;
+  const int64_t p0 = int64_t(blockIdx.x) * kL2Tile;
+  const int tile_n = int(min<int64_t>(kL2Tile, n - p0));
+  for (int b = tid; b < kBins; b += kL2Threads) s_cnt[b] = 0;
+  if (tid == 0) s_first = (uint32_t(tmp_g[p0]) >> lo_bits) << lo_bits;  // first group of the tile's first super-group
+  __syncthreads();
+  const uint32_t base_g = s_first;
+  const uint32_t n_bins = min<uint32_t>(uint32_t(kBins), (2u << lo_bits));
+  RcRecord<KeyT> mine[kL2Per];
+  uint32_t bin[kL2Per], rank[kL2Per];
+#pragma unroll
+  for (int j = 0; j < kL2Per; j++) {
+    const int i = tid + j * kL2Threads;
+    bin[j] = 0xFFFFFFFFu;
+    if (i >= tile_n) continue;
+    mine[j] = tmp_rec[p0 + i];
+    const uint32_t g = tmp_g[p0 + i];
+    if (g - base_g < n_bins) {
+      bin[j] = g - base_g;
+      rank[j] = atomicAdd(&s_cnt[bin[j]], 1u);
+    } else {
+      // a tile over three or more super-groups (tiny or very skewed sets): one record at a time
+      rec[uint32_t(goff[g]) + atomicAdd(&cursor[g], 1u)] = mine[j];
+    }
+  }
+  __syncthreads();
+  for (int b = tid; b < kBins; b += kL2Threads) {
+    uint32_t before = 0;
+    for (int b2 = 0; b2 < b; b2++) before += s_cnt[b2];
+    s_lbase[b] = before;
+    const uint32_t c = s_cnt[b];
+    s_gbase[b] = c ? uint32_t(goff[base_g + b]) + atomicAdd(&cursor[base_g + b], c) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kL2Per; j++) {
+    if (bin[j] == 0xFFFFFFFFu) continue;
+    const uint32_t pos = s_lbase[bin[j]] + rank[j];
+    s_rec[pos] = mine[j];
+    s_bin[pos] = uint16_t(bin[j]);
+  }
+  __syncthreads();
+  uint32_t staged = 0;
+  for (int b = 0; b < kBins; b++) staged += s_cnt[b];  // (uniform; the far records were written directly)
+  for (uint32_t i = tid; i < staged; i += kL2Threads) {
+    const uint32_t b = s_bin[i];
+    rec[s_gbase[b] + (i - s_lbase[b])] = s_rec[i];
+  }
+}
+
 // First index of the set whose k-mer is >= value (value may be 4^K: the set's end).
 template <typename KeyT>
 __device__ int64_t lower_bound_kmer(const DevSet<KeyT>& set, uint64_t value) {
@@ -272,7 +433,6 @@ __device__ __forceinline__ void mark_hit(uint32_t* slot, uint32_t v) {
 }
 
 constexpr int kRcSegs = 16;
-constexpr int kRcThreads = 1024;
 
 // pb[32 * G + 2 * seg + which]: the index range of the set with the (N + 4)-bit prefix
 // [c][tb][G] (seg = 4 c + tb), for every group G: one thread per bound, all searches in flight
@@ -285,7 +445,6 @@ __global__ __launch_bounds__(256) void k_rc_bounds(DevSet<KeyT> set, int nbits, 
   const uint64_t prefix = (seg << nbits) | grp;
   pb[i] = lower_bound_kmer(set, (prefix + which) << (2 * set.k - 4 - nbits));
 }
-static_assert(kRcThreads / 64 == kRcSegs, "pass 1 stages one range per wave");
 struct RcBatch {
   int64_t seg_lo[kRcSegs], seg_hi[kRcSegs];  // the pass's target ranges (indices of the set)
   int64_t win_lo[kRcSegs];                   // the part of each that is staged in this batch ...
@@ -307,8 +466,10 @@ struct RcBatch {
 // A wave's life here is memory round trips, so each is taken once: a thread's records are read
 // into registers up front and serve both passes, the 32 range bounds of pass 1 are searched
 // while bucket G is being staged, every staging loop issues all its loads before the first LDS
-// store, and in pass 1 wave w stages, indexes and stores range w.
-template <typename KeyT>
+// store, and in pass 1 team w (a sixteenth of the workgroup: a wave when it has 1024 threads)
+// stages, indexes and stores range w.  kRcThreads follows the group size (1024 for the 6 000-key
+// groups of a 10^8-k-mer set, 256 or 64 for small sets: a workgroup's fixed cost is its barriers).
+template <typename KeyT, int kRcThreads>
 __global__ __launch_bounds__(kRcThreads) void k_adj_rc(DevSet<KeyT> set, int nbits,
                                                         const int64_t* __restrict__ goff,
                                                         const RcRecord<KeyT>* __restrict__ rec,
@@ -320,7 +481,9 @@ __global__ __launch_bounds__(kRcThreads) void k_adj_rc(DevSet<KeyT> set, int nbi
   uint16_t* sidx = reinterpret_cast<uint16_t*>(lds_raw + size_t(cap) * (sizeof(KeyT) + 4));
   __shared__ RcBatch bt;
   __shared__ int64_t prev_bounds[2 * kRcSegs];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  static_assert(kRcThreads % kRcSegs == 0, "pass 1 deals the ranges out to sixteen teams");
+  constexpr int kTeam = kRcThreads / kRcSegs;
+  const int tid = threadIdx.x, lane = tid % kTeam, wave = tid / kTeam;
   const int64_t grp = blockIdx.x;
   const int k = set.k, low_bits = set.key_bits - 2;
   const uint64_t low_mask = (uint64_t(1) << low_bits) - 1;
@@ -382,9 +545,9 @@ __global__ __launch_bounds__(kRcThreads) void k_adj_rc(DevSet<KeyT> set, int nbi
       }
       __syncthreads();
       if (bt.used == 0) break;  // every range of the pass has been staged and stored
-      // who stages what: pass 0, the whole workgroup its one range; pass 1, wave w range w
+      // who stages what: pass 0, the whole workgroup its one range; pass 1, team w range w
       const int my_seg = pass == 0 ? 0 : wave;
-      const int my_id = pass == 0 ? tid : lane, my_step = pass == 0 ? kRcThreads : 64;
+      const int my_id = pass == 0 ? tid : lane, my_step = pass == 0 ? kRcThreads : kTeam;
       const int64_t my_lo = bt.win_lo[my_seg];
       const int my_len = bt.win_len[my_seg], my_off = bt.win_off[my_seg];
       for (int base = 0; base < my_len; base += 4 * my_step) {
@@ -1712,7 +1875,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
                        2 * al(size_t(n)) + 2 * al(size_t(n) * 8) + al(fine_entries * 4) + 4096;
   KSH_TRY(slot_reserve(ctx, kSlotEncode, bytes));
   KSH_TRY(arena_reserve(ctx, size_t(n / 256 + 4096) * 8 * 2 + (1u << 16) +
-                                 (nb <= (1 << 14) ? size_t(kRcRowsMax) * nb * 4 + size_t(nb + 1) * 16 + size_t(nb) * 256 + 8192 : 0)));
+                                 (nb <= (1 << 14) ? size_t(kRcRowsMax) * nb * 4 + size_t(nb + 1) * 16 + size_t(nb) * 260 + 8192 : 0)));
   arena_reset(ctx);
   char* at = ctx->slot[kSlotEncode];
   p->nbr = carve<uint32_t>(at, size_t(2 * n));
@@ -1766,16 +1929,28 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       hipLaunchKernelGGL(k_rc_columns, dim3(unsigned((nb + 255) / 256)), dim3(256), 0, st, hist, rows, int(nb),
                          totals);
       KSH_TRY(scan_exclusive_i64(ctx, totals, goff, nb, goff + nb));
-      {
-        // one round unless KSH_RC_ROUNDS says otherwise (measured: more rounds only add passes over the keys)
-        int round_bits = 0;
-        if (const char* e = getenv("KSH_RC_ROUNDS")) {
-          round_bits = 0;
-          while ((1 << round_bits) < atoi(e) && round_bits < nbits) round_bits++;
-        }
-        for (int round = 0; round < (1 << round_bits); round++)
-          hipLaunchKernelGGL((k_rc_scatter<KeyT>), dim3(unsigned(rows)), dim3(1024), hist_lds, st, set, nbits,
-                             round_bits, round, per_row, hist, goff, rec);
+      static const bool one_level = [] {
+        const char* e = getenv("KSH_RC_SCATTER");
+        return e && std::string(e) == "direct";
+      }();
+      if (n >= (int64_t(1) << 20) && nbits > kSgBits && nbits <= 16 && !one_level) {
+        // two levels of run-wise writes; the intermediate records borrow arrays that are written
+        // later: u32 keys: the upper half of the chain-rank records; u64 keys (16-byte records): the
+        // neighbour + link arrays (rc0 / rc1 and nbr are only written after level 2); the group ids
+        // sit in the head array
+        RcRecord<KeyT>* tmp_rec = sizeof(KeyT) == 4 ? rec + n : reinterpret_cast<RcRecord<KeyT>*>(p->nbr);
+        uint16_t* tmp_g = reinterpret_cast<uint16_t*>(p->head);
+        uint32_t* cursor = static_cast<uint32_t*>(arena_alloc(ctx, size_t(nb) * 4));
+        if (!cursor) return fail(KSH_INTERNAL, "scratch arena too small");
+        KSH_HIP(hipMemsetAsync(cursor, 0, size_t(nb) * 4, st));
+        constexpr int kPer = sizeof(KeyT) == 4 ? 4 : 2;
+        hipLaunchKernelGGL((k_rc_scatter_l1<KeyT, kPer>), dim3(unsigned(rows)), dim3(kL1Threads), 0, st, set, nbits,
+                           per_row, hist, goff, tmp_rec, tmp_g);
+        hipLaunchKernelGGL((k_rc_scatter_l2<KeyT>), dim3(unsigned((n + kL2Tile - 1) / kL2Tile)), dim3(kL2Threads), 0,
+                           st, n, nbits, goff, tmp_rec, tmp_g, cursor, rec);
+      } else {
+        hipLaunchKernelGGL((k_rc_scatter<KeyT>), dim3(unsigned(rows)), dim3(1024), hist_lds, st, set, nbits, 0, 0,
+                           per_row, hist, goff, rec);
       }
       // LDS window: a bucket with a quarter to spare (larger ranges are staged in batches)
       const int cap = int(std::min<int64_t>((kRcWindowBytes - 4 * kRcSegs) / int64_t(sizeof(KeyT) + 6),
@@ -1784,8 +1959,15 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       int64_t* pb = static_cast<int64_t*>(arena_alloc(ctx, size_t(nb) * 2 * kRcSegs * 8));
       if (!pb) return fail(KSH_INTERNAL, "scratch arena too small");
       hipLaunchKernelGGL((k_rc_bounds<KeyT>), dim3(nblk(nb * 2 * kRcSegs)), dim3(256), 0, st, set, nbits, pb);
-      hipLaunchKernelGGL((k_adj_rc<KeyT>), dim3(unsigned(nb)), dim3(kRcThreads), rc_lds, st, set, nbits, goff,
-                         rec, pb, cap, rc0, rc1);
+      if (n / nb > 2048)
+        hipLaunchKernelGGL((k_adj_rc<KeyT, 1024>), dim3(unsigned(nb)), dim3(1024), rc_lds, st, set, nbits, goff,
+                           rec, pb, cap, rc0, rc1);
+      else if (n / nb > 256)
+        hipLaunchKernelGGL((k_adj_rc<KeyT, 256>), dim3(unsigned(nb)), dim3(256), rc_lds, st, set, nbits, goff,
+                           rec, pb, cap, rc0, rc1);
+      else
+        hipLaunchKernelGGL((k_adj_rc<KeyT, 64>), dim3(unsigned(nb)), dim3(64), rc_lds, st, set, nbits, goff,
+                           rec, pb, cap, rc0, rc1);
       static const bool fwd_probe = [] {
         const char* e = getenv("KSH_FWD");
         return e && std::string(e) == "probe";

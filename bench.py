@@ -99,9 +99,12 @@ def main():
                     help="skip the Size / XOR-Hash check of every Get(i) after the timed builds")
     ap.add_argument("--no-pair-merge", action="store_true", help="skip the configs[1] pair-algebra block")
     ap.add_argument("--cpu-sets", type=int, default=16)
-    ap.add_argument("--cpu-size", type=float, default=1e6)
+    ap.add_argument("--cpu-size", type=float, default=2e6)
     ap.add_argument("--cpu-iterations", type=int, default=4)
     ap.add_argument("--cpu-workers", type=int, default=0, help="0 = all host cores")
+    ap.add_argument("--dump-trace", default="",
+                    help="write the last build's merge sequence, node sizes and phase times to this file "
+                         "(input of tools/owned_schedule.py)")
     args = ap.parse_args()
 
     import numpy as np
@@ -217,6 +220,25 @@ def main():
                      "encoded_kmers_per_rank": [r[1] for r in rows], "sets_sent_per_rank": [r[2] for r in rows],
                      "p2p_bytes_sent_per_rank": [r[3] for r in rows], "allgather_bytes_per_rank": [r[4] for r in rows],
                      "note": "last timed build"}
+
+    if args.dump_trace and rank == 0 and world == 1:
+        n_in = len(compacts)
+        node_sizes = [kss.node_size(i) for i in range(kss.size())]
+        # sizes of (child, j', k') right after every merge: replay the trace backwards from the final sizes
+        cur = list(node_sizes)
+        triples = [None] * len(it)
+        for t in range(len(it) - 1, -1, -1):
+            j_, k_ = int(it[t][0]), int(it[t][1])
+            child = n_in + t
+            triples[t] = [cur[child], cur[j_], cur[k_]]
+            # before the merge: |j| = |j'| + |child as it was born|; the child's birth size is its size now plus
+            # whatever later merges moved out of it into ITS children, which the backward replay has restored
+            cur[j_] += cur[child]
+            cur[k_] += cur[child]
+        json.dump({"n_inputs": n_in, "key_bytes": g.key_bytes, "input_sizes": sizes, "trace": it.tolist(),
+                   "result_sizes": triples, "phase_seconds": st["phase_seconds"],
+                   "n_encoded_kmers": st["n_encoded_kmers"], "n_encodes": st["n_encodes"]},
+                  open(args.dump_trace, "w"))
 
     verified = None
     if not args.no_verify:

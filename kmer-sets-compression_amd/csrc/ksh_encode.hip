@@ -1910,7 +1910,10 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     if (directed) {
       hipLaunchKernelGGL((k_adjacency<KeyT, true>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr, flags + 1);
     } else if (staged_adjacency() && nbits <= 14 && 2 * g->k >= nbits + 4 &&
-               key_bits(g) >= nbits + 2 + (nbits & 1)) {
+               key_bits(g) >= nbits + 2 + (nbits & 1) &&
+               n / nb <= 4 * ((kRcWindowBytes - 4 * kRcSegs) / int64_t(sizeof(KeyT) + 6))) {
+      // (a group four windows long is staged in four batches and every batch looks at all of the group's
+      // records: beyond that -- 10^8 k-mers in 2^10 buckets, 5 x 10^8 in 2^14 -- the probing kernel is as fast)
       // E1b: partition by rc-prefix, LDS-staged probe of the reverse-complement half, forward half
       // in place.  The records live in the (still unused) chain-rank records, rc0 / rc1 in the link
       // array, both written only by k_links afterwards.

@@ -321,7 +321,9 @@ int ksh_kss_node_holder(const ksh_kss* k, int32_t i, int32_t* rank);
  *     with j's owner, which also owns the new node;
  *   * at the points where the loop reads SPSS weights (:287 and the end) every rank encodes the
  *     stale nodes it owns and one all-gather of (n_strings, n_bases, size) per stale node puts
- *     the sum on all ranks.
+ *     the sum on all ranks.  A check only decides whether the loop stops, so its exchange is taken
+ *     one check later: the ranks go on with the next interval meanwhile and undo it if the answer
+ *     was "stop" (same result; a loaded rank no longer holds up the others at every check).
  * Trace, checkpoints, DAG and every node's set and SPSS equal the single-GPU build's; a node's
  * set and SPSS live on its owner only (ksh_kss_node_holder; ksh_kss_node answers
  * KSH_FAILED_PRECONDITION elsewhere, ksh_kss_get when a reachable node lives elsewhere).
@@ -349,9 +351,12 @@ int ksh_comm_destroy(ksh_comm* comm);
 int ksh_kss_build_owned(ksh_ctx* ctx, ksh_comm* comm, const ksh_geom* g, const ksh_spss_view* inputs,
                         int32_t n_inputs, const int32_t* owners, const int32_t* bucket_ids, int32_t n_ids,
                         int canonical, int32_t max_iterations, ksh_kss** out);
-/* Bytes this rank sent / received point to point and the sets that travelled (the merged pairs whose
- * members lived on different ranks), and the bytes it contributed to all-gathers. */
-int ksh_kss_comm_stats(const ksh_kss* k, int64_t stats[4]);
+/* stats = { bytes this rank sent point to point, bytes it received, sets it sent (merged pairs whose
+ * members lived on different ranks), bytes it contributed to all-gathers, convergence checks whose
+ * exchange was deferred by one check (the ranks go on with the next interval instead of waiting for the
+ * slowest encoder; KSH_OWNED_LOOKAHEAD=0 turns that off), intervals undone because a deferred check
+ * said "stop" }. */
+int ksh_kss_comm_stats(const ksh_kss* k, int64_t stats[6]);
 /* SPSS encodes this process ran for the build, and the k-mers they covered (the sharded build's
  * balance; in a single-GPU build: how many encodes the deferral left). */
 int ksh_kss_encode_counts(const ksh_kss* k, int64_t* n_encodes, int64_t* n_encoded_kmers);

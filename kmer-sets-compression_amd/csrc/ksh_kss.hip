@@ -18,6 +18,7 @@
 #include <cstring>
 #include <map>
 #include <queue>
+#include <unordered_set>
 #include <algorithm>
 #include <chrono>
 #include <utility>
@@ -68,6 +69,11 @@ struct ksh_kss {
   std::vector<bool> sample_pooled;   // false: the keys point into sample_block
   char* sample_block = nullptr;      // the all-gathered samples of the inputs
   int64_t p2p_bytes_sent = 0, p2p_bytes_received = 0, p2p_sets = 0, gather_bytes = 0;
+  // deferred convergence checks (build_owned): while a check is unresolved, buffers of the state it may
+  // have to return to are parked instead of freed
+  const std::unordered_set<void*>* keep_alive = nullptr;
+  std::vector<void*>* graveyard = nullptr;
+  int64_t checks_deferred = 0, rollbacks = 0;
 };
 
 namespace ksh {
@@ -85,6 +91,13 @@ struct PhaseTimer {
     k->phase_seconds[kind] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
   }
 };
+
+// Lets go of a pooled buffer: parked while an unresolved check may still need it, else freed.
+static void retire(ksh_kss* k, void* p) {
+  if (!p) return;
+  if (k->keep_alive && k->keep_alive->count(p)) k->graveyard->push_back(p);
+  else pool_free(k->ctx, p);
+}
 
 static void free_set(ksh_ctx* ctx, KssSet* s) {
   pool_free(ctx, s->off);
@@ -366,8 +379,8 @@ static int sample_weights(ksh_kss* k, const std::vector<int32_t>& ids, const std
 
 static void free_sample(ksh_kss* k, size_t i) {
   if (k->sample_pooled[i]) {
-    pool_free(k->ctx, k->samples[i].off);
-    pool_free(k->ctx, k->samples[i].keys);
+    retire(k, k->samples[i].off);
+    retire(k, k->samples[i].keys);
   }
   k->samples[i] = KssSet{};
   k->sample_pooled[i] = false;
@@ -564,17 +577,198 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
   std::vector<int64_t> my_rows;
   std::vector<int> executor;
 
+  // ---- deferred convergence checks.  A check only decides whether the loop stops; its weights are
+  // not needed to go on.  At a check every rank encodes the stale nodes it owns and, instead of
+  // waiting for the others, goes on with the next interval (control, merges, and at the next check
+  // its encodes); the exchange of check c happens when the ranks meet at check c + 1.  A rank with
+  // little to encode at check c thus works on c + 1 while a loaded rank catches up: per pair of
+  // checks the ranks wait for max(load_c + load_c+1) instead of max(load_c) + max(load_c+1)
+  // (DESIGN.md 7.3).  If check c says "stop", the interval run in the meantime is undone: the state
+  // at the check is kept (vectors copied, device buffers parked instead of freed) until it resolves.
+  // KSH_OWNED_LOOKAHEAD=0: resolve every check on the spot (the schedule of 7.1 as first built).
+  static const bool lookahead = [] {
+    const char* e = getenv("KSH_OWNED_LOOKAHEAD");
+    return !(e && e[0] == '0');
+  }();
+  struct Pending {
+    bool active = false;
+    int id = 0, iteration = 0;
+    std::vector<size_t> stale;
+    std::vector<int64_t> send;
+    int local_rc = KSH_OK;
+    std::string local_msg;
+    // the state at the check
+    std::vector<KssSet> sets, samples;
+    std::vector<bool> sample_pooled;
+    std::vector<KssCompact> compacts;
+    std::vector<int> owner, pending_of;
+    std::map<int, std::vector<int>> children;
+    std::map<std::pair<int, int>, int64_t> weights;
+    size_t n_rows = 0, n_exec = 0;
+    std::unordered_set<void*> alive;
+    std::vector<void*> graveyard;
+  } pend;
+  std::vector<int> pending_of(k->compacts.size(), -1);  // the unresolved check that covers a node's SPSS, or -1
+  int n_checks = 0;
+  bool stopped = false;
+
+  const auto collect_alive = [&](std::unordered_set<void*>* out) {
+    for (const KssSet& st : k->sets) {
+      if (st.off) out->insert(st.off);
+      if (st.keys) out->insert(st.keys);
+    }
+    for (size_t q = 0; q < k->samples.size(); q++)
+      if (k->sample_pooled[q]) {
+        out->insert(k->samples[q].off);
+        out->insert(k->samples[q].keys);
+      }
+    for (const KssCompact& c : k->compacts)
+      if (c.owned) {
+        out->insert(c.words);
+        out->insert(c.lens);
+      }
+  };
+
+  // encodes the stale nodes this rank owns; fills stale / send
+  const auto encode_stale = [&](Pending* pd) {
+    PhaseTimer pt(k, 3);
+    pd->stale.clear();
+    for (size_t q = 0; q < k->compacts.size(); q++)
+      if (!k->compacts[q].valid && pending_of[q] < 0) pd->stale.push_back(q);
+    pd->send.assign(3 * pd->stale.size(), -1);
+    pd->local_rc = KSH_OK;
+    for (size_t q = 0; q < pd->stale.size(); q++) {
+      const size_t node = pd->stale[q];
+      KssCompact c;
+      c.valid = false;
+      c.holder = k->owner[node];
+      if (k->owner[node] == rank && pd->local_rc == KSH_OK) {
+        pd->local_rc = encode_set(ctx, g, k->sets[node], k->canonical, &c);
+        if (pd->local_rc == KSH_OK) {
+          c.valid = false;  // known here, not yet everywhere
+          k->n_encodes++;
+          k->n_encoded_kmers += k->sets[node].n;
+          pd->send[3 * q] = c.n_strings;
+          pd->send[3 * q + 1] = c.n_bases;
+          pd->send[3 * q + 2] = c.size;
+        } else {
+          pd->local_msg = ksh_last_error();
+          c = KssCompact{};
+          c.valid = false;
+        }
+        c.holder = rank;
+      }
+      k->compacts[node] = c;
+      pending_of[node] = pd->id;
+    }
+    return KSH_OK;
+  };
+
+  // the exchange and the decision of an unresolved check; *stop_out: the loop ends at that check
+  const auto resolve = [&](Pending* pd, bool* stop_out) {
+    PhaseTimer pt(k, 3);
+    std::vector<int64_t> recv;
+    KSH_TRY(gather_i64(k, pd->send, &recv));  // (every rank gets here, whatever its local encodes did)
+    if (pd->local_rc != KSH_OK) return fail(pd->local_rc, "%s", pd->local_msg.c_str());
+    const std::vector<KssCompact>& at_check = pd->compacts;
+    std::vector<const int64_t*> from(pd->stale.size(), nullptr);
+    for (size_t q = 0; q < pd->stale.size(); q++) {
+      const int holder = at_check[pd->stale[q]].holder;
+      from[q] = recv.data() + size_t(holder) * pd->send.size() + 3 * q;
+      if (from[q][0] < 0 || from[q][1] < 0 || from[q][2] < 0)
+        return fail(KSH_INTERNAL, "rank %d did not report node %zu", holder, pd->stale[q]);
+    }
+    int64_t updated = 0;
+    {
+      std::vector<int64_t> bases(at_check.size(), -1);
+      for (size_t q = 0; q < pd->stale.size(); q++) bases[pd->stale[q]] = from[q][1];
+      for (size_t q = 0; q < at_check.size(); q++) updated += bases[q] >= 0 ? bases[q] : at_check[q].n_bases;
+    }
+    const float improvement = static_cast<float>(total_spss_weight - updated) / total_spss_weight;
+    const bool stop = improvement <= improvement_threshold;
+    k->checkpoints.insert(k->checkpoints.end(), {int64_t(pd->iteration), total_spss_weight, updated, int64_t(stop)});
+    k->improvements.push_back(improvement);
+    k->keep_alive = nullptr;
+    k->graveyard = nullptr;
+    if (stop) {
+      // back to the state at the check: whatever was made since goes, what was parked is in use again
+      std::unordered_set<void*> now;
+      collect_alive(&now);
+      for (void* ptr : now)
+        if (!pd->alive.count(ptr)) pool_free(ctx, ptr);
+      k->sets = pd->sets;
+      k->samples = pd->samples;
+      k->sample_pooled = pd->sample_pooled;
+      k->compacts = pd->compacts;
+      k->owner = pd->owner;
+      k->children = pd->children;
+      weights = pd->weights;
+      pending_of = pd->pending_of;
+      if (my_rows.size() > pd->n_rows || executor.size() > pd->n_exec) k->rollbacks++;
+      my_rows.resize(pd->n_rows);
+      executor.resize(pd->n_exec);
+    } else {
+      total_spss_weight = updated;
+      for (void* ptr : pd->graveyard) pool_free(ctx, ptr);
+    }
+    for (size_t q = 0; q < pd->stale.size(); q++) {
+      const size_t node = pd->stale[q];
+      if (pending_of[node] != pd->id) continue;  // merged again since: a later check covers its new version
+      KssCompact& c = k->compacts[node];
+      c.n_strings = from[q][0];
+      c.n_bases = from[q][1];
+      c.size = from[q][2];
+      c.valid = true;
+      pending_of[node] = -1;
+    }
+    pd->graveyard.clear();
+    pd->alive.clear();
+    pd->active = false;
+    *stop_out = stop;
+    return KSH_OK;
+  };
+
   for (int i = 0;; i++) {
     if (max_iterations >= 0 && i >= max_iterations) break;
     if (i > 0 && i % interval == 0) {
-      int64_t updated = 0;
-      KSH_TRY(total_spss_weight_now(&updated));
-      const float improvement = static_cast<float>(total_spss_weight - updated) / total_spss_weight;
-      const bool stop = improvement <= improvement_threshold;
-      k->checkpoints.insert(k->checkpoints.end(), {int64_t(i), total_spss_weight, updated, int64_t(stop)});
-      k->improvements.push_back(improvement);
-      if (stop) break;
-      total_spss_weight = updated;
+      Pending next;
+      next.id = ++n_checks;
+      next.iteration = i;
+      KSH_TRY(encode_stale(&next));
+      if (pend.active) {
+        bool stop = false;
+        KSH_TRY(resolve(&pend, &stop));
+        if (stop) {
+          stopped = true;  // (this check's encodes went with the roll-back)
+          break;
+        }
+      }
+      // this check: the state to come back to, and what may not be freed until it resolves
+      next.sets = k->sets;
+      next.samples = k->samples;
+      next.sample_pooled = k->sample_pooled;
+      next.compacts = k->compacts;
+      next.owner = k->owner;
+      next.pending_of = pending_of;
+      next.children = k->children;
+      next.weights = weights;
+      next.n_rows = my_rows.size();
+      next.n_exec = executor.size();
+      collect_alive(&next.alive);
+      next.active = true;
+      pend = std::move(next);
+      k->keep_alive = &pend.alive;
+      k->graveyard = &pend.graveyard;
+      if (!lookahead) {
+        bool stop = false;
+        KSH_TRY(resolve(&pend, &stop));
+        if (stop) {
+          stopped = true;
+          break;
+        }
+      } else {
+        k->checks_deferred++;
+      }
     }
     const int n = int(k->compacts.size());
     int64_t weight = 0;
@@ -616,6 +810,11 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
     executor.push_back(ex);
     my_rows.insert(my_rows.end(), {int64_t(j), int64_t(kk), weight, -1, 0});
     k->sets.emplace_back();
+    const auto retire_set = [&](KssSet* st) {
+      retire(k, st->off);
+      retire(k, st->keys);
+      *st = KssSet{};
+    };
     if (rank == ex) {
       PhaseTimer pt(k, 2);
       KssSet pulled;
@@ -633,8 +832,8 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
       KSH_TRY(alloc_keys(ctx, g, totals[1], &sj));
       KSH_TRY(alloc_keys(ctx, g, totals[2], &sk));
       KSH_TRY(ksh_pair_write(ctx, g, &vj, &vk, sn.keys, sj.keys, sk.keys));
-      if (src != ex) free_set(ctx, &pulled); else free_set(ctx, &k->sets[size_t(kk)]);
-      free_set(ctx, &k->sets[size_t(j)]);
+      if (src != ex) retire_set(&pulled); else retire_set(&k->sets[size_t(kk)]);
+      retire_set(&k->sets[size_t(j)]);
       k->sets[size_t(j)] = sj;
       k->sets[size_t(kk)] = sk;
       k->sets[size_t(n)] = sn;
@@ -645,17 +844,24 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
       PhaseTimer pt(k, 2);
       KSH_TRY(send_set(k, k->sets[size_t(kk)], ex));
       KSH_HIP(hipStreamSynchronize(ctx->stream));  // the keys have left before their buffer is reused
-      free_set(ctx, &k->sets[size_t(kk)]);
+      retire_set(&k->sets[size_t(kk)]);
     }
     for (int node : {j, kk}) {
-      free_compact(ctx, &k->compacts[size_t(node)]);
-      k->compacts[size_t(node)].valid = false;
-      k->compacts[size_t(node)].holder = ex;
+      KssCompact& c = k->compacts[size_t(node)];
+      if (c.owned) {
+        retire(k, c.words);
+        retire(k, c.lens);
+      }
+      c = KssCompact{};
+      c.valid = false;
+      c.holder = ex;
+      pending_of[size_t(node)] = -1;
     }
     KssCompact cn;
     cn.valid = false;
     cn.holder = ex;
     k->compacts.push_back(cn);
+    pending_of.push_back(-1);
     k->owner[size_t(kk)] = ex;
     k->owner.push_back(ex);
     k->children[j].push_back(n);
@@ -680,6 +886,12 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
       for (size_t q = 0; q < pairs.size(); q++) weights[pairs[q]] = w[q];
     }
   }
+  if (pend.active) {  // the loop ended between checks (max_iterations, no common k-mers left): the last check still decides
+    bool stop = false;
+    KSH_TRY(resolve(&pend, &stop));
+    stopped = stopped || stop;
+  }
+  (void)stopped;
   KSH_TRY(total_spss_weight_now(&k->final_spss_weight));
 
   // the trace: every row from the rank that ran its merge
@@ -945,12 +1157,14 @@ int ksh_kss_build_owned(ksh_ctx* ctx, ksh_comm* comm, const ksh_geom* g, const k
   return KSH_OK;
 }
 
-int ksh_kss_comm_stats(const ksh_kss* k, int64_t stats[4]) {
+int ksh_kss_comm_stats(const ksh_kss* k, int64_t stats[6]) {
   if (!k || !stats) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
   stats[0] = k->p2p_bytes_sent;
   stats[1] = k->p2p_bytes_received;
   stats[2] = k->p2p_sets;
   stats[3] = k->gather_bytes;
+  stats[4] = k->checks_deferred;
+  stats[5] = k->rollbacks;
   return KSH_OK;
 }
 

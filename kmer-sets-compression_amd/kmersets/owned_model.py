@@ -3,7 +3,9 @@ schedule over plain numpy sets, with the exchanges through any torch.distributed
 so that the protocol -- who owns what, what is exchanged when, and the claim that the control loop
 can run on the 2 % samples alone -- is checked with world_size 2 on CPU (tests/test_dist_cpu.py),
 where the HIP kernels cannot run; the SPSS weight of a node comes from a caller-supplied function
-(the tests pass the oracle's encoder).
+(the tests pass the oracle's encoder).  The model resolves every check on the spot; the library defers a
+check's exchange by one interval and rolls back on "stop", which changes when ranks wait, not what they
+compute (tests/test_gpu_kmer_set_set.py runs both routes).
 
 A set is a sorted uint64 array of 2K-bit k-mers; a sample is the sub-array whose bucket
 (k-mer >> key_bits) is one of bucket_ids.

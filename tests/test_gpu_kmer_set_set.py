@@ -157,6 +157,30 @@ def test_owned_build(gpu, world, shape, layout):
     if layout == "striped":
         assert sum(res["sets_sent_per_rank"]) > 0          # sets did travel
     assert sum(res["encodes_per_rank"]) > 0
+    # the checks were deferred by one (the default); a loop that stops at a check has undone the
+    # interval it ran in the meantime
+    assert res["checks_deferred"] == res["checks"] > 0
+    if shape[0] == "23":
+        assert res["rollbacks"] == 1      # this family stops at a check: the interval after it was undone
+
+
+def test_owned_build_without_lookahead(gpu, monkeypatch):
+    """KSH_OWNED_LOOKAHEAD=0: every check resolved on the spot -- the same result by the other route."""
+    monkeypatch.setenv("KSH_OWNED_LOOKAHEAD", "0")
+    import json
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29597",
+           os.path.join(here, "dist_owned_worker.py"), "23", "14", "4", "8", "30000", "5", "striped"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert res["ok"] and res["checks_deferred"] == 0 and res["rollbacks"] == 0
 
 
 def test_owned_build_rccl_one_rank(gpu):

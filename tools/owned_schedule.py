@@ -4,8 +4,8 @@ the merge sequence of a real single-GPU run (bench.py --dump-trace): who owns wh
 merge (contiguous blocks, merge on the owner of j, k's remainder and the child stay there), which sets
 travel, and what every rank encodes at every convergence check.  The per-phase rates are the
 single-GPU measurements of the same run (its `phase_seconds`), so the output is the expected N-GPU
-wall time under the barrier-per-check schedule that the code implements, and under one-check
-lookahead; it is arithmetic, not a measurement.
+wall time with every check resolved on the spot (KSH_OWNED_LOOKAHEAD=0) and with the checks deferred
+by one, which is what the code does; it is arithmetic, not a measurement.
 
   owned_schedule.py trace.json [--gpus 8] [--link-gbs 64]
 """

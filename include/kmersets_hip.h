@@ -323,7 +323,10 @@ int ksh_kss_node_holder(const ksh_kss* k, int32_t i, int32_t* rank);
  *     stale nodes it owns and one all-gather of (n_strings, n_bases, size) per stale node puts
  *     the sum on all ranks.  A check only decides whether the loop stops, so its exchange is taken
  *     one check later: the ranks go on with the next interval meanwhile and undo it if the answer
- *     was "stop" (same result; a loaded rank no longer holds up the others at every check).
+ *     was "stop" (same result; a loaded rank no longer holds up the others at every check), and
+ *     before a check's encodes run they are dealt out again: the most loaded rank hands its largest
+ *     stale node to the least loaded one (the set travels under the encodes, on a second
+ *     communicator), which owns it from then on.
  * Trace, checkpoints, DAG and every node's set and SPSS equal the single-GPU build's; a node's
  * set and SPSS live on its owner only (ksh_kss_node_holder; ksh_kss_node answers
  * KSH_FAILED_PRECONDITION elsewhere, ksh_kss_get when a reachable node lives elsewhere).
@@ -355,8 +358,9 @@ int ksh_kss_build_owned(ksh_ctx* ctx, ksh_comm* comm, const ksh_geom* g, const k
  * members lived on different ranks), bytes it contributed to all-gathers, convergence checks whose
  * exchange was deferred by one check (the ranks go on with the next interval instead of waiting for the
  * slowest encoder; KSH_OWNED_LOOKAHEAD=0 turns that off), intervals undone because a deferred check
- * said "stop" }. */
-int ksh_kss_comm_stats(const ksh_kss* k, int64_t stats[6]);
+ * said "stop", sets this rank handed to a less loaded rank for encoding at a check (they live there
+ * afterwards; KSH_OWNED_MIGRATE=0 turns that off) }. */
+int ksh_kss_comm_stats(const ksh_kss* k, int64_t stats[7]);
 /* SPSS encodes this process ran for the build, and the k-mers they covered (the sharded build's
  * balance; in a single-GPU build: how many encodes the deferral left). */
 int ksh_kss_encode_counts(const ksh_kss* k, int64_t* n_encodes, int64_t* n_encoded_kmers);

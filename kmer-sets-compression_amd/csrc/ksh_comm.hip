@@ -83,6 +83,13 @@ struct ksh_comm {
   ksh_comm_fns fns{};
   Rccl rccl;
   comm_t nccl = nullptr;
+  // The side channel: a second communicator on a stream of its own, for what travels UNDER the
+  // context's compute -- the deferred exchanges of the convergence checks and the sets handed to
+  // another rank for encoding.  (A communicator of its own, because operations of one communicator
+  // must not run concurrently on two streams.)
+  comm_t nccl_side = nullptr;
+  hipStream_t side = nullptr;
+  hipEvent_t side_ready = nullptr, side_done = nullptr;
 };
 
 namespace ksh {
@@ -125,6 +132,55 @@ int comm_send(ksh_comm* c, const void* d_buf, size_t bytes, int peer) {
     return KSH_OK;
   }
   KSH_RCCL(c, c->rccl.send(d_buf, bytes, 0, peer, c->nccl, c->ctx->stream));
+  return KSH_OK;
+}
+
+// ---- the side channel.  Every operation starts when what the context's stream holds so far is done
+// (its buffers are complete) and then runs on the side stream, in the order of the calls -- which must be
+// the same on all ranks, like on the main channel.  Custom transport: the calls block, in place.
+static int side_after_main(ksh_comm* c) {
+  KSH_HIP(hipEventRecord(c->side_ready, c->ctx->stream));
+  KSH_HIP(hipStreamWaitEvent(c->side, c->side_ready, 0));
+  return KSH_OK;
+}
+
+int comm_side_allgather(ksh_comm* c, const void* d_send, void* d_recv, size_t bytes) {
+  if (c->custom || c->world == 1) return comm_allgather(c, d_send, d_recv, bytes);
+  KSH_TRY(side_after_main(c));
+  KSH_RCCL(c, c->rccl.all_gather(d_send, d_recv, bytes, 0, c->nccl_side, c->side));
+  return KSH_OK;
+}
+
+int comm_side_send(ksh_comm* c, const void* d_buf, size_t bytes, int peer) {
+  if (bytes == 0) return KSH_OK;
+  if (c->custom) return comm_send(c, d_buf, bytes, peer);
+  KSH_TRY(side_after_main(c));
+  KSH_RCCL(c, c->rccl.send(d_buf, bytes, 0, peer, c->nccl_side, c->side));
+  return KSH_OK;
+}
+
+int comm_side_recv(ksh_comm* c, void* d_buf, size_t bytes, int peer) {
+  if (bytes == 0) return KSH_OK;
+  if (c->custom) return comm_recv(c, d_buf, bytes, peer);
+  KSH_TRY(side_after_main(c));
+  KSH_RCCL(c, c->rccl.recv(d_buf, bytes, 0, peer, c->nccl_side, c->side));
+  return KSH_OK;
+}
+
+// The stream side operations run on (the context's own stream for the custom transport and for one rank).
+hipStream_t comm_side_stream(ksh_comm* c) { return (c->custom || c->world == 1) ? c->ctx->stream : c->side; }
+
+// The context's stream waits for everything the side channel holds so far (data it received).
+int comm_side_join_main(ksh_comm* c) {
+  if (c->custom || c->world == 1) return KSH_OK;
+  KSH_HIP(hipEventRecord(c->side_done, c->side));
+  KSH_HIP(hipStreamWaitEvent(c->ctx->stream, c->side_done, 0));
+  return KSH_OK;
+}
+
+// The host waits for everything the side channel holds so far.
+int comm_side_sync(ksh_comm* c) {
+  KSH_HIP(hipStreamSynchronize(comm_side_stream(c)));
   return KSH_OK;
 }
 
@@ -180,6 +236,34 @@ int ksh_comm_create_rccl(ksh_ctx* ctx, int32_t rank, int32_t world, const unsign
     delete c;
     return fail(KSH_INTERNAL, "ncclCommInitRank failed: %s", msg);
   }
+  // the side channel's communicator: rank 0 draws its id, an all-gather on the first one carries it
+  {
+    auto cleanup = [&](int code, const char* what) {
+      (void)c->rccl.comm_destroy(c->nccl);
+      delete c;
+      return fail(code, "side communicator: %s", what);
+    };
+    UniqueId mine;
+    std::memset(&mine, 0, sizeof(mine));
+    if (rank == 0 && c->rccl.get_unique_id(&mine) != 0) return cleanup(KSH_INTERNAL, "ncclGetUniqueId failed");
+    unsigned char *d_one = nullptr, *d_all = nullptr;
+    if (hipMalloc(reinterpret_cast<void**>(&d_one), sizeof(UniqueId)) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void**>(&d_all), sizeof(UniqueId) * size_t(world)) != hipSuccess)
+      return cleanup(KSH_INTERNAL, "hipMalloc failed");
+    UniqueId first;
+    bool ok = hipMemcpyAsync(d_one, &mine, sizeof(UniqueId), hipMemcpyHostToDevice, ctx->stream) == hipSuccess &&
+              c->rccl.all_gather(d_one, d_all, sizeof(UniqueId), 0, c->nccl, ctx->stream) == 0 &&
+              hipMemcpyAsync(&first, d_all, sizeof(UniqueId), hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+              hipStreamSynchronize(ctx->stream) == hipSuccess;
+    (void)hipFree(d_one);
+    (void)hipFree(d_all);
+    if (!ok) return cleanup(KSH_INTERNAL, "the exchange of its id failed");
+    if (c->rccl.comm_init_rank(&c->nccl_side, world, first, rank) != 0) return cleanup(KSH_INTERNAL, "ncclCommInitRank failed");
+    if (hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->side_ready, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->side_done, hipEventDisableTiming) != hipSuccess)
+      return cleanup(KSH_INTERNAL, "stream / event creation failed");
+  }
   *out = c;
   return KSH_OK;
 }
@@ -201,6 +285,13 @@ int ksh_comm_create_custom(ksh_ctx* ctx, int32_t rank, int32_t world, const ksh_
 
 int ksh_comm_destroy(ksh_comm* c) {
   if (!c) return KSH_OK;
+  if (c->side) {
+    (void)hipStreamSynchronize(c->side);
+    if (c->nccl_side) (void)c->rccl.comm_destroy(c->nccl_side);
+    (void)hipStreamDestroy(c->side);
+    (void)hipEventDestroy(c->side_ready);
+    (void)hipEventDestroy(c->side_done);
+  }
   if (c->nccl) {
     (void)hipStreamSynchronize(c->ctx->stream);
     (void)c->rccl.comm_destroy(c->nccl);

@@ -73,7 +73,7 @@ struct ksh_kss {
   // have to return to are parked instead of freed
   const std::unordered_set<void*>* keep_alive = nullptr;
   std::vector<void*>* graveyard = nullptr;
-  int64_t checks_deferred = 0, rollbacks = 0;
+  int64_t checks_deferred = 0, rollbacks = 0, sets_migrated = 0;
 };
 
 namespace ksh {
@@ -360,6 +360,24 @@ static int recv_set(ksh_kss* k, int peer, KssSet* out) {
   return KSH_OK;
 }
 
+// The same over the side channel (a set handed over for encoding): the context's stream picks the data up
+// when it has arrived.
+static int recv_set_side(ksh_kss* k, int peer, KssSet* out) {
+  ksh_ctx* ctx = k->ctx;
+  const int64_t nb = n_buckets(&k->g);
+  KSH_TRY(alloc_offsets(ctx, &k->g, out));
+  KSH_TRY(comm_side_recv(k->comm, out->off, size_t(nb + 1) * 8, peer));
+  KSH_TRY(comm_side_join_main(k->comm));
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, out->off + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  const int64_t n = ctx->h_pinned[0];
+  KSH_TRY(alloc_keys(ctx, &k->g, n, out));
+  KSH_TRY(comm_side_recv(k->comm, out->keys, size_t(n) * k->g.key_bytes, peer));
+  KSH_TRY(comm_side_join_main(k->comm));
+  k->p2p_bytes_received += (nb + 1) * 8 + n * k->g.key_bytes;
+  return KSH_OK;
+}
+
 // Weight table over the samples (every rank computes all of it: 2 % of the data, no exchange).
 static int sample_weights(ksh_kss* k, const std::vector<int32_t>& ids, const std::vector<std::pair<int, int>>& pairs,
                           std::vector<int64_t>* out) {
@@ -607,6 +625,10 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
     size_t n_rows = 0, n_exec = 0;
     std::unordered_set<void*> alive;
     std::vector<void*> graveyard;
+    // its exchange, started at the check, waited for at the next one
+    void *d_send = nullptr, *d_recv = nullptr;
+    int64_t* h_recv = nullptr;
+    hipEvent_t arrived = nullptr;
   } pend;
   std::vector<int> pending_of(k->compacts.size(), -1);  // the unresolved check that covers a node's SPSS, or -1
   int n_checks = 0;
@@ -629,7 +651,23 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
       }
   };
 
-  // encodes the stale nodes this rank owns; fills stale / send
+  // ---- who encodes what at a check.  A node is encoded where it lives, unless that rank is behind: the
+  // nine merges of an interval fall on eight ranks unevenly (and each leaves its large child where it
+  // ran), so a check's encodes are dealt out again -- the most loaded rank hands its largest node to the
+  // least loaded one while that shortens the longer of the two, a 10^8-k-mer set travels in 6 ms and
+  // encodes in 26 -- and the node then lives on its encoder.  Every rank computes the same deal from
+  // what all of them know: the sample sizes (2 % of the set sizes, up to noise) and, with deferred
+  // checks, how far behind each rank already is (lag: its load of the last checks beyond the
+  // lightest rank's).  A rank either gives or takes in one check, never both, so the transfers cannot
+  // wait on each other: givers send first (on the transport's side stream, under their own encodes),
+  // takers encode their own nodes first and then what arrives.  KSH_OWNED_MIGRATE=0 turns it off.
+  static const bool migrate = [] {
+    const char* e = getenv("KSH_OWNED_MIGRATE");
+    return !(e && e[0] == '0');
+  }();
+  std::vector<double> lag(size_t(world), 0.0);
+
+  // encodes the stale nodes this rank owns (after the deal); fills stale / send
   const auto encode_stale = [&](Pending* pd) {
     PhaseTimer pt(k, 3);
     pd->stale.clear();
@@ -637,12 +675,48 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
       if (!k->compacts[q].valid && pending_of[q] < 0) pd->stale.push_back(q);
     pd->send.assign(3 * pd->stale.size(), -1);
     pd->local_rc = KSH_OK;
-    for (size_t q = 0; q < pd->stale.size(); q++) {
+    const size_t n_tasks = pd->stale.size();
+    std::vector<int> encoder(n_tasks);
+    std::vector<double> cost(n_tasks);
+    std::vector<double> load = lag;
+    for (size_t q = 0; q < n_tasks; q++) {
+      encoder[q] = k->owner[pd->stale[q]];
+      cost[q] = double(k->samples[pd->stale[q]].n) + 1.0;
+      load[size_t(encoder[q])] += cost[q];
+    }
+    if (migrate && lookahead && world > 1) {
+      std::vector<int> role(size_t(world), 0);  // +1 gives, -1 takes
+      for (size_t round = 0; round < n_tasks; round++) {
+        int o = 0, m = 0;
+        for (int r = 1; r < world; r++) {
+          if (load[size_t(r)] > load[size_t(o)]) o = r;
+          if (load[size_t(r)] < load[size_t(m)]) m = r;
+        }
+        if (o == m || role[size_t(o)] < 0 || role[size_t(m)] > 0) break;
+        // the largest node of o that still shortens the longer of the two (a quarter of its cost for the trip)
+        int best = -1;
+        for (size_t q = 0; q < n_tasks; q++)
+          if (encoder[q] == o && k->owner[pd->stale[q]] == o && load[size_t(m)] + 1.25 * cost[q] < load[size_t(o)] &&
+              (best < 0 || cost[q] > cost[size_t(best)]))
+            best = int(q);
+        if (best < 0) break;
+        encoder[size_t(best)] = m;
+        load[size_t(o)] -= cost[size_t(best)];
+        load[size_t(m)] += 1.25 * cost[size_t(best)];
+        role[size_t(o)] = 1;
+        role[size_t(m)] = -1;
+      }
+    }
+    {
+      double lightest = load[0];
+      for (double l : load) lightest = std::min(lightest, l);
+      for (int r = 0; r < world; r++) lag[size_t(r)] = lookahead ? load[size_t(r)] - lightest : 0.0;
+    }
+    const auto encode_node = [&](size_t q) {
       const size_t node = pd->stale[q];
       KssCompact c;
       c.valid = false;
-      c.holder = k->owner[node];
-      if (k->owner[node] == rank && pd->local_rc == KSH_OK) {
+      if (pd->local_rc == KSH_OK) {
         pd->local_rc = encode_set(ctx, g, k->sets[node], k->canonical, &c);
         if (pd->local_rc == KSH_OK) {
           c.valid = false;  // known here, not yet everywhere
@@ -656,19 +730,95 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
           c = KssCompact{};
           c.valid = false;
         }
-        c.holder = rank;
       }
+      c.holder = rank;
       k->compacts[node] = c;
+    };
+    // 1. what I give away leaves first, under my own encodes
+    std::vector<size_t> given;
+    for (size_t q = 0; q < n_tasks; q++) {
+      const size_t node = pd->stale[q];
+      if (encoder[q] == k->owner[node]) continue;
+      if (k->owner[node] == rank) {
+        const KssSet& st = k->sets[node];
+        KSH_TRY(comm_side_send(k->comm, st.off, size_t(nb + 1) * 8, encoder[q]));
+        KSH_TRY(comm_side_send(k->comm, st.keys, size_t(st.n) * g->key_bytes, encoder[q]));
+        k->p2p_bytes_sent += (nb + 1) * 8 + st.n * g->key_bytes;
+        k->p2p_sets++;
+        k->sets_migrated++;
+        given.push_back(node);
+      }
+    }
+    // 2. my own nodes
+    for (size_t q = 0; q < n_tasks; q++)
+      if (encoder[q] == rank && k->owner[pd->stale[q]] == rank) encode_node(q);
+    // 3. what I take, as it arrives
+    for (size_t q = 0; q < n_tasks; q++) {
+      const size_t node = pd->stale[q];
+      if (encoder[q] == rank && k->owner[node] != rank) {
+        KSH_TRY(recv_set_side(k, k->owner[node], &k->sets[node]));
+        encode_node(q);
+      }
+    }
+    if (!given.empty()) {
+      KSH_TRY(comm_side_sync(k->comm));
+      for (size_t node : given) {
+        retire(k, k->sets[node].off);
+        retire(k, k->sets[node].keys);
+        k->sets[node] = KssSet{};
+      }
+    }
+    for (size_t q = 0; q < n_tasks; q++) {
+      const size_t node = pd->stale[q];
+      if (encoder[q] != rank) {
+        KssCompact c;
+        c.valid = false;
+        c.holder = encoder[q];
+        k->compacts[node] = c;
+      }
+      k->owner[node] = encoder[q];
       pending_of[node] = pd->id;
     }
     return KSH_OK;
   };
 
-  // the exchange and the decision of an unresolved check; *stop_out: the loop ends at that check
+  // a check's exchange starts right after the rank's encodes, on the transport's side channel: it
+  // completes when the last rank has got that far, while this one is already in the next interval
+  const auto start_exchange = [&](Pending* pd) {
+    const size_t bytes = pd->send.size() * 8;
+    if (bytes == 0) return KSH_OK;
+    KSH_TRY(pool_alloc(ctx, bytes, &pd->d_send));
+    KSH_TRY(pool_alloc(ctx, bytes * size_t(world), &pd->d_recv));
+    KSH_HIP(hipHostMalloc(reinterpret_cast<void**>(&pd->h_recv), bytes * size_t(world), hipHostMallocDefault));
+    KSH_HIP(hipEventCreateWithFlags(&pd->arrived, hipEventDisableTiming));
+    KSH_HIP(hipMemcpyAsync(pd->d_send, pd->send.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+    KSH_TRY(comm_side_allgather(k->comm, pd->d_send, pd->d_recv, bytes));  // (every rank gets here, whatever its encodes did)
+    KSH_HIP(hipMemcpyAsync(pd->h_recv, pd->d_recv, bytes * size_t(world), hipMemcpyDeviceToHost,
+                           comm_side_stream(k->comm)));
+    KSH_HIP(hipEventRecord(pd->arrived, comm_side_stream(k->comm)));
+    k->gather_bytes += int64_t(bytes);
+    return KSH_OK;
+  };
+  const auto finish_exchange = [&](Pending* pd, std::vector<int64_t>* recv) {
+    recv->assign(pd->send.size() * size_t(world), 0);
+    if (pd->send.empty()) return KSH_OK;
+    KSH_HIP(hipEventSynchronize(pd->arrived));
+    std::memcpy(recv->data(), pd->h_recv, recv->size() * 8);
+    pool_free(ctx, pd->d_send);
+    pool_free(ctx, pd->d_recv);
+    (void)hipHostFree(pd->h_recv);
+    (void)hipEventDestroy(pd->arrived);
+    pd->d_send = pd->d_recv = nullptr;
+    pd->h_recv = nullptr;
+    pd->arrived = nullptr;
+    return KSH_OK;
+  };
+
+  // the decision of an unresolved check; *stop_out: the loop ends at that check
   const auto resolve = [&](Pending* pd, bool* stop_out) {
     PhaseTimer pt(k, 3);
     std::vector<int64_t> recv;
-    KSH_TRY(gather_i64(k, pd->send, &recv));  // (every rank gets here, whatever its local encodes did)
+    KSH_TRY(finish_exchange(pd, &recv));
     if (pd->local_rc != KSH_OK) return fail(pd->local_rc, "%s", pd->local_msg.c_str());
     const std::vector<KssCompact>& at_check = pd->compacts;
     std::vector<const int64_t*> from(pd->stale.size(), nullptr);
@@ -735,11 +885,14 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
       next.id = ++n_checks;
       next.iteration = i;
       KSH_TRY(encode_stale(&next));
+      KSH_TRY(start_exchange(&next));
       if (pend.active) {
         bool stop = false;
         KSH_TRY(resolve(&pend, &stop));
         if (stop) {
-          stopped = true;  // (this check's encodes went with the roll-back)
+          stopped = true;  // (this check's encodes went with the roll-back; its exchange is in flight on every rank)
+          std::vector<int64_t> unused;
+          KSH_TRY(finish_exchange(&next, &unused));
           break;
         }
       }
@@ -1157,7 +1310,7 @@ int ksh_kss_build_owned(ksh_ctx* ctx, ksh_comm* comm, const ksh_geom* g, const k
   return KSH_OK;
 }
 
-int ksh_kss_comm_stats(const ksh_kss* k, int64_t stats[6]) {
+int ksh_kss_comm_stats(const ksh_kss* k, int64_t stats[7]) {
   if (!k || !stats) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
   stats[0] = k->p2p_bytes_sent;
   stats[1] = k->p2p_bytes_received;
@@ -1165,6 +1318,7 @@ int ksh_kss_comm_stats(const ksh_kss* k, int64_t stats[6]) {
   stats[3] = k->gather_bytes;
   stats[4] = k->checks_deferred;
   stats[5] = k->rollbacks;
+  stats[6] = k->sets_migrated;
   return KSH_OK;
 }
 

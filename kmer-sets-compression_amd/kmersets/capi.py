@@ -946,10 +946,10 @@ class OwnedKmerSetSet(DeviceKmerSetSet):
     __del__ = close
 
     def comm_stats(self):
-        st = (C.c_int64 * 6)()
+        st = (C.c_int64 * 7)()
         check(lib().ksh_kss_comm_stats(self.h, st))
         return dict(zip(["p2p_bytes_sent", "p2p_bytes_received", "p2p_sets", "gather_bytes", "checks_deferred",
-                         "rollbacks"], [int(x) for x in st]))
+                         "rollbacks", "sets_migrated"], [int(x) for x in st]))
 
     def node_table(self):
         """(size, XOR hash) of every node, from the ranks that hold them (one all-gather)."""

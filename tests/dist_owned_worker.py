@@ -75,7 +75,7 @@ def main():
     assert int(mine.min()) == 1 and int(mine.max()) == 1      # every node lives on exactly one rank
     cs = dkss.comm_stats()
     vec = torch.tensor([dkss.stats()["n_encodes"], cs["p2p_sets"], cs["p2p_bytes_sent"], cs["p2p_bytes_received"],
-                        len(held), cs["checks_deferred"], cs["rollbacks"]], dtype=torch.int64)
+                        len(held), cs["checks_deferred"], cs["rollbacks"], cs["sets_migrated"]], dtype=torch.int64)
     allv = [torch.zeros_like(vec) for _ in range(world)]
     dist.all_gather(allv, vec)
     if rank == 0:
@@ -84,7 +84,8 @@ def main():
                           "sets_sent_per_rank": [int(v[1]) for v in allv],
                           "bytes_sent": sum(int(v[2]) for v in allv), "bytes_received": sum(int(v[3]) for v in allv),
                           "nodes_per_rank": [int(v[4]) for v in allv],
-                          "checks": int(len(cp)), "checks_deferred": int(allv[0][5]), "rollbacks": int(allv[0][6])}))
+                          "checks": int(len(cp)), "checks_deferred": int(allv[0][5]), "rollbacks": int(allv[0][6]),
+                          "sets_migrated": sum(int(v[7]) for v in allv)}))
     dkss.close()
     dist.barrier()
     dist.destroy_process_group()

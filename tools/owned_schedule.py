@@ -72,6 +72,76 @@ def main():
     for c in range(0, len(pending), 2):
         pool = [sum(x) for x in zip(*pending[c:c + 2])]
         t_look += max(pool)
+    # ---- the schedule the library runs by default: a check's exchange is started after the rank's encodes
+    # and waited for at the NEXT check; before encoding, a check's nodes are dealt out again (the most loaded
+    # rank hands its largest node to the least loaded one while that shortens the longer of the two, a
+    # quarter of its cost for the trip, a rank either gives or takes; loads carry each rank's lag from the
+    # checks before) -- ksh_kss.hip build_owned, encode_stale.  Per-rank timelines:
+    def implemented():
+        sizes2 = list(d["input_sizes"])
+        own = [i * world // n0 for i in range(n0)]
+        st2 = set()
+        t = [0.0] * world
+        lag = [0.0] * world
+        done_prev = 0.0
+        moved = 0
+
+        def check2():
+            nonlocal done_prev, moved
+            tasks = sorted(st2)
+            cost = {n: sizes2[n] * enc_rate for n in tasks}
+            enc = {n: own[n] for n in tasks}
+            load = list(lag)
+            for n in tasks:
+                load[own[n]] += cost[n]
+            role = [0] * world
+            for _ in tasks:
+                o = max(range(world), key=lambda r: (load[r], -r))
+                m = min(range(world), key=lambda r: (load[r], r))
+                if o == m or role[o] < 0 or role[m] > 0:
+                    break
+                cand = [n for n in tasks if enc[n] == o and own[n] == o and load[m] + 1.25 * cost[n] < load[o]]
+                if not cand:
+                    break
+                n = max(cand, key=lambda x: cost[x])
+                enc[n] = m
+                load[o] -= cost[n]
+                load[m] += 1.25 * cost[n]
+                role[o], role[m] = 1, -1
+            lightest = min(load)
+            for r in range(world):
+                lag[r] = load[r] - lightest
+            start = list(t)
+            for r in range(world):
+                for n in tasks:
+                    if enc[n] == r and own[n] == r:
+                        t[r] += cost[n]
+            for n in tasks:
+                if enc[n] != own[n]:
+                    r = enc[n]
+                    arrive = start[own[n]] + sizes2[n] * key_bytes / (args.link_gbs * 1e9)
+                    t[r] = max(t[r], arrive) + cost[n]
+                    own[n] = r
+                    moved += 1
+            done_now = max(t)
+            for r in range(world):
+                t[r] = max(t[r], done_prev)       # the exchange of the check before, waited for here
+            done_prev = done_now
+            st2.clear()
+
+        for it2, (j2, k2, w2, orig2, diff2) in enumerate(rows):
+            if it2 > 0 and it2 % interval == 0:
+                check2()
+            nn2, nj2, nk2 = triples[it2]
+            sizes2[j2], sizes2[k2] = nj2, nk2
+            sizes2.append(nn2)
+            own[k2] = own[j2]
+            own.append(own[j2])
+            st2.update((j2, k2, len(own) - 1))
+        check2()
+        return max(max(t), done_prev), moved
+
+    t_impl, moved_impl = implemented()
     decode = ph["decode_inputs"] / world
     control = ph["weights"]                 # initial table + re-weighting + sample merges: replicated
     t1 = sum(ph.values())
@@ -84,10 +154,16 @@ def main():
         "encodes_perfect_balance_s": ph["encodes"] / world,
         "expected_total_barrier_s": decode + control + t_merge + t_p2p + t_barrier,
         "expected_total_lookahead_s": decode + control + t_merge + t_p2p + t_look,
+        "encodes_implemented_schedule_s": t_impl, "sets_handed_over_for_encoding": moved_impl,
+        "expected_total_implemented_s": decode + control + t_merge + t_p2p + t_impl,
         "max_rank_share_per_check": [max(l) / max(sum(l), 1e-12) for l in per_check],
     }
     out["speedup_barrier"] = t1 / out["expected_total_barrier_s"]
     out["speedup_lookahead"] = t1 / out["expected_total_lookahead_s"]
+    out["speedup_implemented"] = t1 / out["expected_total_implemented_s"]
+    # the merges run on one rank each while the others go on: a rank's own share of them is about 1 / N
+    out["expected_total_implemented_merges_spread_s"] = decode + control + t_merge / world + t_p2p + t_impl
+    out["speedup_implemented_merges_spread"] = t1 / out["expected_total_implemented_merges_spread_s"]
     print(json.dumps(out, indent=1))
 
 

@@ -85,6 +85,11 @@ class KmerSetSet {
     int rank = 0, world = 1;
     ksh_allgather_i64 gather = nullptr;
     void* user = nullptr;
+    // The owner-sharded build (ksh_kss_build_owned) when `comm` is set: a node's set and SPSS live on
+    // one rank; `owners[i]` holds input i, whose container only that rank needs to pass (the others'
+    // entries are ignored); comm comes from ksh_comm_create_rccl (or _custom) with this rank / world.
+    ksh_comm* comm = nullptr;
+    std::vector<std::int32_t> owners;
   };
 
   KmerSetSet(std::vector<Compact> kmer_sets_compact, bool canonical, int /*n_workers*/,
@@ -94,7 +99,15 @@ class KmerSetSet {
     for (const Compact& c : kmer_sets_compact) views.push_back(c.View());
     std::vector<std::int32_t> ids(bucket_ids.begin(), bucket_ids.end());
     ksh_kss* kss = nullptr;
-    if (shard.world > 1)
+    if (shard.comm) {
+      std::vector<std::int32_t> owners = shard.owners;
+      if (owners.empty())  // contiguous blocks
+        for (std::size_t i = 0; i < views.size(); i++)
+          owners.push_back(static_cast<std::int32_t>(i * std::size_t(shard.world) / views.size()));
+      ksc::Check(ksh_kss_build_owned(ksc::Ctx(), shard.comm, &g, views.data(), static_cast<std::int32_t>(views.size()),
+                                     owners.data(), ids.data(), static_cast<std::int32_t>(ids.size()),
+                                     canonical ? 1 : 0, max_iterations, &kss));
+    } else if (shard.world > 1)
       ksc::Check(ksh_kss_build_sharded(ksc::Ctx(), &g, views.data(), static_cast<std::int32_t>(views.size()),
                                        ids.data(), static_cast<std::int32_t>(ids.size()), canonical ? 1 : 0,
                                        max_iterations, shard.rank, shard.world, shard.gather, shard.user, &kss));

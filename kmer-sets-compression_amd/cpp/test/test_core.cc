@@ -337,6 +337,28 @@ static void TestSetSet(int n_sets, int length) {
   std::printf("  KmerSetSet<%d,%d>: %d -> %d nodes, %zu merges, N_proc = %lld\n", K, N, n_sets, kss.Size(),
               kss.Iterations().size(), static_cast<long long>(kss.ProcessedKmers()));
   std::filesystem::remove_all(dir);
+  // the owner-sharded constructor over an RCCL communicator, as far as one process goes (one rank):
+  // the same merge sequence and nodes as the plain constructor with the same bucket ids
+  {
+    const std::vector<int> ids = ksc::SampleBucketIds(N, ksc::BucketSeedFromEnv());
+    KmerSetSet<K, N, KeyType> plain(compacts, true, 4, ids);
+    unsigned char id[KSH_COMM_ID_BYTES];
+    ksc::Check(ksh_comm_unique_id(id));
+    ksh_comm* comm = nullptr;
+    ksc::Check(ksh_comm_create_rccl(ksc::Ctx(), 0, 1, id, &comm));
+    typename KmerSetSet<K, N, KeyType>::Shard shard;
+    shard.comm = comm;
+    KmerSetSet<K, N, KeyType> owned(compacts, true, 4, ids, -1, shard);
+    EXPECT_EQ(owned.Size(), plain.Size());
+    EXPECT_EQ(owned.Iterations().size(), plain.Iterations().size());
+    for (std::size_t t = 0; t < plain.Iterations().size() && t < owned.Iterations().size(); t++) {
+      EXPECT_EQ(owned.Iterations()[t].j, plain.Iterations()[t].j);
+      EXPECT_EQ(owned.Iterations()[t].k, plain.Iterations()[t].k);
+      EXPECT_EQ(owned.Iterations()[t].size_diff, plain.Iterations()[t].size_diff);
+    }
+    for (int i = 0; i < n_sets; i++) EXPECT_TRUE(owned.Get(i, true, 4).Equals(sets[i], 4));
+    ksc::Check(ksh_comm_destroy(comm));
+  }
 }
 
 int main() {

@@ -272,6 +272,8 @@ def main():
         "chars_per_kmer_before": st["initial_spss_weight"] / total,
         "chars_per_kmer_after": st["final_spss_weight"] / total,
         "nodes": st["nodes"], "iterations": int(it.shape[0]), "checkpoints": int(cp.shape[0]),
+        "encodes": st["n_encodes"], "encoded_kmers": st["n_encoded_kmers"],
+        "of_them_weight_only": st.get("n_weighed", 0), "weight_only_kmers": st.get("n_weighed_kmers", 0),
         "note": "from the last timed build; bytes = sum over nodes of ceil(2 * Weight / 8) + StreamVByte-0124 "
                 "size of the lengths (SURVEY.md 8d, metric 2)",
     }

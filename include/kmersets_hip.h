@@ -364,6 +364,12 @@ int ksh_kss_comm_stats(const ksh_kss* k, int64_t stats[7]);
 /* SPSS encodes this process ran for the build, and the k-mers they covered (the sharded build's
  * balance; in a single-GPU build: how many encodes the deferral left). */
 int ksh_kss_encode_counts(const ksh_kss* k, int64_t* n_encodes, int64_t* n_encoded_kmers);
+/* Of those encodes, the ones that only computed Weight() (the encode's plan without the write): with
+ * KSH_KSS_LOOP=ahead ksh_kss_build runs the control loop on the samples two intervals ahead of the sets
+ * (every decision of the loop reads sampled buckets only) and only weighs the stale nodes it will merge
+ * again.  Off by default: on loops of a few checks the strings owed when the last check stops the loop
+ * cost what the skipped writes saved. */
+int ksh_kss_weighed_counts(const ksh_kss* k, int64_t* n_weighed, int64_t* n_weighed_kmers);
 /* Wall seconds the build spent in: [0] decode of the inputs, [1] weight computations,
  * [2] merges (pair plan + write), [3] SPSS encodes (with, in a sharded build, the exchanges). */
 int ksh_kss_phase_seconds(const ksh_kss* k, double seconds[4]);

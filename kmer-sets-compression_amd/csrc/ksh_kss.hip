@@ -36,6 +36,7 @@ struct KssCompact {
   int64_t n_strings = 0, n_bases = 0, size = 0;
   bool owned = false;
   bool valid = true;  // false: the node's set changed and its SPSS has not been re-encoded yet
+  bool weight_only = false;  // valid, but only (n_strings, n_bases) are known: the strings were not written
   int holder = -1;    // sharded build: the rank that holds the SPSS (-1: every rank does)
 };
 
@@ -53,6 +54,7 @@ struct ksh_kss {
   int64_t initial_total_size = 0, final_total_size = 0, initial_spss_weight = 0, n_processed = 0;
   int64_t final_spss_weight = 0;
   int64_t n_encodes = 0, n_encoded_kmers = 0;
+  int64_t n_weighed = 0, n_weighed_kmers = 0;  // of them: weight only (encode plan without the write)
   double phase_seconds[4] = {0, 0, 0, 0};  // decode of the inputs, weights, merges, encodes
   std::string meta;
   // sharded build (ksh_kss_build_sharded): every rank runs the same loop on resident copies of
@@ -278,6 +280,22 @@ static int pair_weights(ksh_kss* k, const std::vector<int32_t>& ids,
 
 static std::string serialize_children(const std::map<int, std::vector<int>>& a);
 
+// Weight() of the node's SPSS without the SPSS: the encode's plan (unitigs, path cover, string layout)
+// gives n_strings and n_bases; the bases are not emitted.  For nodes the loop will merge again before it
+// ends: their strings would be thrown away (the convergence checks only read Weight(), kmer_set_set.h:287).
+static int weigh_set(ksh_ctx* ctx, const ksh_geom* g, const KssSet& s, int canonical_flag, KssCompact* out) {
+  const ksh_set_view v = view_of(s);
+  int64_t ns = 0, nbases = 0;
+  KSH_TRY(ksh_spss_encode_plan(ctx, g, &v, canonical_flag, 0, &ns, &nbases));
+  *out = KssCompact{};
+  out->n_strings = ns;
+  out->n_bases = nbases;
+  out->size = s.n;
+  out->valid = true;
+  out->weight_only = true;
+  return KSH_OK;
+}
+
 // ---------------------------------------------------------------------------------- owner-sharded
 // sizes[b] = keys of bucket b if it is sampled, else 0 (the scan of it = the sample's offsets)
 __global__ __launch_bounds__(256) void k_sample_sizes(const int64_t* __restrict__ off, const uint8_t* __restrict__ flag,
@@ -334,6 +352,21 @@ static int extract_sample(ksh_kss* k, const KssSet& full, const uint8_t* d_flag,
   *n_keys = ctx->h_pinned[0];
   (void)d_ids;
   (void)n_ids;
+  return KSH_OK;
+}
+
+// ... as a set of its own in pooled buffers.
+static int make_sample(ksh_kss* k, const KssSet& full, const uint8_t* d_flag, const int32_t* d_ids, int32_t n_ids,
+                       KssSet* out) {
+  ksh_ctx* ctx = k->ctx;
+  KSH_TRY(alloc_offsets(ctx, &k->g, out));
+  int64_t n = 0;
+  KSH_TRY(extract_sample(k, full, d_flag, d_ids, n_ids, out->off, &n));
+  KSH_TRY(alloc_keys(ctx, &k->g, n, out));
+  if (n_ids > 0 && n > 0)
+    hipLaunchKernelGGL(k_sample_copy, dim3(unsigned(n_ids)), dim3(256), 0, ctx->stream, full.off, out->off, d_ids,
+                       k->g.key_bytes, static_cast<const char*>(full.keys), static_cast<char*>(out->keys));
+  out->n = n;
   return KSH_OK;
 }
 
@@ -1222,6 +1255,252 @@ static int build(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs,
   return KSH_OK;
 }
 
+// The single-GPU constructor, control ahead of data.  Every decision of the loop reads sampled buckets
+// only (arg-max :308-316, the break on weight 0), and the samples of a merge's results are the merge of
+// the samples, so the merge sequence can be computed on the 2 % samples ahead of the full-size work
+// (what the loop WILL do unless a convergence check stops it; kept two intervals ahead).  The data
+// plane replays it on the resident sets with the convergence checks, and knows at every check which
+// stale nodes the loop merges again within that horizon: their SPSS would be thrown away, so only
+// their weight is computed (the encode's plan
+// without the write: 12 % of an encode, 44 % of the encoded k-mers at 64 x 10^8).  If a check stops the
+// loop early, the nodes that were only weighed get their strings then.  Same trace, checkpoints and
+// nodes as the statement-by-statement loop (`build`, which the replicated multi-GPU build still uses).
+static int build_single(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs, const std::vector<int32_t>& ids,
+                        int32_t max_iterations) {
+  ksh_ctx* ctx = k->ctx;
+  const ksh_geom* g = &k->g;
+  const int64_t nb = n_buckets(g);
+  for (int32_t i = 0; i < n_inputs; i++) {
+    KssCompact c;
+    c.words = const_cast<uint64_t*>(inputs[i].d_words);
+    c.lens = const_cast<uint32_t*>(inputs[i].d_lens);
+    c.n_strings = inputs[i].n_strings;
+    c.n_bases = inputs[i].n_bases;
+    c.owned = false;
+    KSH_TRY(ksh_spss_size(ctx, g, &inputs[i], &c.size));
+    k->compacts.push_back(c);
+    k->sets.emplace_back();
+    PhaseTimer pt(k, 0);
+    KSH_TRY(decode_to_set(ctx, g, &inputs[i], k->canonical, &k->sets.back()));
+  }
+
+  // ---- the control plane: the merge sequence, on the samples, a bounded distance ahead of the sets
+  // (without the convergence checks the loop would go on merging ever smaller intersections long
+  // after the point where a check stops it, so the sequence is extended on demand: two intervals
+  // beyond what the data plane is about to do)
+  struct Step {
+    int j, kk;
+    int64_t weight;
+  };
+  std::vector<Step> seq;
+  bool seq_complete = false;  // the control loop itself has ended (no common k-mers left / max_iterations)
+  std::map<std::pair<int, int>, int64_t> weights;
+  {
+    PhaseTimer pt(k, 1);
+    std::vector<uint8_t> flag(size_t(nb), 0);
+    for (int32_t b : ids) flag[size_t(b)] = 1;
+    uint8_t* d_flag = nullptr;
+    int32_t* d_ids = nullptr;
+    KSH_TRY(pool_alloc(ctx, size_t(nb), reinterpret_cast<void**>(&d_flag)));
+    KSH_TRY(pool_alloc(ctx, std::max<size_t>(ids.size() * 4, 16), reinterpret_cast<void**>(&d_ids)));
+    KSH_HIP(hipMemcpyAsync(d_flag, flag.data(), size_t(nb), hipMemcpyHostToDevice, ctx->stream));
+    KSH_HIP(hipMemcpyAsync(d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    for (int32_t i = 0; i < n_inputs; i++) {
+      KssSet smp;
+      KSH_TRY(make_sample(k, k->sets[size_t(i)], d_flag, d_ids, int32_t(ids.size()), &smp));
+      k->samples.push_back(smp);
+      k->sample_pooled.push_back(true);
+    }
+    KSH_HIP(hipStreamSynchronize(ctx->stream));
+    pool_free(ctx, d_flag);
+    pool_free(ctx, d_ids);
+    std::vector<std::pair<int, int>> pairs;
+    for (int i = 0; i < n_inputs; i++)
+      for (int j = i + 1; j < n_inputs; j++) pairs.emplace_back(i, j);
+    std::vector<int64_t> w;
+    KSH_TRY(sample_weights(k, ids, pairs, &w));
+    for (size_t i = 0; i < pairs.size(); i++) weights[pairs[i]] = w[i];
+    k->initial_weights = w;
+  }
+  const auto extend_sequence = [&](int upto) {
+    PhaseTimer pt(k, 1);
+    while (!seq_complete && int(seq.size()) < upto) {
+      if (max_iterations >= 0 && int(seq.size()) >= max_iterations) {
+        seq_complete = true;
+        break;
+      }
+      const int n = int(k->samples.size());
+      int64_t weight = 0;
+      int j = -1, kk = -1;
+      for (const auto& p : weights)
+        if (p.second > weight) {
+          j = p.first.first;
+          kk = p.first.second;
+          weight = p.second;
+        }
+      if (weight == 0) {
+        seq_complete = true;
+        break;
+      }
+      seq.push_back({j, kk, weight});
+      const ksh_set_view vj = view_of(k->samples[size_t(j)]), vk = view_of(k->samples[size_t(kk)]);
+      KssSet sn, sj, sk;
+      KSH_TRY(alloc_offsets(ctx, g, &sn));
+      KSH_TRY(alloc_offsets(ctx, g, &sj));
+      KSH_TRY(alloc_offsets(ctx, g, &sk));
+      int64_t totals[3];
+      KSH_TRY(ksh_pair_plan(ctx, g, &vj, &vk, sn.off, sj.off, sk.off, totals));
+      KSH_TRY(alloc_keys(ctx, g, totals[0], &sn));
+      KSH_TRY(alloc_keys(ctx, g, totals[1], &sj));
+      KSH_TRY(alloc_keys(ctx, g, totals[2], &sk));
+      KSH_TRY(ksh_pair_write(ctx, g, &vj, &vk, sn.keys, sj.keys, sk.keys));
+      free_sample(k, size_t(j));
+      free_sample(k, size_t(kk));
+      k->samples[size_t(j)] = sj;
+      k->samples[size_t(kk)] = sk;
+      k->sample_pooled[size_t(j)] = k->sample_pooled[size_t(kk)] = true;
+      k->samples.push_back(sn);
+      k->sample_pooled.push_back(true);
+      std::vector<std::pair<int, int>> pairs;
+      for (int l = 0; l < n; l++)
+        if (j != l) pairs.emplace_back(std::min(j, l), std::max(j, l));
+      for (int l = 0; l < n; l++)
+        if (kk != l) pairs.emplace_back(std::min(kk, l), std::max(kk, l));
+      for (int l = 0; l < n; l++) pairs.emplace_back(l, n);
+      std::vector<int64_t> w;
+      KSH_TRY(sample_weights(k, ids, pairs, &w));
+      for (size_t q = 0; q < pairs.size(); q++) weights[pairs[q]] = w[q];
+    }
+    return KSH_OK;
+  };
+  // will the loop, as far as it is known, merge this node at iteration `from` or later?
+  const auto merged_again = [&](size_t node, int from) {
+    for (size_t t = size_t(from); t < seq.size(); t++)
+      if (size_t(seq[t].j) == node || size_t(seq[t].kk) == node) return true;
+    return false;
+  };
+
+  // ---- the data plane: the sets
+  int64_t total_size = 0;
+  for (const KssCompact& c : k->compacts) total_size += c.size;
+  k->initial_total_size = total_size;
+  k->n_processed = total_size;
+
+  // at_iteration: the loop is about to run this iteration (stale nodes merged at or after it are only weighed)
+  const auto total_spss_weight_now = [&](int at_iteration, int64_t* total) {
+    PhaseTimer pt(k, 3);
+    for (size_t q = 0; q < k->compacts.size(); q++) {
+      if (k->compacts[q].valid) continue;
+      KssCompact c;
+      if (merged_again(q, at_iteration)) {
+        KSH_TRY(weigh_set(ctx, g, k->sets[q], k->canonical, &c));
+        k->n_weighed++;
+        k->n_weighed_kmers += k->sets[q].n;
+      } else {
+        KSH_TRY(encode_set(ctx, g, k->sets[q], k->canonical, &c));
+      }
+      k->compacts[q] = c;
+      k->n_encodes++;
+      k->n_encoded_kmers += k->sets[q].n;
+    }
+    *total = 0;
+    for (const KssCompact& c : k->compacts) *total += c.n_bases;
+    return KSH_OK;
+  };
+  int64_t total_spss_weight = 0;
+  KSH_TRY(total_spss_weight_now(0, &total_spss_weight));
+  k->initial_spss_weight = total_spss_weight;
+
+  const int interval = int(k->compacts.size() / 8 + 1);
+  const float improvement_threshold = 0.1 * interval / k->compacts.size();
+  int done = 0;  // iterations run
+  for (int i = 0;; i++) {
+    KSH_TRY(extend_sequence(i + 2 * interval));
+    if (i >= int(seq.size())) break;  // the control loop ended here
+    if (i > 0 && i % interval == 0) {
+      int64_t updated = 0;
+      KSH_TRY(total_spss_weight_now(i, &updated));
+      const float improvement = static_cast<float>(total_spss_weight - updated) / total_spss_weight;
+      const bool stop = improvement <= improvement_threshold;
+      k->checkpoints.insert(k->checkpoints.end(), {int64_t(i), total_spss_weight, updated, int64_t(stop)});
+      k->improvements.push_back(improvement);
+      if (stop) break;
+      total_spss_weight = updated;
+    }
+    const int n = int(k->compacts.size());
+    const int j = seq[size_t(i)].j, kk = seq[size_t(i)].kk;
+    const int64_t original_size = k->compacts[size_t(j)].size + k->compacts[size_t(kk)].size;
+    {
+      const ksh_set_view vj = view_of(k->sets[size_t(j)]), vk = view_of(k->sets[size_t(kk)]);
+      KssSet sn, sj, sk;
+      KSH_TRY(alloc_offsets(ctx, g, &sn));
+      KSH_TRY(alloc_offsets(ctx, g, &sj));
+      KSH_TRY(alloc_offsets(ctx, g, &sk));
+      int64_t totals[3];
+      {
+        PhaseTimer pt(k, 2);
+        KSH_TRY(ksh_pair_plan(ctx, g, &vj, &vk, sn.off, sj.off, sk.off, totals));
+        KSH_TRY(alloc_keys(ctx, g, totals[0], &sn));
+        KSH_TRY(alloc_keys(ctx, g, totals[1], &sj));
+        KSH_TRY(alloc_keys(ctx, g, totals[2], &sk));
+        KSH_TRY(ksh_pair_write(ctx, g, &vj, &vk, sn.keys, sj.keys, sk.keys));
+      }
+      KssCompact cn, cj, ck;
+      cn.valid = cj.valid = ck.valid = false;
+      cn.size = sn.n;
+      cj.size = sj.n;
+      ck.size = sk.n;
+      k->sets.push_back(sn);
+      k->compacts.push_back(cn);
+      free_set(ctx, &k->sets[size_t(j)]);
+      free_compact(ctx, &k->compacts[size_t(j)]);
+      k->sets[size_t(j)] = sj;
+      k->compacts[size_t(j)] = cj;
+      free_set(ctx, &k->sets[size_t(kk)]);
+      free_compact(ctx, &k->compacts[size_t(kk)]);
+      k->sets[size_t(kk)] = sk;
+      k->compacts[size_t(kk)] = ck;
+      k->children[j].push_back(n);
+      k->children[kk].push_back(n);
+    }
+    const int64_t size_diff = k->compacts[size_t(n)].size + k->compacts[size_t(j)].size +
+                              k->compacts[size_t(kk)].size - original_size;
+    total_size += size_diff;
+    k->n_processed += original_size;
+    k->trace.insert(k->trace.end(), {int64_t(j), int64_t(kk), seq[size_t(i)].weight, original_size, size_diff});
+    done = i + 1;
+  }
+  k->final_total_size = total_size;
+  for (size_t q = 0; q < k->samples.size(); q++) free_sample(k, q);
+  k->samples.clear();
+  k->sample_pooled.clear();
+  // the loop is over: nothing is merged again.  What is stale gets its strings, and so does what was
+  // only weighed (a check stopped the loop before the merge that was to come)
+  {
+    PhaseTimer pt(k, 3);
+    for (size_t q = 0; q < k->compacts.size(); q++) {
+      KssCompact& c = k->compacts[q];
+      if (c.valid && !c.weight_only) continue;
+      const bool was_weighed = c.valid && c.weight_only;
+      const int64_t bases_before = c.n_bases;
+      KssCompact full;
+      KSH_TRY(encode_set(ctx, g, k->sets[q], k->canonical, &full));
+      if (was_weighed && full.n_bases != bases_before)
+        return fail(KSH_INTERNAL, "node %zu: weight %lld when weighed, %lld when encoded", q, (long long)bases_before,
+                    (long long)full.n_bases);
+      c = full;
+      k->n_encodes++;
+      k->n_encoded_kmers += k->sets[q].n;
+    }
+    k->final_spss_weight = 0;
+    for (const KssCompact& c : k->compacts) k->final_spss_weight += c.n_bases;
+  }
+  (void)done;
+  KSH_HIP(hipStreamSynchronize(ctx->stream));
+  k->meta = serialize_children(k->children);
+  return KSH_OK;
+}
+
 }  // namespace ksh
 
 using namespace ksh;
@@ -1241,8 +1520,17 @@ int ksh_kss_build(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* inputs, 
   k->g = *g;
   k->canonical = canonical_flag;
   std::vector<int32_t> ids(bucket_ids, bucket_ids + n_ids);
+  // KSH_KSS_LOOP=ahead: the control loop run on the samples ahead of the sets, so that stale nodes the
+  // loop merges again are only weighed (build_single).  Measured on 64 x 10^8 (7 checks): it skips the
+  // write of 45 % of the encoded k-mers, and gives the time back when the last check stops the loop and
+  // the nodes it had only weighed need their strings after all -- 1.97 s against 1.92 s; not the default.
+  static const bool control_ahead = [] {
+    const char* e = getenv("KSH_KSS_LOOP");
+    return e && std::string(e) == "ahead";
+  }();
   int rc = KSH_OK;
-  if (n_inputs > 0) rc = build(k, inputs, n_inputs, ids, max_iterations);
+  if (n_inputs > 0)
+    rc = control_ahead ? build_single(k, inputs, n_inputs, ids, max_iterations) : build(k, inputs, n_inputs, ids, max_iterations);
   if (rc != KSH_OK) {
     ksh_kss_destroy(k);
     return rc;
@@ -1319,6 +1607,13 @@ int ksh_kss_comm_stats(const ksh_kss* k, int64_t stats[7]) {
   stats[4] = k->checks_deferred;
   stats[5] = k->rollbacks;
   stats[6] = k->sets_migrated;
+  return KSH_OK;
+}
+
+int ksh_kss_weighed_counts(const ksh_kss* k, int64_t* n_weighed, int64_t* n_weighed_kmers) {
+  if (!k || !n_weighed || !n_weighed_kmers) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  *n_weighed = k->n_weighed;
+  *n_weighed_kmers = k->n_weighed_kmers;
   return KSH_OK;
 }
 

@@ -144,6 +144,7 @@ def lib():
                                           C.c_int, i32, C.POINTER(vp)]),
         "ksh_kss_comm_stats": (C.c_int, [vp, C.POINTER(i64)]),
         "ksh_kss_encode_counts": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
+        "ksh_kss_weighed_counts": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
         "ksh_kss_phase_seconds": (C.c_int, [vp, C.POINTER(C.c_double)]),
         "ksh_kss_destroy": (C.c_int, [vp]),
         "ksh_kss_size": (C.c_int, [vp, C.POINTER(i32)]),
@@ -792,6 +793,8 @@ class DeviceKmerSetSet:
         ne, nk = C.c_int64(), C.c_int64()
         check(lib().ksh_kss_encode_counts(self.h, C.byref(ne), C.byref(nk)))
         out["n_encodes"], out["n_encoded_kmers"] = ne.value, nk.value
+        check(lib().ksh_kss_weighed_counts(self.h, C.byref(ne), C.byref(nk)))
+        out["n_weighed"], out["n_weighed_kmers"] = ne.value, nk.value
         ph = (C.c_double * 4)()
         check(lib().ksh_kss_phase_seconds(self.h, ph))
         out["phase_seconds"] = dict(zip(["decode_inputs", "weights", "merges", "encodes"], [float(x) for x in ph]))

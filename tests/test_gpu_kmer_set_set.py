@@ -217,3 +217,38 @@ def test_owned_build_rccl_one_rank(gpu):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "rccl one-rank ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_loop_control_ahead(gpu):
+    """KSH_KSS_LOOP=ahead (the control loop on the samples ahead of the sets, stale nodes that are merged
+    again only weighed): the same trace, checkpoints, DAG and node strings as the oracle -- in a process of
+    its own, the switch is read once."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import oracle_lib as ol\n"
+        "from kmersets import capi, synth\n"
+        "ctx = capi.Context(0)\n"
+        "for (k, n, kb, n_sets, size, seed) in ((15, 14, 2, 10, 6000, 3), (23, 14, 4, 12, 20000, 5), (31, 14, 8, 6, 20000, 7)):\n"
+        "    g = capi.geom(k, n)\n"
+        "    sets = synth.phylogeny_sets(k, n_sets, size, seed=seed); ids = synth.sample_bucket_ids(n, seed=seed + 1)\n"
+        "    oc = [ol.Set.from_kmers(k, n, kb, s).compact() for s in sets]\n"
+        "    o = ol.KmerSetSet(oc, ids)\n"
+        "    d = capi.DeviceKmerSetSet(ctx, [capi.DeviceSpss.from_strings(g, c.strings(), ctx.device) for c in oc], ids)\n"
+        "    it, cp, imp = d.trace(); ocp, oimp = o.checkpoints()\n"
+        "    assert np.array_equal(it, o.iterations()) and np.array_equal(cp, ocp) and np.array_equal(imp, oimp)\n"
+        "    assert d.meta() == o.meta() and d.size() == o.size()\n"
+        "    assert all(d.node_strings(i) == o.node(i).strings() for i in range(o.size()))\n"
+        "    st = d.stats(); assert st['n_processed'] == o.stat(3)\n"
+        "    print('weighed', st['n_weighed'], 'of', st['n_encodes'])\n"
+        "    d.close()\n"
+        "print('control ahead ok')\n"
+    ) % (os.path.join(here, "..", "kmer-sets-compression_amd"), here)
+    env = dict(os.environ, KSH_KSS_LOOP="ahead")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "control ahead ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

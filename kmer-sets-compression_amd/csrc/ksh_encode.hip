@@ -634,10 +634,21 @@ __global__ __launch_bounds__(kRcThreads) void k_adj_rc(DevSet<KeyT> set, int nbi
 // A chunk whose k-mers span two top bases, or whose range does not fit the window or spans too
 // many buckets, probes that part in global memory as k_adj_fwd does.
 constexpr int kFwdChunk = 512;
-constexpr int kFwdCapNext = 3072;  // keys: 4 x chunk with half to spare
-constexpr int kFwdCapPrev = 256;   // keys per c: chunk / 4 with as much to spare
-static_assert(kFwdCapPrev <= kFwdChunk && kFwdCapNext % kFwdChunk == 0, "staging shape");
-constexpr int kFwdSpan = 8;        // bucket offsets kept per range (and for the chunk itself)
+// The ranges are "about" 4 x and 1/4 x the chunk only where the set is equally dense at the chunk and at
+// its targets, and a canonical set is not: a k-mer is the smaller of itself and its reverse complement,
+// so k-mers starting with A, C, G, T are kept in the proportions 7 : 5 : 3 : 1, and a chunk of T... k-mers
+// whose successors start with A finds 7 x as many keys in its Next range.  The windows below hold a
+// ratio of 1.5; 15 % of the k-mers of a random genome exceed it and probe in global memory (a build with
+// -DKSH_FWD_DEBUG counts them).  Measured: windows for a ratio of 4 cut that to 3 % and made the kernel
+// SLOWER (2.0 -> 2.2 ms per 10^8: 48 KB of LDS, three workgroups per CU instead of four) -- the kernel is
+// bound by how many workgroups are in flight, not by the fall-backs.
+template <typename KeyT>
+struct FwdCfg {
+  static constexpr int kCapNext = 3072;  // keys: 4 x chunk with half to spare
+  static constexpr int kCapPrev = 512;   // keys per c (a whole number of rounds of the workgroup)
+  static_assert(kCapPrev % kFwdChunk == 0 && kCapNext % kFwdChunk == 0, "staging shape");
+};
+constexpr int kFwdSpan = 16;       // bucket offsets kept per range (and for the chunk itself)
 
 // bounds[kFwdBounds * c + ..] for chunk boundary t = c * kFwdChunk (c = 0 .. n_chunks):
 //   [0]     first index >= Next(x_t, 0)            (start of chunk c's Next range)
@@ -681,12 +692,16 @@ __device__ __forceinline__ int lds_lower_bound(const KeyT* a, int lo, int hi, Ke
   return lo;
 }
 
+// KSH_FWD_DEBUG=1: how often the staged forward probe falls back to global probes (per k-mer and cause)
+__device__ unsigned long long g_fwd_dbg[8];
+
 template <typename KeyT>
 __global__ __launch_bounds__(kFwdChunk) void k_adj_fwd_staged(DevSet<KeyT> set, const int64_t* __restrict__ bounds,
                                                               const uint32_t* __restrict__ rc0,
                                                               const uint32_t* __restrict__ rc1,
                                                               uint32_t* __restrict__ nbr,
                                                               int* __restrict__ self_rc) {
+  constexpr int kFwdCapNext = FwdCfg<KeyT>::kCapNext, kFwdCapPrev = FwdCfg<KeyT>::kCapPrev;
   __shared__ KeyT s_next[kFwdCapNext];
   __shared__ KeyT s_prev[4][kFwdCapPrev];
   __shared__ int64_t s_b[2 * kFwdBounds];     // this boundary's and the next one's records
@@ -732,20 +747,24 @@ __global__ __launch_bounds__(kFwdChunk) void k_adj_fwd_staged(DevSet<KeyT> set, 
   }
   {
     // every load of the staging before the first LDS store: one round trip, not ten
-    constexpr int kPer = kFwdCapNext / kFwdChunk;
-    KeyT vn[kPer], vp[4];
+    constexpr int kPer = kFwdCapNext / kFwdChunk, kPerPrev = kFwdCapPrev / kFwdChunk;
+    KeyT vn[kPer], vp[4][kPerPrev];
 #pragma unroll
     for (int u = 0; u < kPer; u++)
       if (tid + u * kFwdChunk < len[0]) vn[u] = set.keys[lo_of[0] + tid + u * kFwdChunk];
 #pragma unroll
     for (int cc = 0; cc < 4; cc++)
-      if (tid < len[1 + cc]) vp[cc] = set.keys[lo_of[1 + cc] + tid];
+#pragma unroll
+      for (int u = 0; u < kPerPrev; u++)
+        if (tid + u * kFwdChunk < len[1 + cc]) vp[cc][u] = set.keys[lo_of[1 + cc] + tid + u * kFwdChunk];
 #pragma unroll
     for (int u = 0; u < kPer; u++)
       if (tid + u * kFwdChunk < len[0]) s_next[tid + u * kFwdChunk] = vn[u];
 #pragma unroll
     for (int cc = 0; cc < 4; cc++)
-      if (tid < len[1 + cc]) s_prev[cc][tid] = vp[cc];
+#pragma unroll
+      for (int u = 0; u < kPerPrev; u++)
+        if (tid + u * kFwdChunk < len[1 + cc]) s_prev[cc][tid + u * kFwdChunk] = vp[cc][u];
   }
   __syncthreads();
   if (t >= set.n) return;
@@ -774,6 +793,13 @@ __global__ __launch_bounds__(kFwdChunk) void k_adj_fwd_staged(DevSet<KeyT> set, 
   {
     const uint64_t g0 = kmer_next(x, k, 0);
     int64_t blo, bhi;
+#ifdef KSH_FWD_DEBUG
+    atomicAdd(&g_fwd_dbg[0], 1ull);
+    if (!usable[0]) atomicAdd(&g_fwd_dbg[1], 1ull);
+    else if (!bucket_range(0, int64_t(g0 >> set.key_bits), &blo, &bhi)) atomicAdd(&g_fwd_dbg[2], 1ull);
+    if (s_b[kFwdBounds + 5] - s_b[0] > kFwdCapNext) atomicAdd(&g_fwd_dbg[5], 1ull);
+    if ((x_first >> (2 * k - 2)) != (x_last >> (2 * k - 2))) atomicAdd(&g_fwd_dbg[6], 1ull);
+#endif
     if (usable[0] && bucket_range(0, int64_t(g0 >> set.key_bits), &blo, &bhi)) {
       const KeyT gkey = KeyT(g0 & set.key_mask());
       const int64_t hi0 = lo_of[0] + len[0];
@@ -804,6 +830,10 @@ __global__ __launch_bounds__(kFwdChunk) void k_adj_fwd_staged(DevSet<KeyT> set, 
     if (z == x) continue;
     int64_t idx = -1;
     int64_t blo, bhi;
+#ifdef KSH_FWD_DEBUG
+    if (!usable[1 + c]) atomicAdd(&g_fwd_dbg[3], 1ull);
+    else if (!bucket_range(1 + c, int64_t(z >> set.key_bits), &blo, &bhi)) atomicAdd(&g_fwd_dbg[4], 1ull);
+#endif
     if (usable[1 + c] && bucket_range(1 + c, int64_t(z >> set.key_bits), &blo, &bhi)) {
       const KeyT zkey = KeyT(z & set.key_mask());
       const int64_t hi0 = lo_of[1 + c] + len[1 + c];
@@ -1984,6 +2014,17 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
         hipLaunchKernelGGL((k_fwd_bounds<KeyT>), dim3(nblk(n_chunks + 1)), dim3(256), 0, st, set, n_chunks, bounds);
         hipLaunchKernelGGL((k_adj_fwd_staged<KeyT>), dim3(unsigned(n_chunks)), dim3(kFwdChunk), 0, st, set, bounds,
                            rc0, rc1, p->nbr, flags + 1);
+#ifdef KSH_FWD_DEBUG
+        {
+          unsigned long long h[8];
+          (void)hipStreamSynchronize(st);
+          (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fwd_dbg), sizeof(h));
+          fprintf(stderr, "fwd dbg: kmers %llu next!usable %llu next-bucket-miss %llu prev!usable %llu prev-bucket-miss %llu "
+                          "next-range>cap %llu two-top-bases %llu\n", h[0], h[1], h[2], h[3], h[4], h[5], h[6]);
+          unsigned long long z[8] = {};
+          (void)hipMemcpyToSymbol(HIP_SYMBOL(g_fwd_dbg), z, sizeof(z));
+        }
+#endif
       }
     } else {
       hipLaunchKernelGGL((k_adjacency<KeyT, false>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr, flags + 1);

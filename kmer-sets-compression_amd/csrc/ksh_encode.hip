@@ -16,7 +16,7 @@
 //
 //   k_adjacency   8 membership probes per k-mer (4 Next, 4 Prev, forward or reverse
 //                 complement) -> per side: none / the single neighbour / many
-//   k_links       mutual singles
+//   k_link_cut    mutual singles: the k-mers with several neighbours on a side cut the facing entries
 //   k_ruler_*     chains of states ranked through a sparse ruler set: (end, distance to end)
 //   k_choose      per k-mer: the chain that starts at the larger end (spss.h:511,555)
 //   k_loops       non-branching loops, spelled from their smallest k-mer (spss.h:585-610)
@@ -79,6 +79,55 @@ __global__ __launch_bounds__(256) void k_fine_index(const int64_t* __restrict__ 
   if (b == n_buckets - 1 && threadIdx.x == 0) fine[n_buckets << fine_bits] = uint32_t(hi);
 }
 
+// The neighbours of one side of k-mer x (index t, rx = rc(x)): f(index, same) for each, where
+// same = 1 when the edge joins the same side of both k-mers (the neighbour is reached through a
+// reverse complement).
+//   Canonical sets: the 8 candidates of the reference (Next / Prev of x, each as is or
+//   reverse-complemented, spss.h:238-273) in two kinds.  The four Next(x, c) are consecutive
+//   values, and so are the four Next(rc(x), c) = rc(Prev(x, 3 - c)): one bounded search each
+//   finds all of their members that are in the set (only a canonical k-mer can be).  The other
+//   candidates, Prev(x, c) and Prev(rc(x), c) = rc(Next(x, 3 - c)), sit in four different buckets
+//   and are probed one by one, and only when they are the canonical form.
+//   Non-canonical sets (GetUnitigs, spss.h:76-96): k-mers as they are, side 1 = outgoing edges
+//   Next(x, .) (one bounded search), side 0 = incoming edges Prev(x, .) (four buckets, probed one
+//   by one); no edge flips an orientation.
+template <typename KeyT, bool kDirected, typename F>
+__device__ __forceinline__ void for_side_neighbours(const DevSet<KeyT>& set, uint64_t x, uint64_t rx,
+                                                    int64_t t, int side, F f) {
+  const int k = set.k;
+  if (kDirected) {
+    if (side) {
+      set.for_group4(kmer_next(x, k, 0), [&](int64_t idx) {
+        if (idx != t) f(idx, 0u);  // next != kmer (spss.h:81)
+      });
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const uint64_t z = kmer_prev(x, k, c);
+        if (z == x) continue;  // prev != kmer (spss.h:91)
+        const int64_t idx = set.find(z);
+        if (idx >= 0) f(idx, 0u);
+      }
+    }
+    return;
+  }
+  // group: side 1 -> Next(x, .) (neighbour as is);  side 0 -> Next(rc(x), .) (neighbour
+  // reverse-complemented, i.e. a same-side edge)
+  set.for_group4(kmer_next(side ? x : rx, k, 0), [&](int64_t idx) {
+    if (idx != t) f(idx, side ? 0u : 1u);  // kmer != next (spss.h:242,248)
+  });
+  // singles: side 1 -> Prev(rc(x), c) = rc(Next(x, 3 - c));  side 0 -> Prev(x, c) as is
+  const uint64_t base = side ? rx : x;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    const uint64_t z = kmer_prev(base, k, c);
+    if (revcomp(z, k) < z) continue;  // not canonical: cannot be in the set
+    if (z == x) continue;
+    const int64_t idx = set.find(z);
+    if (idx >= 0) f(idx, side ? 1u : 0u);
+  }
+}
+
 // *self_rc is raised when a canonical set holds a k-mer that is its own reverse complement
 // (possible for even k only): its two sides coincide, which the edge table of the path cover (one
 // slot per base) does not model, and no instantiation of the reference has an even K.
@@ -89,63 +138,47 @@ __global__ __launch_bounds__(256) void k_adjacency(DevSet<KeyT> set, uint32_t* _
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const uint64_t x = set.kmer_in_block(t, s_bucket);
   if (t >= set.n) return;
-  const int k = set.k;
+  const uint64_t rx = kDirected ? 0 : revcomp(x, set.k);
+  if (!kDirected && rx == x) *self_rc = 1;
   int cnt[2] = {0, 0};
   uint32_t single[2] = {kNone, kNone};
-  if (kDirected) {
-    // Non-canonical sets (GetUnitigs, spss.h:76-96): k-mers as they are, side 1 = outgoing edges
-    // Next(x, .) (four consecutive values, one bounded search), side 0 = incoming edges
-    // Prev(x, .) (four buckets, probed one by one); no edge flips an orientation.
-    set.for_group4(kmer_next(x, k, 0), [&](int64_t idx) {
-      if (idx == t) return;  // next != kmer (spss.h:81)
-      cnt[1]++;
-      single[1] = uint32_t(idx) << 1;
-    });
 #pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const uint64_t z = kmer_prev(x, k, c);
-      if (z == x) continue;  // prev != kmer (spss.h:91)
-      const int64_t idx = set.find(z);
-      if (idx < 0) continue;
-      cnt[0]++;
-      single[0] = uint32_t(idx) << 1;
-    }
-  } else {
-  // The 8 candidates of the reference (Next / Prev of x, each as is or reverse-complemented,
-  // spss.h:238-273) in two kinds.  The four Next(x, c) are consecutive values, and so are the
-  // four Next(rc(x), c) = rc(Prev(x, 3 - c)): one bounded search each finds all of their
-  // members that are in the set (only a canonical k-mer can be).  The other candidates,
-  // Prev(x, c) and Prev(rc(x), c) = rc(Next(x, 3 - c)), sit in four different buckets and are
-  // probed one by one, and only when they are the canonical form.
-  const uint64_t rx = revcomp(x, k);
-  if (rx == x) *self_rc = 1;
-#pragma unroll
-  for (int side = 0; side < 2; side++) {
-    // group: side 1 -> Next(x, .) (neighbour as is);  side 0 -> Next(rc(x), .) (neighbour
-    // reverse-complemented, i.e. a same-side edge)
-    set.for_group4(kmer_next(side ? x : rx, k, 0), [&](int64_t idx) {
-      if (idx == t) return;  // kmer != next (spss.h:242,248)
+  for (int side = 0; side < 2; side++)
+    for_side_neighbours<KeyT, kDirected>(set, x, rx, t, side, [&](int64_t idx, uint32_t same) {
       cnt[side]++;
-      single[side] = (uint32_t(idx) << 1) | (side ? 0u : 1u);
+      single[side] = (uint32_t(idx) << 1) | same;
     });
-    // singles: side 1 -> Prev(rc(x), c) = rc(Next(x, 3 - c));  side 0 -> Prev(x, c) as is
-    const uint64_t base = side ? rx : x;
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-      const uint64_t z = kmer_prev(base, k, c);
-      if (revcomp(z, k) < z) continue;  // not canonical: cannot be in the set
-      if (z == x) continue;
-      const int64_t idx = set.find(z);
-      if (idx < 0) continue;
-      cnt[side]++;
-      single[side] = (uint32_t(idx) << 1) | (side ? 1u : 0u);
-    }
-  }
-  }
   nbr[2 * t] = cnt[0] == 0 ? kNone : (cnt[0] == 1 ? single[0] : kMulti);
   nbr[2 * t + 1] = cnt[1] == 0 ? kNone : (cnt[1] == 1 ? single[1] : kMulti);
 }
 
+// A link is an edge that is the only one on its side at BOTH ends (spss.h:275-313: a side is
+// terminal unless it has exactly one neighbour whose facing side has exactly one).  Instead of
+// every k-mer reading its neighbour's facing side (two cache-missing reads per k-mer), the rare
+// k-mers with several neighbours on a side look those neighbours up again and cut the facing
+// entries: nbr turns into the link table in place (several -> none on the way), and the
+// chain-rank records of the two states start unset.  Entries only ever change to kNone, and a
+// k-mer decides from its own two entries alone whether it cuts (`several` is never overwritten
+// by another k-mer), so the order of the threads does not matter.
+template <typename KeyT, bool kDirected>
+__global__ __launch_bounds__(256) void k_link_cut(DevSet<KeyT> set, uint32_t* __restrict__ nbr,
+                                                   unsigned long long* __restrict__ info) {
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= set.n) return;
+  reinterpret_cast<ulonglong2*>(info)[t] = make_ulonglong2(kUnset, kUnset);  // chain-rank records
+  const uint2 mine = reinterpret_cast<const uint2*>(nbr)[t];
+  if (mine.x != kMulti && mine.y != kMulti) return;
+  const uint64_t x = set.kmer(t);
+  const uint64_t rx = kDirected ? 0 : revcomp(x, set.k);
+  for (int side = 0; side < 2; side++) {
+    if ((side ? mine.y : mine.x) != kMulti) continue;
+    for_side_neighbours<KeyT, kDirected>(set, x, rx, t, side, [&](int64_t idx, uint32_t same) {
+      uint32_t* facing = nbr + 2 * idx + (same ? side : side ^ 1);
+      if (*reinterpret_cast<volatile uint32_t*>(facing) < kMulti) *reinterpret_cast<volatile uint32_t*>(facing) = kNone;
+    });
+    nbr[2 * t + side] = kNone;
+  }
+}
 
 // ---------------------------------------------------------------------------------- E1b
 // The neighbour probe of a canonical set, LDS-staged.  Of the 8 candidates of a k-mer x, the
@@ -901,33 +934,6 @@ __global__ __launch_bounds__(256) void k_adj_fwd(DevSet<KeyT> set, const uint32_
   reinterpret_cast<uint2*>(nbr)[t] = make_uint2(out[0], out[1]);
 }
 
-// One thread per k-mer: both links; the chain-rank records of its two states start unset.
-__global__ __launch_bounds__(256) void k_links(const uint32_t* __restrict__ nbr, int64_t n,
-                                                uint32_t* __restrict__ link,
-                                                unsigned long long* __restrict__ info,
-                                                uint8_t* __restrict__ start_flags) {
-  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (t >= n) return;
-  const uint2 nb2 = reinterpret_cast<const uint2*>(nbr)[t];
-  const uint32_t v[2] = {nb2.x, nb2.y};
-  uint32_t out[2];
-#pragma unroll
-  for (uint32_t side = 0; side < 2; side++) {
-    out[side] = kNone;
-    if (v[side] < kMulti) {
-      const uint32_t y = v[side] >> 1, same = v[side] & 1;
-      const uint32_t facing = same ? side : side ^ 1;
-      if (nbr[2 * int64_t(y) + facing] < kMulti) out[side] = v[side];
-    }
-  }
-  reinterpret_cast<uint2*>(link)[t] = make_uint2(out[0], out[1]);
-  reinterpret_cast<ulonglong2*>(info)[t] = make_ulonglong2(kUnset, kUnset);  // chain-rank records
-  // which of its two states start a chain without being a sampled ruler (k_ruler_heads):
-  // state 2t enters through side 0, state 2t + 1 through side 1
-  const bool sampled = (t & (kRulerEvery - 1)) == 0;
-  start_flags[t] = sampled ? 0 : uint8_t((out[0] == kNone ? 1 : 0) | (out[1] == kNone ? 2 : 0));
-}
-
 // ---------------------------------------------------------------------------------- E2
 // Chains of states are ranked with a sparse ruler set instead of one serial walk per
 // chain (a 10^7-k-mer unitig would otherwise be a 10^7-step dependent walk):
@@ -1017,7 +1023,7 @@ __global__ __launch_bounds__(256) void k_ruler_walk(const uint32_t* __restrict__
 }
 
 // One thread per k-mer; acts on those of its two states that start a chain without being a
-// sampled ruler (flags from k_links).  One walk from the start S to the first sampled ruler ahead,
+// sampled ruler (nothing links into them).  One walk from the start S to the first sampled ruler ahead,
 // or to the chain's end: the d == 0 states it passes are stamped "off steps after start S" (kind
 // 3), and what lies ahead goes into chain_info at S's k-mer (a k-mer starts at most one chain of
 // two or more states: its other state then enters through the side that has the link).  Both
@@ -1029,13 +1035,15 @@ __device__ __forceinline__ uint64_t make_chain_info(bool ruler_ahead, uint32_t s
 }
 
 __global__ __launch_bounds__(256) void k_ruler_heads(const uint32_t* __restrict__ link,
-                                                      const uint8_t* __restrict__ start_flags,
                                                       int64_t n,
                                                       unsigned long long* __restrict__ rec,
                                                       unsigned long long* __restrict__ chain_info) {
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= n) return;
-  const uint32_t flags = start_flags[t];
+  if ((t & (kRulerEvery - 1)) == 0) return;  // a sampled ruler: k_ruler_walk
+  // state 2t enters through side 0, state 2t + 1 through side 1: a start when nothing links in
+  const uint2 own = reinterpret_cast<const uint2*>(link)[t];
+  const uint32_t flags = (own.x == kNone ? 1u : 0u) | (own.y == kNone ? 2u : 0u);
   if (!flags) return;
   for (uint32_t d = 0; d < 2; d++) {
     if (!(flags & (1u << d))) continue;
@@ -1105,6 +1113,14 @@ __device__ __forceinline__ bool resolve_rec(uint64_t r, const unsigned long long
   return true;
 }
 
+// ori[t]: bit 0 = the k-mer is spelled reverse-complemented in its unitig's head-first order; bits
+// 1..4 = the low four bits of its distance to the unitig's far end (len - 1 - pos), which is its
+// position when the path cover traverses the unitig the other way round: k_emit picks its writers
+// from pos and these bits without looking the unitig up.
+__device__ __forceinline__ uint8_t ori_byte(uint32_t d, uint32_t to_far_end) {
+  return uint8_t((d & 1u) | ((to_far_end & 15u) << 1));
+}
+
 // For k-mer t the chain of (t, 0) ends at E0 and the chain of (t, 1) ends at E1, i.e. the
 // forward chain runs from k-mer E1 >> 1 to k-mer E0 >> 1; the spelling starts at the larger
 // end (spss.h:511,555).  hcls: 0xFE marks a k-mer on a non-branching loop (k_loops fills it in).
@@ -1158,7 +1174,7 @@ __global__ __launch_bounds__(256) void k_choose(const unsigned long long* __rest
   const uint32_t p = d ? d0 : d1;
   head[t] = start_state >> 1;
   pos[t] = p;
-  ori[t] = uint8_t(d);
+  ori[t] = ori_byte(d, d ? d1 : d0);
   if (p == 0) {
     hcls[t] = (directed || fwd_start == fwd_end) ? 0 : ((start_state & 1) == 0 ? 1 : 2);
     hlen[t] = d0 + d1 + 1;
@@ -1187,13 +1203,14 @@ __global__ __launch_bounds__(256) void k_loops(const uint32_t* __restrict__ link
     steps++;
   } while (s != start && steps <= 2 * n);
   if (s != start) return;
+  const uint32_t len = uint32_t(steps);
   uint32_t p = 0, last = start;
   s = start;
   do {
     const uint32_t y = s >> 1;
     head[y] = uint32_t(t);
     pos[y] = p;
-    ori[y] = uint8_t(s & 1);
+    ori[y] = ori_byte(s & 1, len - 1 - p);
     last = s;
     const uint32_t lk = link[s ^ 1];
     s = ((lk >> 1) << 1) | ((s & 1) ^ (lk & 1));
@@ -1293,7 +1310,7 @@ __global__ __launch_bounds__(256) void k_unitig_fill(
     const int64_t u = c[i] == 0 ? next[0]++ : c[i] == 1 ? next[1]++ : c[i] == 2 ? next[2]++ : next[3]++;
     uid[t] = uint32_t(u);
     u_head[u] = uint32_t(t);
-    u_first[u] = uint32_t(2 * t) | ori[t];
+    u_first[u] = uint32_t(2 * t) | (ori[t] & 1u);
     u_last[u] = hlast[t];
     u_len[u] = hlen[t];
   }
@@ -1770,7 +1787,16 @@ __global__ __launch_bounds__(256) void k_unitig_place(const uint32_t* __restrict
   place_at_head[u_head[u]] = pl;
 }
 
-template <typename KeyT>
+// A k-mer at slot q of its string spells the bases q .. q + K - 1 of that string, all of them
+// inside the string.  So one k-mer in kEmitBases writes kEmitBases bases in one (unaligned) store
+// instead of every k-mer one byte at a scattered address: the writers are the k-mers whose slot
+// within the unitig is a multiple of kEmitBases (the slots of a unitig start at 0, so these cover
+// it, running over into the next unitig of the string or into the string's tail with the same
+// bases those k-mers would write), and the last k-mer of a string adds its whole spelling.  Which
+// way round a unitig is traversed is only known at its place record: a k-mer is a candidate if
+// either of its two possible slots qualifies (pos, or the far-end distance bits of ori), and only
+// candidates look their unitig up -- one k-mer in kEmitBases / 2.
+template <typename KeyT, int kEmitBases>
 __global__ __launch_bounds__(256) void k_emit(DevSet<KeyT> set, const uint32_t* __restrict__ head,
                                                const uint32_t* __restrict__ pos,
                                                const uint8_t* __restrict__ ori,
@@ -1778,19 +1804,41 @@ __global__ __launch_bounds__(256) void k_emit(DevSet<KeyT> set, const uint32_t* 
                                                uint8_t* __restrict__ bytes) {
   __shared__ int64_t s_bucket[2];
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  const uint64_t x = set.kmer_in_block(t, s_bucket);
+  set.block_bucket(s_bucket);
   if (t >= set.n) return;
+  constexpr uint32_t kMask = uint32_t(kEmitBases - 1);
+  const uint32_t p = pos[t], ob = ori[t];
+  if ((p & kMask) != 0 && ((ob >> 1) & kMask) != 0) return;
   const uint32_t h = head[t];
   if (h == kNone) return;
   const UnitigPlace pl = place_at_head[h];
   const uint32_t flip = pl.flags & 1;
-  const uint32_t q = flip ? (pl.len - 1 - pos[t]) : pos[t];
+  const uint32_t q = flip ? (pl.len - 1 - p) : p;
+  const bool tail = (pl.flags & 2) && q == pl.len - 1;  // last k-mer of the string
+  const bool writer = (q & kMask) == 0;
+  if (!writer && !tail) return;
   const int k = set.k;
-  const uint64_t o = (uint32_t(ori[t]) ^ flip) ? revcomp(x, k) : x;
+  const uint64_t x = set.kmer_from_block(t, s_bucket);
+  const uint64_t o = ((ob & 1u) ^ flip) ? revcomp(x, k) : x;
   const int64_t at = pl.base + q;
-  bytes[at] = uint8_t((o >> (2 * (k - 1))) & 3);
-  if ((pl.flags & 2) && q == pl.len - 1) {  // last k-mer of the string: its remaining K - 1 bases
-    for (int i = 1; i < k; i++) bytes[at + i] = uint8_t((o >> (2 * (k - 1 - i))) & 3);
+  if (writer) {
+    if (kEmitBases == 1) {
+      bytes[at] = uint8_t((o >> (2 * (k - 1))) & 3);
+    } else {
+      // the first kEmitBases bases of o, one per byte, first base at the lowest address
+      struct __attribute__((packed, aligned(1))) Run {
+        uint32_t w[kEmitBases / 4];
+      } run;
+#pragma unroll
+      for (int j = 0; j < kEmitBases / 4; j++) {
+        const uint32_t b = uint32_t(o >> (2 * (k - 4 * (j + 1)))) & 0xFFu;  // bases 4j .. 4j + 3
+        run.w[j] = (b >> 6) | (((b >> 4) & 3u) << 8) | (((b >> 2) & 3u) << 16) | ((b & 3u) << 24);
+      }
+      *reinterpret_cast<Run*>(bytes + at) = run;
+    }
+  }
+  if (tail) {
+    for (int i = writer ? kEmitBases : 0; i < k; i++) bytes[at + i] = uint8_t((o >> (2 * (k - 1 - i))) & 3);
   }
 }
 
@@ -1946,7 +1994,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       // records: beyond that -- 10^8 k-mers in 2^10 buckets, 5 x 10^8 in 2^14 -- the probing kernel is as fast)
       // E1b: partition by rc-prefix, LDS-staged probe of the reverse-complement half, forward half
       // in place.  The records live in the (still unused) chain-rank records, rc0 / rc1 in the link
-      // array, both written only by k_links afterwards.
+      // array; the records are reset by k_link_cut afterwards.
       const int64_t rows = std::max<int64_t>(1, std::min<int64_t>(kRcRowsMax, (n + 65535) / 65536));
       const int64_t per_row = ((n + rows - 1) / rows + 1023) / 1024 * 1024;
       uint32_t* hist = static_cast<uint32_t*>(arena_alloc(ctx, size_t(rows) * nb * 4));
@@ -2030,8 +2078,11 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       hipLaunchKernelGGL((k_adjacency<KeyT, false>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr, flags + 1);
     }
   }
-  hipLaunchKernelGGL(k_links, dim3(nblk(n)), dim3(256), 0, st, p->nbr, n, p->link, p->info,
-                     p->hcls);  // hcls doubles as the start-flag bytes until k_choose
+  if (directed)
+    hipLaunchKernelGGL((k_link_cut<KeyT, true>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr, p->info);
+  else
+    hipLaunchKernelGGL((k_link_cut<KeyT, false>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr, p->info);
+  const uint32_t* link = p->nbr;  // the link table from here on
   {
     int* changed = flags;
     const int64_t ns2 = 2 * n;
@@ -2039,10 +2090,10 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     unsigned long long* rinfo = reinterpret_cast<unsigned long long*>(p->c01);  // n_dense * 8 <= 8n
     {
       Timer timer(ctx, 4, n);
-      hipLaunchKernelGGL(k_ruler_walk, dim3(nblk(n_dense)), dim3(256), 0, st, p->link, ns2, n_dense, rinfo,
+      hipLaunchKernelGGL(k_ruler_walk, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo,
                          p->info);
     }
-    hipLaunchKernelGGL(k_ruler_heads, dim3(nblk(n)), dim3(256), 0, st, p->link, p->hcls, n, p->info,
+    hipLaunchKernelGGL(k_ruler_heads, dim3(nblk(n)), dim3(256), 0, st, link, n, p->info,
                        reinterpret_cast<unsigned long long*>(p->c23));  // c23: chain_info until k_choose is done
     int max_rounds = 2;
     for (int64_t x = n_dense; x > 1; x >>= 1) max_rounds++;
@@ -2062,7 +2113,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
                      reinterpret_cast<const unsigned long long*>(p->c01),
                      reinterpret_cast<const unsigned long long*>(p->c23), n, directed, p->head, p->pos, p->ori,
                      p->hcls, p->hlen, p->hlast);
-  hipLaunchKernelGGL(k_loops, dim3(nblk(n)), dim3(256), 0, st, p->link, n, p->head, p->pos, p->ori,
+  hipLaunchKernelGGL(k_loops, dim3(nblk(n)), dim3(256), 0, st, link, n, p->head, p->pos, p->ori,
                      p->hcls, p->hlen, p->hlast);
   const int64_t n_hblocks = (n + kHeadSpan - 1) / kHeadSpan;
   int64_t* b01 = p->c23;              // per-workgroup head counts (n / 2048 values each) live in
@@ -2222,8 +2273,13 @@ int encode_write_t(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens) {
   }
   {
     Timer timer(ctx, 5, n);
-    hipLaunchKernelGGL((k_emit<KeyT>), dim3(nblk(n)), dim3(256), 0, st, set, p->head, p->pos, p->ori,
-                       reinterpret_cast<const UnitigPlace*>(p->c01), bytes);
+    const UnitigPlace* place = reinterpret_cast<const UnitigPlace*>(p->c01);
+    if (g->k >= 16)
+      hipLaunchKernelGGL((k_emit<KeyT, 16>), dim3(nblk(n)), dim3(256), 0, st, set, p->head, p->pos, p->ori, place, bytes);
+    else if (g->k >= 4)
+      hipLaunchKernelGGL((k_emit<KeyT, 4>), dim3(nblk(n)), dim3(256), 0, st, set, p->head, p->pos, p->ori, place, bytes);
+    else
+      hipLaunchKernelGGL((k_emit<KeyT, 1>), dim3(nblk(n)), dim3(256), 0, st, set, p->head, p->pos, p->ori, place, bytes);
   }
   const int64_t n_words = (p->n_bases + 31) / 32;
   hipLaunchKernelGGL(k_pack, dim3(nblk(n_words)), dim3(256), 0, st, bytes, p->n_bases, n_words,

@@ -169,6 +169,26 @@ struct DevSet {
     }
     return (uint64_t(b) << key_bits) | uint64_t(keys[t]);
   }
+
+  // The same in two halves, for kernels in which only a few threads need their k-mer: every
+  // thread of the workgroup calls block_bucket, those few kmer_from_block.
+  __device__ __forceinline__ void block_bucket(int64_t* lds2) const {
+    if (threadIdx.x == 0) {
+      const int64_t t0 = int64_t(blockIdx.x) * blockDim.x;
+      const int64_t b0 = bucket_of(t0 < n ? t0 : n - 1);
+      lds2[0] = b0;
+      lds2[1] = off[b0 + 1];
+    }
+    __syncthreads();
+  }
+  __device__ __forceinline__ uint64_t kmer_from_block(int64_t t, const int64_t* lds2) const {
+    int64_t b = lds2[0];
+    if (t >= lds2[1]) {
+      b++;
+      while (off[b + 1] <= t) b++;
+    }
+    return (uint64_t(b) << key_bits) | uint64_t(keys[t]);
+  }
 };
 
 }  // namespace ksh

@@ -50,7 +50,6 @@ constexpr uint32_t kRulerEvery = 1u << kRulerShift;
 
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kMulti = 0xFFFFFFFEu;
-constexpr uint64_t kUnset = ~uint64_t(0);
 
 // ---------------------------------------------------------------------------------- E1
 // Fine index of a set: one workgroup per bucket walks its sorted keys once and records
@@ -156,16 +155,14 @@ __global__ __launch_bounds__(256) void k_adjacency(DevSet<KeyT> set, uint32_t* _
 // terminal unless it has exactly one neighbour whose facing side has exactly one).  Instead of
 // every k-mer reading its neighbour's facing side (two cache-missing reads per k-mer), the rare
 // k-mers with several neighbours on a side look those neighbours up again and cut the facing
-// entries: nbr turns into the link table in place (several -> none on the way), and the
-// chain-rank records of the two states start unset.  Entries only ever change to kNone, and a
+// entries: nbr turns into the link table in place (several -> none on the way).  Entries only
+// ever change to kNone, and a
 // k-mer decides from its own two entries alone whether it cuts (`several` is never overwritten
 // by another k-mer), so the order of the threads does not matter.
 template <typename KeyT, bool kDirected>
-__global__ __launch_bounds__(256) void k_link_cut(DevSet<KeyT> set, uint32_t* __restrict__ nbr,
-                                                   unsigned long long* __restrict__ info) {
+__global__ __launch_bounds__(256) void k_link_cut(DevSet<KeyT> set, uint32_t* __restrict__ nbr) {
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (t >= set.n) return;
-  reinterpret_cast<ulonglong2*>(info)[t] = make_ulonglong2(kUnset, kUnset);  // chain-rank records
   const uint2 mine = reinterpret_cast<const uint2*>(nbr)[t];
   if (mine.x != kMulti && mine.y != kMulti) return;
   const uint64_t x = set.kmer(t);
@@ -987,6 +984,7 @@ __device__ __forceinline__ uint64_t make_rinfo(bool end, uint32_t dist, uint32_t
 }
 
 // One thread per sampled ruler (dense index i <-> state 32 * (i >> 1) + (i & 1)).
+template <bool kStamp>
 __global__ __launch_bounds__(256) void k_ruler_walk(const uint32_t* __restrict__ link,
                                                      int64_t n_states, int64_t n_dense,
                                                      unsigned long long* __restrict__ rinfo,
@@ -1000,7 +998,7 @@ __global__ __launch_bounds__(256) void k_ruler_walk(const uint32_t* __restrict__
   }
   const uint32_t r = uint32_t(s64);
   uint32_t lk = leave_link(link_pair(link, r), r);
-  if ((r & 1) == 0) rec[r] = make_rec(0, 0, uint32_t(i));
+  if (kStamp && (r & 1) == 0) rec[r] = make_rec(0, 0, uint32_t(i));
   if (lk == kNone) {
     rinfo[i] = make_rinfo(true, 0, r);
     return;
@@ -1013,7 +1011,7 @@ __global__ __launch_bounds__(256) void k_ruler_walk(const uint32_t* __restrict__
       rinfo[i] = make_rinfo(false, steps, cur);
       return;
     }
-    if ((cur & 1) == 0) rec[cur] = make_rec(0, steps, uint32_t(i));  // see mirror_rec
+    if (kStamp && (cur & 1) == 0) rec[cur] = make_rec(0, steps, uint32_t(i));  // see mirror_rec
     lk = leave_link(link_pair(link, cur), cur);
     if (lk == kNone) {
       rinfo[i] = make_rinfo(true, steps, cur);
@@ -1034,6 +1032,7 @@ __device__ __forceinline__ uint64_t make_chain_info(bool ruler_ahead, uint32_t s
   return (ruler_ahead ? kEndFlag : 0) | (uint64_t(steps & 0x7FFFFFFFu) << 32) | ref;
 }
 
+template <bool kStamp>
 __global__ __launch_bounds__(256) void k_ruler_heads(const uint32_t* __restrict__ link,
                                                       int64_t n,
                                                       unsigned long long* __restrict__ rec,
@@ -1050,12 +1049,12 @@ __global__ __launch_bounds__(256) void k_ruler_heads(const uint32_t* __restrict_
     const uint32_t s0 = uint32_t(2 * t) | d;
     uint32_t lk = leave_link(link_pair(link, s0), s0);
     if (lk == kNone) {
-      rec[s0] = make_rec(2, 0, s0);  // a one-state chain: its own end, in both orientations
+      if (kStamp) rec[s0] = make_rec(2, 0, s0);  // a one-state chain: its own end, in both orientations
       continue;
     }
     uint32_t cur = s0, off = 0;
     while (true) {
-      if ((cur & 1) == 0) rec[cur] = make_rec(3, off, s0);
+      if (kStamp && (cur & 1) == 0) rec[cur] = make_rec(3, off, s0);
       cur = step_to(cur, lk);
       off++;
       if (sampled_ruler(cur)) {
@@ -1064,7 +1063,7 @@ __global__ __launch_bounds__(256) void k_ruler_heads(const uint32_t* __restrict_
       }
       lk = leave_link(link_pair(link, cur), cur);
       if (lk == kNone || off >= 0x3FFFFFFFu) {
-        if ((cur & 1) == 0) rec[cur] = make_rec(3, off, s0);
+        if (kStamp && (cur & 1) == 0) rec[cur] = make_rec(3, off, s0);
         chain_info[t] = make_chain_info(false, off, cur);
         break;
       }
@@ -1111,6 +1110,31 @@ __device__ __forceinline__ bool resolve_rec(uint64_t r, const unsigned long long
   *end = uint32_t(ri);
   *dist = kind == 0 ? rd - off : rd + off;
   return true;
+}
+
+// For k-mer t the chain of (t, 0) ends at E0 and the chain of (t, 1) ends at E1, i.e. the
+// forward chain runs from k-mer E1 >> 1 to k-mer E0 >> 1; the spelling starts at the larger
+// end (spss.h:511,555).  directed (non-canonical sets): every chain is spelled forward from its
+// start k-mer, and all heads are one class, in start-k-mer order (spss.h:159-199).
+struct Chosen {
+  uint32_t head_state;  // first state of the unitig in head-first order
+  uint32_t p;           // the k-mer's position in that order
+  uint32_t len;         // k-mers in the unitig
+  uint32_t d;           // the k-mer is spelled reverse-complemented in that order
+  uint32_t last;        // last state in that order
+  uint8_t cls;          // class of the head (k_head_block_counts)
+};
+__device__ __forceinline__ Chosen choose_from_ends(uint32_t e0, uint32_t d0, uint32_t e1, uint32_t d1,
+                                                   bool directed) {
+  const uint32_t fwd_start = e1 >> 1, fwd_end = e0 >> 1;
+  Chosen c;
+  c.d = (directed || fwd_start >= fwd_end) ? 0u : 1u;
+  c.head_state = (c.d ? e0 : e1) ^ 1;
+  c.p = c.d ? d0 : d1;
+  c.len = d0 + d1 + 1;
+  c.last = c.d ? e1 : e0;
+  c.cls = (directed || fwd_start == fwd_end) ? uint8_t(0) : uint8_t((c.head_state & 1) == 0 ? 1 : 2);
+  return c;
 }
 
 // ori[t]: bit 0 = the k-mer is spelled reverse-complemented in its unitig's head-first order; bits
@@ -1167,19 +1191,104 @@ __global__ __launch_bounds__(256) void k_choose(const unsigned long long* __rest
     hcls[t] = 0xFE;
     return;
   }
-  hcls[t] = 0xFF;
-  const uint32_t fwd_start = e1 >> 1, fwd_end = e0 >> 1;
-  const uint32_t d = (directed || fwd_start >= fwd_end) ? 0u : 1u;
-  const uint32_t start_state = (d ? e0 : e1) ^ 1;
-  const uint32_t p = d ? d0 : d1;
-  head[t] = start_state >> 1;
-  pos[t] = p;
-  ori[t] = ori_byte(d, d ? d1 : d0);
-  if (p == 0) {
-    hcls[t] = (directed || fwd_start == fwd_end) ? 0 : ((start_state & 1) == 0 ? 1 : 2);
-    hlen[t] = d0 + d1 + 1;
-    hlast[t] = d ? e1 : e0;
+  const Chosen c = choose_from_ends(e0, d0, e1, d1, directed);
+  head[t] = c.head_state >> 1;
+  pos[t] = c.p;
+  ori[t] = ori_byte(c.d, c.len - 1 - c.p);
+  hcls[t] = c.p == 0 ? c.cls : uint8_t(0xFF);
+  if (c.p == 0) {
+    hlen[t] = c.len;
+    hlast[t] = c.last;
   }
+}
+
+// ---- ranking without stamps.  Of the per-k-mer results of k_choose only those of the unitigs'
+// end k-mers are read before the strings are written (ids and lengths of the unitigs, the k-mers
+// at their ends for the edges of the path cover), and the writing itself can walk the chains once
+// more, this time in string order only (k_emit_rulers / k_emit_heads).  So the ranking walks need
+// not stamp the states they pass -- the random 8-byte record write per k-mer that costs more than
+// the two link reads -- and k_choose_ends looks at the k-mers with a missing link alone: such a
+// k-mer ends one chain and starts its mirror image, so both of its states resolve from the
+// chain-start record or the ruler record of the k-mer itself.
+//   A non-branching loop has no end k-mer.  Loops with a sampled ruler show as rulers that never
+// reach an end (*loop_flag), loops without one as k-mers that no unitig accounts for (*total_len
+// != n): either way the encoder falls back to the stamping walks and k_loops.
+__device__ __forceinline__ bool chain_end_of(uint32_t s, uint2 own, const unsigned long long* __restrict__ rinfo,
+                                             const unsigned long long* __restrict__ chain_info,
+                                             uint32_t* end, uint32_t* dist) {
+  if (leave_link(own, s) == kNone) {
+    *end = s;
+    *dist = 0;
+    return true;
+  }
+  if (sampled_ruler(s)) {
+    const uint64_t ri = rinfo[dense_index(s)];
+    *end = uint32_t(ri);
+    *dist = uint32_t((ri >> 32) & 0x7FFFFFFFu);
+    return (ri & kEndFlag) != 0;
+  }
+  const uint64_t ci = chain_info[s >> 1];  // s starts its chain (the callers ask for nothing else)
+  const uint32_t steps = uint32_t((ci >> 32) & 0x7FFFFFFFu);
+  if (!(ci & kEndFlag)) {
+    *end = uint32_t(ci);
+    *dist = steps;
+    return true;
+  }
+  const uint64_t ri = rinfo[uint32_t(ci)];
+  *end = uint32_t(ri);
+  *dist = steps + uint32_t((ri >> 32) & 0x7FFFFFFFu);
+  return (ri & kEndFlag) != 0;
+}
+
+// Both chain ends of a k-mer that is sampled or has a missing link; false on a loop.
+__device__ __forceinline__ bool choose_at(uint32_t t, uint2 own, const unsigned long long* __restrict__ rinfo,
+                                          const unsigned long long* __restrict__ chain_info, bool directed,
+                                          Chosen* c) {
+  uint32_t e0, d0, e1, d1;
+  const bool ok0 = chain_end_of(2 * t, own, rinfo, chain_info, &e0, &d0);
+  const bool ok1 = chain_end_of(2 * t + 1, own, rinfo, chain_info, &e1, &d1);
+  if (!(ok0 && ok1)) return false;
+  *c = choose_from_ends(e0, d0, e1, d1, directed);
+  return true;
+}
+
+__global__ __launch_bounds__(256) void k_choose_ends(const uint32_t* __restrict__ link,
+                                                      const unsigned long long* __restrict__ rinfo,
+                                                      const unsigned long long* __restrict__ chain_info,
+                                                      int64_t n, bool directed, uint32_t* __restrict__ head,
+                                                      uint8_t* __restrict__ ori, uint8_t* __restrict__ hcls,
+                                                      uint32_t* __restrict__ hlen, uint32_t* __restrict__ hlast,
+                                                      unsigned long long* __restrict__ total_len,
+                                                      int* __restrict__ loop_flag) {
+  __shared__ unsigned long long s_len;
+  if (threadIdx.x == 0) s_len = 0;
+  __syncthreads();
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t < n) {
+    const uint2 own = reinterpret_cast<const uint2*>(link)[t];
+    uint8_t cls = 0xFF;
+    if (own.x == kNone || own.y == kNone) {
+      Chosen c;
+      if (!choose_at(uint32_t(t), own, rinfo, chain_info, directed, &c)) {
+        *loop_flag = 1;  // a chain with an end is no loop: cannot happen
+      } else {
+        head[t] = c.head_state >> 1;
+        if (c.p == 0) {
+          cls = c.cls;
+          hlen[t] = c.len;
+          hlast[t] = c.last;
+          ori[t] = uint8_t(c.d);
+          atomicAdd(&s_len, static_cast<unsigned long long>(c.len));
+        }
+      }
+    } else if ((t & (kRulerEvery - 1)) == 0) {
+      const ulonglong2 ri = reinterpret_cast<const ulonglong2*>(rinfo)[t >> kRulerShift];
+      if (!(ri.x & ri.y & kEndFlag)) *loop_flag = 1;
+    }
+    hcls[t] = cls;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0 && s_len) atomicAdd(total_len, s_len);
 }
 
 __global__ __launch_bounds__(256) void k_loops(const uint32_t* __restrict__ link,
@@ -1787,6 +1896,30 @@ __global__ __launch_bounds__(256) void k_unitig_place(const uint32_t* __restrict
   place_at_head[u_head[u]] = pl;
 }
 
+// kEmitBases bases of o (one per byte, first base at the lowest address) when `writer`, all K of
+// them when `tail`.
+template <int kEmitBases>
+__device__ __forceinline__ void store_bases(uint8_t* __restrict__ at, uint64_t o, int k, bool writer, bool tail) {
+  if (writer) {
+    if (kEmitBases == 1) {
+      at[0] = uint8_t((o >> (2 * (k - 1))) & 3);
+    } else {
+      struct __attribute__((packed, aligned(1))) Run {
+        uint32_t w[kEmitBases / 4];
+      } run;
+#pragma unroll
+      for (int j = 0; j < kEmitBases / 4; j++) {
+        const uint32_t b = uint32_t(o >> (2 * (k - 4 * (j + 1)))) & 0xFFu;  // bases 4j .. 4j + 3
+        run.w[j] = (b >> 6) | (((b >> 4) & 3u) << 8) | (((b >> 2) & 3u) << 16) | ((b & 3u) << 24);
+      }
+      *reinterpret_cast<Run*>(at) = run;
+    }
+  }
+  if (tail) {
+    for (int i = writer ? kEmitBases : 0; i < k; i++) at[i] = uint8_t((o >> (2 * (k - 1 - i))) & 3);
+  }
+}
+
 // A k-mer at slot q of its string spells the bases q .. q + K - 1 of that string, all of them
 // inside the string.  So one k-mer in kEmitBases writes kEmitBases bases in one (unaligned) store
 // instead of every k-mer one byte at a scattered address: the writers are the k-mers whose slot
@@ -1817,29 +1950,112 @@ __global__ __launch_bounds__(256) void k_emit(DevSet<KeyT> set, const uint32_t* 
   const bool tail = (pl.flags & 2) && q == pl.len - 1;  // last k-mer of the string
   const bool writer = (q & kMask) == 0;
   if (!writer && !tail) return;
-  const int k = set.k;
   const uint64_t x = set.kmer_from_block(t, s_bucket);
-  const uint64_t o = ((ob & 1u) ^ flip) ? revcomp(x, k) : x;
-  const int64_t at = pl.base + q;
-  if (writer) {
-    if (kEmitBases == 1) {
-      bytes[at] = uint8_t((o >> (2 * (k - 1))) & 3);
-    } else {
-      // the first kEmitBases bases of o, one per byte, first base at the lowest address
-      struct __attribute__((packed, aligned(1))) Run {
-        uint32_t w[kEmitBases / 4];
-      } run;
+  const uint64_t o = ((ob & 1u) ^ flip) ? revcomp(x, set.k) : x;
+  store_bases<kEmitBases>(bytes + pl.base + q, o, set.k, writer, tail);
+}
+
+// The same bytes without the per-k-mer (head, pos, ori) of k_choose (ranking without stamps,
+// k_choose_ends): the chains are walked once more, in string order only.  A sampled k-mer (or
+// the unsampled k-mer that starts a chain) works out its unitig and its slot like k_choose does,
+// looks up the unitig's place, and the one of its two states that runs with the string walks on
+// to the next sampled k-mer or to the chain's end; every k-mer passed knows its slot and
+// orientation from the walk.  A walk writes all K bases of its first k-mer and of every K-th one
+// after it (each covers the K slots up to the next; the walk that follows starts with a write of
+// its own), so the lanes of a wavefront read keys and write in the same iterations, and the last
+// k-mer of a string adds the string's tail.
+//   kRun = the largest power of two <= K (at most 16): K bases go out as the runs [0, kRun) and
+// [K - kRun, K), unaligned stores; kRun = 0: byte by byte (K < 4).
+template <int kRun>
+__device__ __forceinline__ void store_run(uint8_t* __restrict__ at, uint64_t o, int k, int first) {
+  struct __attribute__((packed, aligned(1))) Run {
+    uint32_t w[kRun / 4];
+  } run;
 #pragma unroll
-      for (int j = 0; j < kEmitBases / 4; j++) {
-        const uint32_t b = uint32_t(o >> (2 * (k - 4 * (j + 1)))) & 0xFFu;  // bases 4j .. 4j + 3
-        run.w[j] = (b >> 6) | (((b >> 4) & 3u) << 8) | (((b >> 2) & 3u) << 16) | ((b & 3u) << 24);
-      }
-      *reinterpret_cast<Run*>(bytes + at) = run;
+  for (int j = 0; j < kRun / 4; j++) {
+    const uint32_t b = uint32_t(o >> (2 * (k - first - 4 * (j + 1)))) & 0xFFu;  // bases first + 4j .. + 3
+    run.w[j] = (b >> 6) | (((b >> 4) & 3u) << 8) | (((b >> 2) & 3u) << 16) | ((b & 3u) << 24);
+  }
+  *reinterpret_cast<Run*>(at + first) = run;
+}
+template <int kRun>
+__device__ __forceinline__ void store_kmer(uint8_t* __restrict__ at, uint64_t o, int k) {
+  if (kRun == 0) {
+    for (int i = 0; i < k; i++) at[i] = uint8_t((o >> (2 * (k - 1 - i))) & 3);
+  } else {
+    store_run<(kRun ? kRun : 4)>(at, o, k, 0);
+    if (k > kRun) store_run<(kRun ? kRun : 4)>(at, o, k, k - kRun);
+  }
+}
+
+template <typename KeyT, int kRun>
+__device__ __forceinline__ void emit_walk(const DevSet<KeyT>& set, const uint32_t* __restrict__ link,
+                                          uint32_t first_state, uint2 own, uint64_t x_first,
+                                          const UnitigPlace& pl, uint32_t q, uint8_t* __restrict__ bytes) {
+  const int k = set.k;
+  uint32_t cur = first_state;
+  uint2 pr = own;
+  uint64_t x = x_first;
+  int since = 0;  // k-mers since the last one written
+  while (true) {
+    const bool tail = (pl.flags & 2) && q == pl.len - 1;  // last k-mer of the string
+    if (since == 0 || tail) {
+      if (cur != first_state) x = set.kmer(cur >> 1);
+      store_kmer<kRun>(bytes + pl.base + q, (cur & 1) ? revcomp(x, k) : x, k);
     }
+    const uint32_t lk = leave_link(pr, cur);
+    if (lk == kNone) return;
+    cur = step_to(cur, lk);
+    q++;
+    since = since + 1 == k ? 0 : since + 1;
+    if (sampled_ruler(cur) || q >= pl.len) return;  // (q < len always: the bound only guards the stores)
+    pr = link_pair(link, cur);
   }
-  if (tail) {
-    for (int i = writer ? kEmitBases : 0; i < k; i++) bytes[at + i] = uint8_t((o >> (2 * (k - 1 - i))) & 3);
-  }
+}
+
+// One thread per sampled k-mer.
+template <typename KeyT, int kRun>
+__global__ __launch_bounds__(256) void k_emit_rulers(DevSet<KeyT> set, const uint32_t* __restrict__ link,
+                                                      const unsigned long long* __restrict__ rinfo,
+                                                      const unsigned long long* __restrict__ chain_info,
+                                                      bool directed,
+                                                      const UnitigPlace* __restrict__ place_at_head,
+                                                      uint8_t* __restrict__ bytes) {
+  __shared__ int64_t s_bucket[2];
+  set.block_bucket_at((int64_t(blockIdx.x) * blockDim.x) << kRulerShift, s_bucket);
+  const int64_t t = (int64_t(blockIdx.x) * blockDim.x + threadIdx.x) << kRulerShift;
+  if (t >= set.n) return;
+  const uint2 own = reinterpret_cast<const uint2*>(link)[t];
+  Chosen c;
+  if (!choose_at(uint32_t(t), own, rinfo, chain_info, directed, &c)) return;
+  const UnitigPlace pl = place_at_head[c.head_state >> 1];
+  const uint32_t flip = pl.flags & 1;
+  emit_walk<KeyT, kRun>(set, link, 2 * uint32_t(t) + (c.d ^ flip), own, set.kmer_from_block(t, s_bucket), pl,
+                        flip ? (c.len - 1 - c.p) : c.p, bytes);
+}
+
+// One thread per k-mer: the unsampled k-mers that start a chain in string order.
+template <typename KeyT, int kRun>
+__global__ __launch_bounds__(256) void k_emit_heads(DevSet<KeyT> set, const uint32_t* __restrict__ link,
+                                                     const unsigned long long* __restrict__ rinfo,
+                                                     const unsigned long long* __restrict__ chain_info,
+                                                     bool directed,
+                                                     const UnitigPlace* __restrict__ place_at_head,
+                                                     uint8_t* __restrict__ bytes) {
+  __shared__ int64_t s_bucket[2];
+  set.block_bucket(s_bucket);
+  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (t >= set.n || (t & (kRulerEvery - 1)) == 0) return;
+  const uint2 own = reinterpret_cast<const uint2*>(link)[t];
+  if (own.x != kNone && own.y != kNone) return;
+  Chosen c;
+  if (!choose_at(uint32_t(t), own, rinfo, chain_info, directed, &c)) return;
+  const UnitigPlace pl = place_at_head[c.head_state >> 1];
+  const uint32_t flip = pl.flags & 1;
+  const uint32_t first_state = 2 * uint32_t(t) + (c.d ^ flip);  // the state of t that runs with the string
+  if (enter_link(own, first_state) != kNone) return;            // the walk before this k-mer passes it
+  emit_walk<KeyT, kRun>(set, link, first_state, own, set.kmer_from_block(t, s_bucket), pl,
+                        flip ? (c.len - 1 - c.p) : c.p, bytes);
 }
 
 __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ bytes, int64_t n_bases,
@@ -1891,6 +2107,11 @@ struct EncPlan {
   int64_t *s_nk = nullptr, *sc01 = nullptr, *sc2 = nullptr, *str_start = nullptr;
   int* any_live = nullptr;
   int rounds = 0;
+  // ranking without stamps (k_choose_ends): the ruler and chain-start records live on in `info`
+  // until the strings are written (k_emit_rulers / k_emit_heads)
+  bool stamped = true;
+  bool directed = false;
+  const unsigned long long *rinfo = nullptr, *chain_info = nullptr;
 };
 
 inline size_t al(size_t x) { return (x + 255) & ~size_t(255); }
@@ -1904,6 +2125,15 @@ inline bool staged_adjacency() {
   static const bool on = [] {
     const char* e = getenv("KSH_ADJACENCY");
     return !(e && std::string(e) == "probe");
+  }();
+  return on;
+}
+// KSH_RANK=stamp: the ranking walks stamp every k-mer and k_choose / k_emit work per k-mer (the
+// path every set with a non-branching loop takes anyway).
+inline bool rank_with_stamps() {
+  static const bool on = [] {
+    const char* e = getenv("KSH_RANK");
+    return e && std::string(e) == "stamp";
   }();
   return on;
 }
@@ -2079,22 +2309,37 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     }
   }
   if (directed)
-    hipLaunchKernelGGL((k_link_cut<KeyT, true>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr, p->info);
+    hipLaunchKernelGGL((k_link_cut<KeyT, true>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr);
   else
-    hipLaunchKernelGGL((k_link_cut<KeyT, false>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr, p->info);
+    hipLaunchKernelGGL((k_link_cut<KeyT, false>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr);
   const uint32_t* link = p->nbr;  // the link table from here on
-  {
+  const int64_t n_hblocks = (n + kHeadSpan - 1) / kHeadSpan;
+  int64_t* b01 = p->c23;              // per-workgroup head counts (n / 2048 values each) live in
+  int64_t* b23 = p->c23 + n_hblocks;  // the front of c23; c01 still holds the ruler records
+  // d_tot[0..1]: unitig counts by class; [2]: k-mers the unitigs account for, [3]: a ruler on a loop
+  int64_t* d_tot = static_cast<int64_t*>(arena_alloc(ctx, 32));
+  if (!d_tot) return fail(KSH_INTERNAL, "scratch arena too small");
+  p->directed = directed;
+  for (bool stamped = rank_with_stamps();; stamped = true) {
     int* changed = flags;
     const int64_t ns2 = 2 * n;
     const int64_t n_dense = 2 * ((n + kRulerEvery - 1) / kRulerEvery);
-    unsigned long long* rinfo = reinterpret_cast<unsigned long long*>(p->c01);  // n_dense * 8 <= 8n
+    // with stamps: ruler records in c01 (n_dense * 8 <= 8n), chain starts in c23, both dead after
+    // k_choose; without: both in the record array, which nothing stamps, until the strings are written
+    unsigned long long* rinfo = stamped ? reinterpret_cast<unsigned long long*>(p->c01) : p->info;
+    unsigned long long* chain_info = stamped ? reinterpret_cast<unsigned long long*>(p->c23) : p->info + n_dense;
+    if (stamped) KSH_HIP(hipMemsetAsync(p->info, 0xFF, size_t(2 * n) * 8, st));  // chain-rank records unset
     {
       Timer timer(ctx, 4, n);
-      hipLaunchKernelGGL(k_ruler_walk, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo,
-                         p->info);
+      if (stamped)
+        hipLaunchKernelGGL(k_ruler_walk<true>, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, p->info);
+      else
+        hipLaunchKernelGGL(k_ruler_walk<false>, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, p->info);
     }
-    hipLaunchKernelGGL(k_ruler_heads, dim3(nblk(n)), dim3(256), 0, st, link, n, p->info,
-                       reinterpret_cast<unsigned long long*>(p->c23));  // c23: chain_info until k_choose is done
+    if (stamped)
+      hipLaunchKernelGGL(k_ruler_heads<true>, dim3(nblk(n)), dim3(256), 0, st, link, n, p->info, chain_info);
+    else
+      hipLaunchKernelGGL(k_ruler_heads<false>, dim3(nblk(n)), dim3(256), 0, st, link, n, p->info, chain_info);
     int max_rounds = 2;
     for (int64_t x = n_dense; x > 1; x >>= 1) max_rounds++;
     for (int round = 0; round < max_rounds;) {
@@ -2108,24 +2353,29 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
                                           "complement (even k): not supported");
       if (reinterpret_cast<int*>(ctx->h_pinned)[0] == 0) break;
     }
+    KSH_HIP(hipMemsetAsync(d_tot, 0, 32, st));
+    if (stamped) {
+      hipLaunchKernelGGL(k_choose, dim3(nblk(n)), dim3(256), 0, st, p->info, rinfo, chain_info, n, directed,
+                         p->head, p->pos, p->ori, p->hcls, p->hlen, p->hlast);
+      hipLaunchKernelGGL(k_loops, dim3(nblk(n)), dim3(256), 0, st, link, n, p->head, p->pos, p->ori,
+                         p->hcls, p->hlen, p->hlast);
+    } else {
+      hipLaunchKernelGGL(k_choose_ends, dim3(nblk(n)), dim3(256), 0, st, link, rinfo, chain_info, n, directed,
+                         p->head, p->ori, p->hcls, p->hlen, p->hlast,
+                         reinterpret_cast<unsigned long long*>(d_tot + 2), reinterpret_cast<int*>(d_tot + 3));
+    }
+    hipLaunchKernelGGL(k_head_block_counts, dim3(unsigned(n_hblocks)), dim3(256), 0, st, p->hcls, n, b01, b23);
+    KSH_TRY(scan_exclusive_i64(ctx, b01, b01, n_hblocks, d_tot));
+    KSH_TRY(scan_exclusive_i64(ctx, b23, b23, n_hblocks, d_tot + 1));
+    KSH_HIP(hipGetLastError());
+    KSH_HIP(hipMemcpyAsync(ctx->h_pinned, d_tot, 32, hipMemcpyDeviceToHost, st));
+    KSH_HIP(hipStreamSynchronize(st));
+    p->stamped = stamped;
+    p->rinfo = rinfo;
+    p->chain_info = chain_info;
+    // a non-branching loop has no end k-mer for k_choose_ends to find: once more, with stamps
+    if (stamped || (ctx->h_pinned[2] == n && ctx->h_pinned[3] == 0)) break;
   }
-  hipLaunchKernelGGL(k_choose, dim3(nblk(n)), dim3(256), 0, st, p->info,
-                     reinterpret_cast<const unsigned long long*>(p->c01),
-                     reinterpret_cast<const unsigned long long*>(p->c23), n, directed, p->head, p->pos, p->ori,
-                     p->hcls, p->hlen, p->hlast);
-  hipLaunchKernelGGL(k_loops, dim3(nblk(n)), dim3(256), 0, st, link, n, p->head, p->pos, p->ori,
-                     p->hcls, p->hlen, p->hlast);
-  const int64_t n_hblocks = (n + kHeadSpan - 1) / kHeadSpan;
-  int64_t* b01 = p->c23;              // per-workgroup head counts (n / 2048 values each) live in
-  int64_t* b23 = p->c23 + n_hblocks;  // the front of c23; c01 still holds the ruler records
-  hipLaunchKernelGGL(k_head_block_counts, dim3(unsigned(n_hblocks)), dim3(256), 0, st, p->hcls, n, b01, b23);
-  int64_t* d_tot = static_cast<int64_t*>(arena_alloc(ctx, 16));
-  if (!d_tot) return fail(KSH_INTERNAL, "scratch arena too small");
-  KSH_TRY(scan_exclusive_i64(ctx, b01, b01, n_hblocks, d_tot));
-  KSH_TRY(scan_exclusive_i64(ctx, b23, b23, n_hblocks, d_tot + 1));
-  KSH_HIP(hipGetLastError());
-  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, d_tot, 16, hipMemcpyDeviceToHost, st));
-  KSH_HIP(hipStreamSynchronize(st));
   const int64_t n0 = ctx->h_pinned[0] & 0xFFFFFFFF, n1 = ctx->h_pinned[0] >> 32;
   const int64_t n2 = ctx->h_pinned[1] & 0xFFFFFFFF, n3 = ctx->h_pinned[1] >> 32;
   const int64_t n_u = n0 + n1 + n2 + n3;
@@ -2261,12 +2511,13 @@ int encode_write_t(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens) {
   set.fine = p->fine;
   set.fine_bits = p->fine_bits;
   hipStream_t st = ctx->stream;
-  // byte staging aliases the neighbour array (2n * 4 bytes >= n_bases needs checking)
+  // byte staging aliases the array the staged neighbour probe kept its partial results in (dead
+  // since then; 2n * 4 bytes >= n_bases needs checking)
   const size_t need = size_t(p->n_bases) + 64;
   uint8_t* bytes;
   void* tmp = nullptr;
   if (need <= size_t(2 * n) * 4) {
-    bytes = reinterpret_cast<uint8_t*>(p->nbr);
+    bytes = reinterpret_cast<uint8_t*>(p->link);
   } else {
     KSH_TRY(pool_alloc(ctx, need, &tmp));
     bytes = static_cast<uint8_t*>(tmp);
@@ -2274,12 +2525,28 @@ int encode_write_t(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens) {
   {
     Timer timer(ctx, 5, n);
     const UnitigPlace* place = reinterpret_cast<const UnitigPlace*>(p->c01);
+    const int64_t n_sampled = (n + kRulerEvery - 1) / kRulerEvery;
+#define KSH_EMIT(W, R)                                                                                         \
+  do {                                                                                                         \
+    if (p->stamped) {                                                                                          \
+      hipLaunchKernelGGL((k_emit<KeyT, W>), dim3(nblk(n)), dim3(256), 0, st, set, p->head, p->pos, p->ori,     \
+                         place, bytes);                                                                        \
+    } else {                                                                                                   \
+      hipLaunchKernelGGL((k_emit_rulers<KeyT, R>), dim3(nblk(n_sampled)), dim3(256), 0, st, set, p->nbr,       \
+                         p->rinfo, p->chain_info, p->directed, place, bytes);                                  \
+      hipLaunchKernelGGL((k_emit_heads<KeyT, R>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr, p->rinfo,      \
+                         p->chain_info, p->directed, place, bytes);                                            \
+    }                                                                                                          \
+  } while (0)
     if (g->k >= 16)
-      hipLaunchKernelGGL((k_emit<KeyT, 16>), dim3(nblk(n)), dim3(256), 0, st, set, p->head, p->pos, p->ori, place, bytes);
+      KSH_EMIT(16, 16);
+    else if (g->k >= 8)
+      KSH_EMIT(4, 8);
     else if (g->k >= 4)
-      hipLaunchKernelGGL((k_emit<KeyT, 4>), dim3(nblk(n)), dim3(256), 0, st, set, p->head, p->pos, p->ori, place, bytes);
+      KSH_EMIT(4, 4);
     else
-      hipLaunchKernelGGL((k_emit<KeyT, 1>), dim3(nblk(n)), dim3(256), 0, st, set, p->head, p->pos, p->ori, place, bytes);
+      KSH_EMIT(1, 0);
+#undef KSH_EMIT
   }
   const int64_t n_words = (p->n_bases + 31) / 32;
   hipLaunchKernelGGL(k_pack, dim3(nblk(n_words)), dim3(256), 0, st, bytes, p->n_bases, n_words,

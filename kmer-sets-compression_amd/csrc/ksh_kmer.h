@@ -173,8 +173,11 @@ struct DevSet {
   // The same in two halves, for kernels in which only a few threads need their k-mer: every
   // thread of the workgroup calls block_bucket, those few kmer_from_block.
   __device__ __forceinline__ void block_bucket(int64_t* lds2) const {
+    block_bucket_at(int64_t(blockIdx.x) * blockDim.x, lds2);
+  }
+  // (t0 = the smallest index any thread of the workgroup will ask for)
+  __device__ __forceinline__ void block_bucket_at(int64_t t0, int64_t* lds2) const {
     if (threadIdx.x == 0) {
-      const int64_t t0 = int64_t(blockIdx.x) * blockDim.x;
       const int64_t b0 = bucket_of(t0 < n ? t0 : n - 1);
       lds2[0] = b0;
       lds2[1] = off[b0 + 1];

@@ -1020,7 +1020,7 @@ __global__ __launch_bounds__(256) void k_ruler_walk(const uint32_t* __restrict__
   }
 }
 
-// One thread per k-mer; acts on those of its two states that start a chain without being a
+// One thread per end k-mer; acts on those of its two states that start a chain without being a
 // sampled ruler (nothing links into them).  One walk from the start S to the first sampled ruler ahead,
 // or to the chain's end: the d == 0 states it passes are stamped "off steps after start S" (kind
 // 3), and what lies ahead goes into chain_info at S's k-mer (a k-mer starts at most one chain of
@@ -1034,11 +1034,12 @@ __device__ __forceinline__ uint64_t make_chain_info(bool ruler_ahead, uint32_t s
 
 template <bool kStamp>
 __global__ __launch_bounds__(256) void k_ruler_heads(const uint32_t* __restrict__ link,
-                                                      int64_t n,
+                                                      const uint32_t* __restrict__ ends, int64_t n_ends,
                                                       unsigned long long* __restrict__ rec,
                                                       unsigned long long* __restrict__ chain_info) {
-  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (t >= n) return;
+  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= n_ends) return;
+  const int64_t t = ends[e];
   if ((t & (kRulerEvery - 1)) == 0) return;  // a sampled ruler: k_ruler_walk
   // state 2t enters through side 0, state 2t + 1 through side 1: a start when nothing links in
   const uint2 own = reinterpret_cast<const uint2*>(link)[t];
@@ -1116,6 +1117,7 @@ __device__ __forceinline__ bool resolve_rec(uint64_t r, const unsigned long long
 // forward chain runs from k-mer E1 >> 1 to k-mer E0 >> 1; the spelling starts at the larger
 // end (spss.h:511,555).  directed (non-canonical sets): every chain is spelled forward from its
 // start k-mer, and all heads are one class, in start-k-mer order (spss.h:159-199).
+constexpr int kLenSums = 32;  // partial sums of k_choose_ends
 struct Chosen {
   uint32_t head_state;  // first state of the unitig in head-first order
   uint32_t p;           // the k-mer's position in that order
@@ -1253,42 +1255,45 @@ __device__ __forceinline__ bool choose_at(uint32_t t, uint2 own, const unsigned 
 }
 
 __global__ __launch_bounds__(256) void k_choose_ends(const uint32_t* __restrict__ link,
+                                                      const uint32_t* __restrict__ ends, int64_t n_ends,
                                                       const unsigned long long* __restrict__ rinfo,
                                                       const unsigned long long* __restrict__ chain_info,
-                                                      int64_t n, bool directed, uint32_t* __restrict__ head,
+                                                      bool directed, uint32_t* __restrict__ head,
                                                       uint8_t* __restrict__ ori, uint8_t* __restrict__ hcls,
                                                       uint32_t* __restrict__ hlen, uint32_t* __restrict__ hlast,
-                                                      unsigned long long* __restrict__ total_len,
+                                                      unsigned long long* __restrict__ len_sums,
                                                       int* __restrict__ loop_flag) {
   __shared__ unsigned long long s_len;
   if (threadIdx.x == 0) s_len = 0;
   __syncthreads();
-  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (t < n) {
+  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e < n_ends) {
+    const uint32_t t = ends[e];
     const uint2 own = reinterpret_cast<const uint2*>(link)[t];
-    uint8_t cls = 0xFF;
-    if (own.x == kNone || own.y == kNone) {
-      Chosen c;
-      if (!choose_at(uint32_t(t), own, rinfo, chain_info, directed, &c)) {
-        *loop_flag = 1;  // a chain with an end is no loop: cannot happen
-      } else {
-        head[t] = c.head_state >> 1;
-        if (c.p == 0) {
-          cls = c.cls;
-          hlen[t] = c.len;
-          hlast[t] = c.last;
-          ori[t] = uint8_t(c.d);
-          atomicAdd(&s_len, static_cast<unsigned long long>(c.len));
-        }
+    Chosen c;
+    if (!choose_at(t, own, rinfo, chain_info, directed, &c)) {
+      *loop_flag = 1;  // a chain with an end is no loop: cannot happen
+    } else {
+      head[t] = c.head_state >> 1;
+      if (c.p == 0) {  // (the class bytes of all other k-mers are preset to 0xFF)
+        hcls[t] = c.cls;
+        hlen[t] = c.len;
+        hlast[t] = c.last;
+        ori[t] = uint8_t(c.d);
+        atomicAdd(&s_len, static_cast<unsigned long long>(c.len));
       }
-    } else if ((t & (kRulerEvery - 1)) == 0) {
-      const ulonglong2 ri = reinterpret_cast<const ulonglong2*>(rinfo)[t >> kRulerShift];
-      if (!(ri.x & ri.y & kEndFlag)) *loop_flag = 1;
     }
-    hcls[t] = cls;
   }
   __syncthreads();
-  if (threadIdx.x == 0 && s_len) atomicAdd(total_len, s_len);
+  // (many workgroups adding to one word would queue up behind each other)
+  if (threadIdx.x == 0 && s_len) atomicAdd(len_sums + (blockIdx.x & (kLenSums - 1)), s_len);
+}
+
+// Every sampled ruler on a chain with ends has reached one after the pointer jumping.
+__global__ __launch_bounds__(256) void k_rulers_done(const unsigned long long* __restrict__ rinfo, int64_t n_dense,
+                                                      int* __restrict__ loop_flag) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i < n_dense && !(rinfo[i] & kEndFlag)) *loop_flag = 1;
 }
 
 __global__ __launch_bounds__(256) void k_loops(const uint32_t* __restrict__ link,
@@ -1376,6 +1381,50 @@ __device__ __forceinline__ uint64_t block_scan_packed(uint64_t v, uint64_t* lds4
     if (w < wave) before += lds4[w];
   *total = lds4[0] + lds4[1] + lds4[2] + lds4[3];
   return before + inc;
+}
+
+// The end k-mers (a side without a link: they end one chain and start its mirror image), in
+// ascending order: the same count / scan / fill over workgroups of 2048 k-mers.  The kernels that
+// only have work at chain ends run one thread per entry of this list (k_ruler_heads,
+// k_choose_ends, k_emit_heads) -- in a set of short unitigs a tenth of the k-mers are ends, and a
+// thread per k-mer would leave the wavefronts a tenth full while they wait on their walks.
+__device__ __forceinline__ uint32_t end_flags8(const uint32_t* __restrict__ link, int64_t t0, int64_t n) {
+  uint32_t flags = 0;
+#pragma unroll
+  for (int i = 0; i < kHeadItems; i += 2) {
+    if (t0 + i + 1 < n) {
+      const uint4 v = *reinterpret_cast<const uint4*>(link + 2 * (t0 + i));  // two k-mers' link pairs
+      if (v.x == kNone || v.y == kNone) flags |= 1u << i;
+      if (v.z == kNone || v.w == kNone) flags |= 1u << (i + 1);
+    } else if (t0 + i < n) {
+      const uint2 v = *reinterpret_cast<const uint2*>(link + 2 * (t0 + i));
+      if (v.x == kNone || v.y == kNone) flags |= 1u << i;
+    }
+  }
+  return flags;
+}
+
+__global__ __launch_bounds__(256) void k_end_counts(const uint32_t* __restrict__ link, int64_t n,
+                                                     int64_t* __restrict__ counts) {
+  __shared__ uint64_t lds4[4];
+  const int64_t t0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * kHeadItems;
+  uint64_t total;
+  (void)block_scan_packed(uint64_t(__popc(end_flags8(link, t0, n))), lds4, &total);
+  if (threadIdx.x == 0) counts[blockIdx.x] = int64_t(total);
+}
+
+__global__ __launch_bounds__(256) void k_end_fill(const uint32_t* __restrict__ link, int64_t n,
+                                                   const int64_t* __restrict__ before,
+                                                   uint32_t* __restrict__ ends) {
+  __shared__ uint64_t lds4[4];
+  const int64_t t0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * kHeadItems;
+  const uint32_t flags = end_flags8(link, t0, n);
+  const uint64_t mine = uint64_t(__popc(flags));
+  uint64_t total;
+  int64_t at = before[blockIdx.x] + int64_t(block_scan_packed(mine, lds4, &total) - mine);
+#pragma unroll
+  for (int i = 0; i < kHeadItems; i++)
+    if (flags & (1u << i)) ends[at++] = uint32_t(t0 + i);
 }
 
 // b01[b] = heads of class 0 | class 1 << 32 in workgroup b's k-mers, b23[b] the same for 2, 3.
@@ -2034,28 +2083,27 @@ __global__ __launch_bounds__(256) void k_emit_rulers(DevSet<KeyT> set, const uin
                         flip ? (c.len - 1 - c.p) : c.p, bytes);
 }
 
-// One thread per k-mer: the unsampled k-mers that start a chain in string order.
+// One thread per end k-mer: the unsampled ones that start a chain in string order.
 template <typename KeyT, int kRun>
 __global__ __launch_bounds__(256) void k_emit_heads(DevSet<KeyT> set, const uint32_t* __restrict__ link,
                                                      const unsigned long long* __restrict__ rinfo,
                                                      const unsigned long long* __restrict__ chain_info,
-                                                     bool directed,
+                                                     bool directed, const uint32_t* __restrict__ ends,
+                                                     int64_t n_ends,
                                                      const UnitigPlace* __restrict__ place_at_head,
                                                      uint8_t* __restrict__ bytes) {
-  __shared__ int64_t s_bucket[2];
-  set.block_bucket(s_bucket);
-  const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (t >= set.n || (t & (kRulerEvery - 1)) == 0) return;
+  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= n_ends) return;
+  const int64_t t = ends[e];
+  if ((t & (kRulerEvery - 1)) == 0) return;
   const uint2 own = reinterpret_cast<const uint2*>(link)[t];
-  if (own.x != kNone && own.y != kNone) return;
   Chosen c;
   if (!choose_at(uint32_t(t), own, rinfo, chain_info, directed, &c)) return;
   const UnitigPlace pl = place_at_head[c.head_state >> 1];
   const uint32_t flip = pl.flags & 1;
   const uint32_t first_state = 2 * uint32_t(t) + (c.d ^ flip);  // the state of t that runs with the string
   if (enter_link(own, first_state) != kNone) return;            // the walk before this k-mer passes it
-  emit_walk<KeyT, kRun>(set, link, first_state, own, set.kmer_from_block(t, s_bucket), pl,
-                        flip ? (c.len - 1 - c.p) : c.p, bytes);
+  emit_walk<KeyT, kRun>(set, link, first_state, own, set.kmer(t), pl, flip ? (c.len - 1 - c.p) : c.p, bytes);
 }
 
 __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ bytes, int64_t n_bases,
@@ -2112,6 +2160,8 @@ struct EncPlan {
   bool stamped = true;
   bool directed = false;
   const unsigned long long *rinfo = nullptr, *chain_info = nullptr;
+  const uint32_t* ends = nullptr;  // the end k-mers, ascending (aliases pos)
+  int64_t n_ends = 0;
 };
 
 inline size_t al(size_t x) { return (x + 255) & ~size_t(255); }
@@ -2182,7 +2232,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   const size_t bytes = 2 * al(size_t(2 * n) * 4) + al(size_t(2 * n) * 8) + 5 * al(size_t(n) * 4) +
                        2 * al(size_t(n)) + 2 * al(size_t(n) * 8) + al(fine_entries * 4) + 4096;
   KSH_TRY(slot_reserve(ctx, kSlotEncode, bytes));
-  KSH_TRY(arena_reserve(ctx, size_t(n / 256 + 4096) * 8 * 2 + (1u << 16) +
+  KSH_TRY(arena_reserve(ctx, size_t(n / 256 + 4096) * 8 * 2 + (1u << 16) + size_t(n / kHeadSpan + 64) * 8 +
                                  (nb <= (1 << 14) ? size_t(kRcRowsMax) * nb * 4 + size_t(nb + 1) * 16 + size_t(nb) * 260 + 8192 : 0)));
   arena_reset(ctx);
   char* at = ctx->slot[kSlotEncode];
@@ -2316,10 +2366,19 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   const int64_t n_hblocks = (n + kHeadSpan - 1) / kHeadSpan;
   int64_t* b01 = p->c23;              // per-workgroup head counts (n / 2048 values each) live in
   int64_t* b23 = p->c23 + n_hblocks;  // the front of c23; c01 still holds the ruler records
-  // d_tot[0..1]: unitig counts by class; [2]: k-mers the unitigs account for, [3]: a ruler on a loop
-  int64_t* d_tot = static_cast<int64_t*>(arena_alloc(ctx, 32));
-  if (!d_tot) return fail(KSH_INTERNAL, "scratch arena too small");
+  // d_tot[0..1]: unitig counts by class; [2 .. 2 + kLenSums): k-mers the unitigs account for (partial
+  // sums), [2 + kLenSums]: a ruler on a loop (an int)
+  int64_t* d_tot = static_cast<int64_t*>(arena_alloc(ctx, (3 + kLenSums) * 8));
+  // the end k-mers, ascending (k_end_counts / k_end_fill): per-workgroup counts -> offsets, total
+  int64_t* end_before = static_cast<int64_t*>(arena_alloc(ctx, size_t(n_hblocks + 1) * 8));
+  if (!d_tot || !end_before) return fail(KSH_INTERNAL, "scratch arena too small");
+  uint32_t* ends = p->pos;  // (k_choose writes pos after the last kernel that reads the list)
+  hipLaunchKernelGGL(k_end_counts, dim3(unsigned(n_hblocks)), dim3(256), 0, st, link, n, end_before);
+  KSH_TRY(scan_exclusive_i64(ctx, end_before, end_before, n_hblocks, end_before + n_hblocks));
+  hipLaunchKernelGGL(k_end_fill, dim3(unsigned(n_hblocks)), dim3(256), 0, st, link, n, end_before, ends);
   p->directed = directed;
+  p->ends = ends;
+  int64_t n_ends = -1;
   for (bool stamped = rank_with_stamps();; stamped = true) {
     int* changed = flags;
     const int64_t ns2 = 2 * n;
@@ -2336,10 +2395,6 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       else
         hipLaunchKernelGGL(k_ruler_walk<false>, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, p->info);
     }
-    if (stamped)
-      hipLaunchKernelGGL(k_ruler_heads<true>, dim3(nblk(n)), dim3(256), 0, st, link, n, p->info, chain_info);
-    else
-      hipLaunchKernelGGL(k_ruler_heads<false>, dim3(nblk(n)), dim3(256), 0, st, link, n, p->info, chain_info);
     int max_rounds = 2;
     for (int64_t x = n_dense; x > 1; x >>= 1) max_rounds++;
     for (int round = 0; round < max_rounds;) {
@@ -2347,34 +2402,49 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       for (int b = 0; b < 4 && round < max_rounds; b++, round++)
         hipLaunchKernelGGL(k_ruler_jump, dim3(nblk(n_dense)), dim3(256), 0, st, n_dense, rinfo, changed);
       KSH_HIP(hipMemcpyAsync(ctx->h_pinned, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
+      if (n_ends < 0)  // the length of the end list rides along with the first of these round trips
+        KSH_HIP(hipMemcpyAsync(ctx->h_pinned + 1, end_before + n_hblocks, 8, hipMemcpyDeviceToHost, st));
       KSH_HIP(hipStreamSynchronize(st));
+      if (n_ends < 0) n_ends = ctx->h_pinned[1];
       if (reinterpret_cast<int*>(ctx->h_pinned)[1])
         return fail(KSH_INVALID_ARGUMENT, "the canonical set holds a k-mer that is its own reverse "
                                           "complement (even k): not supported");
       if (reinterpret_cast<int*>(ctx->h_pinned)[0] == 0) break;
     }
-    KSH_HIP(hipMemsetAsync(d_tot, 0, 32, st));
+    p->n_ends = n_ends;
+    // (the chain starts only point at the ruler ahead of them: the order against the jumping is free)
+    if (stamped)
+      hipLaunchKernelGGL(k_ruler_heads<true>, dim3(nblk(n_ends)), dim3(256), 0, st, link, ends, n_ends, p->info, chain_info);
+    else
+      hipLaunchKernelGGL(k_ruler_heads<false>, dim3(nblk(n_ends)), dim3(256), 0, st, link, ends, n_ends, p->info, chain_info);
+    KSH_HIP(hipMemsetAsync(d_tot, 0, (3 + kLenSums) * 8, st));
+    int* loop_flag = reinterpret_cast<int*>(d_tot + 2 + kLenSums);
     if (stamped) {
       hipLaunchKernelGGL(k_choose, dim3(nblk(n)), dim3(256), 0, st, p->info, rinfo, chain_info, n, directed,
                          p->head, p->pos, p->ori, p->hcls, p->hlen, p->hlast);
       hipLaunchKernelGGL(k_loops, dim3(nblk(n)), dim3(256), 0, st, link, n, p->head, p->pos, p->ori,
                          p->hcls, p->hlen, p->hlast);
     } else {
-      hipLaunchKernelGGL(k_choose_ends, dim3(nblk(n)), dim3(256), 0, st, link, rinfo, chain_info, n, directed,
-                         p->head, p->ori, p->hcls, p->hlen, p->hlast,
-                         reinterpret_cast<unsigned long long*>(d_tot + 2), reinterpret_cast<int*>(d_tot + 3));
+      KSH_HIP(hipMemsetAsync(p->hcls, 0xFF, size_t(n), st));
+      hipLaunchKernelGGL(k_choose_ends, dim3(nblk(n_ends)), dim3(256), 0, st, link, ends, n_ends, rinfo, chain_info,
+                         directed, p->head, p->ori, p->hcls, p->hlen, p->hlast,
+                         reinterpret_cast<unsigned long long*>(d_tot + 2), loop_flag);
+      hipLaunchKernelGGL(k_rulers_done, dim3(nblk(n_dense)), dim3(256), 0, st, rinfo, n_dense, loop_flag);
     }
     hipLaunchKernelGGL(k_head_block_counts, dim3(unsigned(n_hblocks)), dim3(256), 0, st, p->hcls, n, b01, b23);
     KSH_TRY(scan_exclusive_i64(ctx, b01, b01, n_hblocks, d_tot));
     KSH_TRY(scan_exclusive_i64(ctx, b23, b23, n_hblocks, d_tot + 1));
     KSH_HIP(hipGetLastError());
-    KSH_HIP(hipMemcpyAsync(ctx->h_pinned, d_tot, 32, hipMemcpyDeviceToHost, st));
+    KSH_HIP(hipMemcpyAsync(ctx->h_pinned, d_tot, (3 + kLenSums) * 8, hipMemcpyDeviceToHost, st));
     KSH_HIP(hipStreamSynchronize(st));
     p->stamped = stamped;
     p->rinfo = rinfo;
     p->chain_info = chain_info;
+    if (stamped) break;
     // a non-branching loop has no end k-mer for k_choose_ends to find: once more, with stamps
-    if (stamped || (ctx->h_pinned[2] == n && ctx->h_pinned[3] == 0)) break;
+    int64_t accounted = 0;
+    for (int i = 0; i < kLenSums; i++) accounted += ctx->h_pinned[2 + i];
+    if (accounted == n && *reinterpret_cast<int*>(ctx->h_pinned + 2 + kLenSums) == 0) break;
   }
   const int64_t n0 = ctx->h_pinned[0] & 0xFFFFFFFF, n1 = ctx->h_pinned[0] >> 32;
   const int64_t n2 = ctx->h_pinned[1] & 0xFFFFFFFF, n3 = ctx->h_pinned[1] >> 32;
@@ -2534,8 +2604,8 @@ int encode_write_t(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens) {
     } else {                                                                                                   \
       hipLaunchKernelGGL((k_emit_rulers<KeyT, R>), dim3(nblk(n_sampled)), dim3(256), 0, st, set, p->nbr,       \
                          p->rinfo, p->chain_info, p->directed, place, bytes);                                  \
-      hipLaunchKernelGGL((k_emit_heads<KeyT, R>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr, p->rinfo,      \
-                         p->chain_info, p->directed, place, bytes);                                            \
+      hipLaunchKernelGGL((k_emit_heads<KeyT, R>), dim3(nblk(p->n_ends)), dim3(256), 0, st, set, p->nbr,        \
+                         p->rinfo, p->chain_info, p->directed, p->ends, p->n_ends, place, bytes);              \
     }                                                                                                          \
   } while (0)
     if (g->k >= 16)

@@ -32,6 +32,7 @@ constexpr int kDecThreads = 256;
 constexpr int kMaxLdsBuckets = 16384;   // 64 KiB of u32 counters
 constexpr int kSortLdsBytes = 40960;   // + 2 x 8 KiB of counters stays under 64 KiB
 constexpr int kMaxSubBits = 11;
+constexpr int kSortThreads = 1024;      // one workgroup per bucket (two fit a CU by LDS: 2048 threads)
 
 __global__ __launch_bounds__(256) void k_str_bases(const uint32_t* __restrict__ lens, int64_t n,
                                                     int k, int64_t* __restrict__ bases) {
@@ -140,8 +141,8 @@ __global__ __launch_bounds__(256) void k_hist_columns(uint32_t* __restrict__ his
 // ---- per-bucket sort --------------------------------------------------------------------------
 struct SortLds {
   uint32_t sub_cnt[(1 << kMaxSubBits) + 1];
-  int wave_cnt[4];
-  int wave_below[4];
+  int wave_cnt[kSortThreads / 64];
+  int wave_below[kSortThreads / 64];
   int overflow;
   int kept;
 };
@@ -159,14 +160,14 @@ __device__ void block_sort_into_lds(const KeyT* __restrict__ src, int cnt, int e
   if (bits > eff_bits) bits = eff_bits;
   const int n_sub = 1 << bits;
   const int shift = eff_bits - bits;
-  for (int i = threadIdx.x; i <= n_sub; i += 256) sh->sub_cnt[i] = 0;
+  for (int i = threadIdx.x; i <= n_sub; i += kSortThreads) sh->sub_cnt[i] = 0;
   if (threadIdx.x == 0) sh->overflow = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < cnt; i += 256)
+  for (int i = threadIdx.x; i < cnt; i += kSortThreads)
     atomicAdd(&sh->sub_cnt[uint32_t(uint64_t(src[i]) >> shift) & uint32_t(n_sub - 1)], 1u);
   __syncthreads();
   {  // exclusive scan of the sub-bin counts
-    const int per = (n_sub + 255) / 256;
+    const int per = (n_sub + kSortThreads - 1) / kSortThreads;
     const int c0 = min(int(threadIdx.x) * per, n_sub), c1 = min(c0 + per, n_sub);
     int mine = 0;
     for (int i = c0; i < c1; i++) mine += int(sh->sub_cnt[i]);
@@ -188,14 +189,14 @@ __device__ void block_sort_into_lds(const KeyT* __restrict__ src, int cnt, int e
     }
   }
   __syncthreads();
-  for (int i = threadIdx.x; i < cnt; i += 256) {
+  for (int i = threadIdx.x; i < cnt; i += kSortThreads) {
     const KeyT key = src[i];
     const uint32_t pos = atomicAdd(&sh->sub_cnt[uint32_t(uint64_t(key) >> shift) & uint32_t(n_sub - 1)], 1u);
     lds[pos] = key;
   }
   __syncthreads();
   // sub_cnt[b] is now the end of sub-bin b (= start of b + 1)
-  for (int b2 = threadIdx.x; b2 < n_sub; b2 += 256) {
+  for (int b2 = threadIdx.x; b2 < n_sub; b2 += kSortThreads) {
     const int s0 = b2 ? int(sh->sub_cnt[b2 - 1]) : 0, s1 = int(sh->sub_cnt[b2]);
     if (s1 - s0 > 64) {
       sh->overflow = 1;
@@ -218,7 +219,7 @@ __device__ void block_sort_into_lds(const KeyT* __restrict__ src, int cnt, int e
   const int half = padded >> 1;
   for (int size = 2; size <= padded; size <<= 1) {
     const int hs = size >> 1;
-    for (int p = threadIdx.x; p < half; p += 256) {
+    for (int p = threadIdx.x; p < half; p += kSortThreads) {
       const int block = p / hs, o = p - block * hs;
       const int i = block * size + o, j = block * size + size - 1 - o;
       if (j < cnt) {
@@ -231,7 +232,7 @@ __device__ void block_sort_into_lds(const KeyT* __restrict__ src, int cnt, int e
     }
     __syncthreads();
     for (int stride = size >> 2; stride > 0; stride >>= 1) {
-      for (int p = threadIdx.x; p < half; p += 256) {
+      for (int p = threadIdx.x; p < half; p += kSortThreads) {
         const int i = 2 * stride * (p / stride) + (p % stride), j = i + stride;
         if (j < cnt) {
           const KeyT x = lds[i], y = lds[j];
@@ -254,7 +255,7 @@ __device__ void block_sort_into_lds(const KeyT* __restrict__ src, int cnt, int e
 template <typename KeyT>
 __device__ int block_unique_write(const KeyT* __restrict__ lds, int cnt, KeyT* __restrict__ dst,
                                   SortLds* __restrict__ sh, int cutoff, int64_t* below) {
-  const int per = (cnt + 255) / 256;
+  const int per = (cnt + kSortThreads - 1) / kSortThreads;
   const int c0 = min(int(threadIdx.x) * per, cnt), c1 = min(c0 + per, cnt);
   int mine = 0, mine_below = 0;
   for (int i = c0; i < c1; i++) {
@@ -284,9 +285,11 @@ __device__ int block_unique_write(const KeyT* __restrict__ lds, int cnt, KeyT* _
   __syncthreads();
   int at = inc - mine;
   for (int w = 0; w < wave; w++) at += sh->wave_cnt[w];
-  const int total = sh->wave_cnt[0] + sh->wave_cnt[1] + sh->wave_cnt[2] + sh->wave_cnt[3];
+  int total = 0;
+#pragma unroll
+  for (int w = 0; w < kSortThreads / 64; w++) total += sh->wave_cnt[w];
   if (threadIdx.x == 0 && below)
-    *below += sh->wave_below[0] + sh->wave_below[1] + sh->wave_below[2] + sh->wave_below[3];
+    for (int w = 0; w < kSortThreads / 64; w++) *below += sh->wave_below[w];
   for (int i = c0; i < c1; i++) {
     if (i == 0 || lds[i] != lds[i - 1]) {
       bool keep = true;
@@ -307,7 +310,7 @@ __device__ int block_unique_write(const KeyT* __restrict__ lds, int cnt, KeyT* _
 // set put 30 k keys in a bucket) is first partitioned by its top key bits into `scratch`
 // (same index range as `keys`), then every part is sorted in LDS and written back in order.
 template <typename KeyT>
-__global__ __launch_bounds__(256) void k_bucket_sort(const int64_t* __restrict__ offsets,
+__global__ __launch_bounds__(kSortThreads) void k_bucket_sort(const int64_t* __restrict__ offsets,
                                                       KeyT* __restrict__ keys,
                                                       KeyT* __restrict__ scratch,
                                                       int64_t* __restrict__ uniq, int key_bits,
@@ -346,9 +349,9 @@ __global__ __launch_bounds__(256) void k_bucket_sort(const int64_t* __restrict__
   if (bits > key_bits) bits = key_bits;
   const int n_part = 1 << bits;
   const int shift = key_bits - bits;
-  for (int i = threadIdx.x; i <= n_part; i += 256) part_end[i] = 0;
+  for (int i = threadIdx.x; i <= n_part; i += kSortThreads) part_end[i] = 0;
   __syncthreads();
-  for (int64_t i = threadIdx.x; i < cnt64; i += 256)
+  for (int64_t i = threadIdx.x; i < cnt64; i += kSortThreads)
     atomicAdd(&part_end[uint32_t(uint64_t(g[i]) >> shift) & uint32_t(n_part - 1)], 1u);
   __syncthreads();
   if (threadIdx.x == 0) {  // serial exclusive scan of <= 2048 counters
@@ -360,7 +363,7 @@ __global__ __launch_bounds__(256) void k_bucket_sort(const int64_t* __restrict__
     }
   }
   __syncthreads();
-  for (int64_t i = threadIdx.x; i < cnt64; i += 256) {
+  for (int64_t i = threadIdx.x; i < cnt64; i += kSortThreads) {
     const KeyT key = g[i];
     const uint32_t pos = atomicAdd(&part_end[uint32_t(uint64_t(key) >> shift) & uint32_t(n_part - 1)], 1u);
     tmp[pos] = key;
@@ -383,7 +386,7 @@ __global__ __launch_bounds__(256) void k_bucket_sort(const int64_t* __restrict__
       const int64_t half = padded >> 1;
       for (int64_t size = 2; size <= padded; size <<= 1) {
         const int64_t hs = size >> 1;
-        for (int64_t q = threadIdx.x; q < half; q += 256) {
+        for (int64_t q = threadIdx.x; q < half; q += kSortThreads) {
           const int64_t block = q / hs, o = q - block * hs;
           const int64_t i = block * size + o, j = block * size + size - 1 - o;
           if (j < pc) {
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(256) void k_bucket_sort(const int64_t* __restrict__
         }
         __syncthreads();
         for (int64_t stride = size >> 2; stride > 0; stride >>= 1) {
-          for (int64_t q = threadIdx.x; q < half; q += 256) {
+          for (int64_t q = threadIdx.x; q < half; q += kSortThreads) {
             const int64_t i = 2 * stride * (q / stride) + (q % stride), j = i + stride;
             if (j < pc) {
               const KeyT x = buf[i], y = buf[j];
@@ -577,7 +580,7 @@ int decode_write_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int 
   int64_t* new_off = static_cast<int64_t*>(arena_alloc(ctx, size_t(nb + 1) * 8));
   int64_t* below = static_cast<int64_t*>(arena_alloc(ctx, size_t(nb + 1) * 8));
   if (!new_off || !below) return fail(KSH_INTERNAL, "scratch arena too small");
-  hipLaunchKernelGGL((k_bucket_sort<KeyT>), dim3(unsigned(nb)), dim3(256), kSortLdsBytes, ctx->stream,
+  hipLaunchKernelGGL((k_bucket_sort<KeyT>), dim3(unsigned(nb)), dim3(kSortThreads), kSortLdsBytes, ctx->stream,
                      d_offsets, keys, scratch, st.totals, key_bits(g), cutoff, n_below ? below : nullptr);
   if (scratch) pool_free(ctx, scratch);
   KSH_HIP(hipGetLastError());

@@ -43,7 +43,7 @@ namespace ksh {
 
 // Sampled rulers: both states of every kRulerEvery-th k-mer (E2).
 #ifndef KSH_RULER_SHIFT
-#define KSH_RULER_SHIFT 4
+#define KSH_RULER_SHIFT 5
 #endif
 constexpr int kRulerShift = KSH_RULER_SHIFT;
 constexpr uint32_t kRulerEvery = 1u << kRulerShift;
@@ -934,11 +934,11 @@ __global__ __launch_bounds__(256) void k_adj_fwd(DevSet<KeyT> set, const uint32_
 // ---------------------------------------------------------------------------------- E2
 // Chains of states are ranked with a sparse ruler set instead of one serial walk per
 // chain (a 10^7-k-mer unitig would otherwise be a 10^7-step dependent walk):
-//   rulers = both states of every 16th k-mer (index order is unrelated to chain order);
-//   k_ruler_walk  every sampled ruler walks to the next one (about 16 steps), stamping the
+//   rulers = both states of every 32nd k-mer (kRulerEvery; index order is unrelated to chain order);
+//   k_ruler_walk  every sampled ruler walks to the next one (about 32 steps), stamping the
 //                 states it passes with (ruler, offset);  k_ruler_heads does the same for the
 //                 head segment of a chain that starts between two sampled k-mers;
-//   k_ruler_jump  pointer jumping over the dense ruler array only (1/16 of the states), until
+//   k_ruler_jump  pointer jumping over the dense ruler array only (1/32 of the states), until
 //                 each ruler holds (chain end, distance to it);
 //   k_choose      resolves every state through its ruler: (end state, distance to end).
 // Rulers on a non-branching loop never reach an end; they and their segments stay unset
@@ -953,9 +953,9 @@ __device__ __forceinline__ uint32_t step_to(uint32_t s, uint32_t lk) {
   return ((lk >> 1) << 1) | ((s & 1) ^ (lk & 1));
 }
 
-// Sampled rulers are both states of every 16th k-mer (index order is unrelated to chain
+// Sampled rulers are both states of every 32nd k-mer (index order is unrelated to chain
 // order, so this is as good as a hash), which makes them enumerable without compaction:
-// dense thread i <-> state 32 * (i >> 1) + (i & 1).  The other rulers are chain starts and
+// dense thread i <-> state 64 * (i >> 1) + (i & 1).  The other rulers are chain starts and
 // chain ends; "is a ruler" needs only the state's own link pair, which the walk loads anyway.
 __device__ __forceinline__ bool sampled_ruler(uint32_t s) { return (s & (2u * kRulerEvery - 2u)) == 0; }
 
@@ -969,7 +969,7 @@ __device__ __forceinline__ bool sampled_ruler(uint32_t s) { return (s & (2u * kR
 //            kind 2: s is a chain of its own (one state), written for both states of the k-mer
 //            kind 3: s lies `off` steps after the chain start `ref` (a state); what lies ahead of
 //                    that start is in chain_info (k_ruler_heads)
-// The dense ruler array is 1/16 of the states (L2/MALL resident at 10^8 k-mers), so pointer
+// The dense ruler array is 1/32 of the states (L2/MALL resident at 10^8 k-mers), so pointer
 // jumping and the final lookups stay on-chip; every state's link pair is read once and its
 // record written once.
 constexpr uint64_t kRecUnset = ~uint64_t(0);
@@ -983,7 +983,7 @@ __device__ __forceinline__ uint64_t make_rinfo(bool end, uint32_t dist, uint32_t
   return (end ? kEndFlag : 0) | (uint64_t(dist & 0x7FFFFFFFu) << 32) | nx;
 }
 
-// One thread per sampled ruler (dense index i <-> state 32 * (i >> 1) + (i & 1)).
+// One thread per sampled ruler (dense index i <-> state 64 * (i >> 1) + (i & 1)).
 template <bool kStamp>
 __global__ __launch_bounds__(256) void k_ruler_walk(const uint32_t* __restrict__ link,
                                                      int64_t n_states, int64_t n_dense,

@@ -10,6 +10,7 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o stats -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-verify --no-pair-merge "$@" > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_rocprof_stats.err
 S=$(find $O/${TAG}_stats -name "*kernel_stats.csv" | head -1)
 cp $S $O/${TAG}_kernel_stats.csv
+python3 $R/tools/gpu_gaps.py "$(find $O/${TAG}_stats -name '*kernel_trace.csv' | head -1)" > $O/${TAG}_gaps.txt
 rm -rf $O/${TAG}_stats
 python3 - "$O/${TAG}_kernel_stats.csv" <<'PY'
 import csv, sys

@@ -984,7 +984,6 @@ __device__ __forceinline__ uint64_t make_rinfo(bool end, uint32_t dist, uint32_t
 }
 
 // One thread per sampled ruler (dense index i <-> state 64 * (i >> 1) + (i & 1)).
-template <bool kStamp>
 __global__ __launch_bounds__(256) void k_ruler_walk(const uint32_t* __restrict__ link,
                                                      int64_t n_states, int64_t n_dense,
                                                      unsigned long long* __restrict__ rinfo,
@@ -998,7 +997,7 @@ __global__ __launch_bounds__(256) void k_ruler_walk(const uint32_t* __restrict__
   }
   const uint32_t r = uint32_t(s64);
   uint32_t lk = leave_link(link_pair(link, r), r);
-  if (kStamp && (r & 1) == 0) rec[r] = make_rec(0, 0, uint32_t(i));
+  if ((r & 1) == 0) rec[r] = make_rec(0, 0, uint32_t(i));
   if (lk == kNone) {
     rinfo[i] = make_rinfo(true, 0, r);
     return;
@@ -1011,7 +1010,7 @@ __global__ __launch_bounds__(256) void k_ruler_walk(const uint32_t* __restrict__
       rinfo[i] = make_rinfo(false, steps, cur);
       return;
     }
-    if (kStamp && (cur & 1) == 0) rec[cur] = make_rec(0, steps, uint32_t(i));  // see mirror_rec
+    if ((cur & 1) == 0) rec[cur] = make_rec(0, steps, uint32_t(i));  // see mirror_rec
     lk = leave_link(link_pair(link, cur), cur);
     if (lk == kNone) {
       rinfo[i] = make_rinfo(true, steps, cur);
@@ -1032,7 +1031,6 @@ __device__ __forceinline__ uint64_t make_chain_info(bool ruler_ahead, uint32_t s
   return (ruler_ahead ? kEndFlag : 0) | (uint64_t(steps & 0x7FFFFFFFu) << 32) | ref;
 }
 
-template <bool kStamp>
 __global__ __launch_bounds__(256) void k_ruler_heads(const uint32_t* __restrict__ link,
                                                       const uint32_t* __restrict__ ends, int64_t n_ends,
                                                       unsigned long long* __restrict__ rec,
@@ -1050,12 +1048,12 @@ __global__ __launch_bounds__(256) void k_ruler_heads(const uint32_t* __restrict_
     const uint32_t s0 = uint32_t(2 * t) | d;
     uint32_t lk = leave_link(link_pair(link, s0), s0);
     if (lk == kNone) {
-      if (kStamp) rec[s0] = make_rec(2, 0, s0);  // a one-state chain: its own end, in both orientations
+      rec[s0] = make_rec(2, 0, s0);  // a one-state chain: its own end, in both orientations
       continue;
     }
     uint32_t cur = s0, off = 0;
     while (true) {
-      if (kStamp && (cur & 1) == 0) rec[cur] = make_rec(3, off, s0);
+      if ((cur & 1) == 0) rec[cur] = make_rec(3, off, s0);
       cur = step_to(cur, lk);
       off++;
       if (sampled_ruler(cur)) {
@@ -1064,12 +1062,104 @@ __global__ __launch_bounds__(256) void k_ruler_heads(const uint32_t* __restrict_
       }
       lk = leave_link(link_pair(link, cur), cur);
       if (lk == kNone || off >= 0x3FFFFFFFu) {
-        if (kStamp && (cur & 1) == 0) rec[cur] = make_rec(3, off, s0);
+        if ((cur & 1) == 0) rec[cur] = make_rec(3, off, s0);
         chain_info[t] = make_chain_info(false, off, cur);
         break;
       }
     }
   }
+}
+
+// ---- the same walks without stamps (see k_choose_ends), each stretch walked once where it can be.
+// A stretch between two stops of a chain (sampled rulers, or the chain's ends) is the business of
+// two walks, one from either side, that pass the same k-mers and count the same steps: the walk
+// from u that arrives at v is the mirror image of the walk from v ^ 1 that arrives at u ^ 1.  With
+// nothing to stamp, one of them is enough: a walk writes its own record and the record of its mirror
+// image.  Neither end knows the other beforehand, so the walks go in two phases: half of the
+// starts (by a hash bit) in the first, and in the second only those whose record no mirror image
+// has filled in -- three walks for two stretches on average instead of four.
+//   Records start unset (all ones: no record looks like that).  Equal values may be written twice.
+__device__ __forceinline__ bool first_phase(uint32_t s) {
+  return (((s >> 1) * 0x9E3779B1u) >> 13 ^ s) & 1u;
+}
+
+template <int kPhase>
+__global__ __launch_bounds__(256) void k_rank_walk(const uint32_t* __restrict__ link, int64_t n_states,
+                                                    int64_t n_dense, unsigned long long* __restrict__ rinfo,
+                                                    unsigned long long* __restrict__ chain_info) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_dense) return;
+  const int64_t s64 = 2 * int64_t(kRulerEvery) * (i >> 1) + (i & 1);
+  if (s64 >= n_states) {
+    rinfo[i] = make_rinfo(true, 0, 0);
+    return;
+  }
+  const uint32_t r = uint32_t(s64);
+  if (kPhase == 1 ? !first_phase(r) : rinfo[i] != kRecUnset) return;
+  uint32_t lk = leave_link(link_pair(link, r), r);
+  if (lk == kNone) {
+    rinfo[i] = make_rinfo(true, 0, r);
+    return;
+  }
+  uint32_t cur = r, steps = 0;
+  while (true) {
+    cur = step_to(cur, lk);
+    steps++;
+    if (sampled_ruler(cur) || steps >= 0x3FFFFFFFu) {
+      rinfo[i] = make_rinfo(false, steps, cur);
+      rinfo[dense_index(cur ^ 1)] = make_rinfo(false, steps, r ^ 1);
+      return;
+    }
+    lk = leave_link(link_pair(link, cur), cur);
+    if (lk == kNone) {
+      rinfo[i] = make_rinfo(true, steps, cur);
+      // the chain that starts at cur ^ 1 (an unsampled k-mer) has ruler r ^ 1 ahead of it
+      chain_info[cur >> 1] = make_chain_info(true, steps, dense_index(r ^ 1));
+      return;
+    }
+  }
+}
+
+template <int kPhase>
+__global__ __launch_bounds__(256) void k_rank_heads(const uint32_t* __restrict__ link,
+                                                     const uint32_t* __restrict__ ends, int64_t n_ends,
+                                                     unsigned long long* __restrict__ rinfo,
+                                                     unsigned long long* __restrict__ chain_info) {
+  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= n_ends) return;
+  const uint32_t t = ends[e];
+  if ((t & (kRulerEvery - 1)) == 0) return;  // a sampled ruler: k_rank_walk
+  const uint2 own = reinterpret_cast<const uint2*>(link)[t];
+  // the one state of t that starts a chain of two or more states, if any
+  uint32_t s0;
+  if (own.x == kNone && own.y != kNone) s0 = 2 * t;
+  else if (own.y == kNone && own.x != kNone) s0 = 2 * t + 1;
+  else return;
+  if (kPhase == 1 ? !first_phase(s0) : chain_info[t] != kRecUnset) return;
+  uint32_t lk = leave_link(own, s0);
+  uint32_t cur = s0, off = 0;
+  while (true) {
+    cur = step_to(cur, lk);
+    off++;
+    if (sampled_ruler(cur)) {
+      chain_info[t] = make_chain_info(true, off, dense_index(cur));
+      rinfo[dense_index(cur ^ 1)] = make_rinfo(true, off, s0 ^ 1);  // its walk ends at the chain end s0 ^ 1
+      return;
+    }
+    lk = leave_link(link_pair(link, cur), cur);
+    if (lk == kNone || off >= 0x3FFFFFFFu) {
+      chain_info[t] = make_chain_info(false, off, cur);
+      chain_info[cur >> 1] = make_chain_info(false, off, s0 ^ 1);  // the mirror chain, from cur ^ 1 to s0 ^ 1
+      return;
+    }
+  }
+}
+
+// The records of the chain starts unset (k_rank_heads, phase 2).
+__global__ __launch_bounds__(256) void k_rank_unset(const uint32_t* __restrict__ ends, int64_t n_ends,
+                                                     unsigned long long* __restrict__ chain_info) {
+  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e < n_ends) chain_info[ends[e]] = kRecUnset;
 }
 
 // Pointer jumping over the dense ruler array until every ruler on a path points at its end.
@@ -2378,7 +2468,10 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   hipLaunchKernelGGL(k_end_fill, dim3(unsigned(n_hblocks)), dim3(256), 0, st, link, n, end_before, ends);
   p->directed = directed;
   p->ends = ends;
-  int64_t n_ends = -1;
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, end_before + n_hblocks, 8, hipMemcpyDeviceToHost, st));
+  KSH_HIP(hipStreamSynchronize(st));
+  const int64_t n_ends = ctx->h_pinned[0];
+  p->n_ends = n_ends;
   for (bool stamped = rank_with_stamps();; stamped = true) {
     int* changed = flags;
     const int64_t ns2 = 2 * n;
@@ -2387,13 +2480,20 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     // k_choose; without: both in the record array, which nothing stamps, until the strings are written
     unsigned long long* rinfo = stamped ? reinterpret_cast<unsigned long long*>(p->c01) : p->info;
     unsigned long long* chain_info = stamped ? reinterpret_cast<unsigned long long*>(p->c23) : p->info + n_dense;
-    if (stamped) KSH_HIP(hipMemsetAsync(p->info, 0xFF, size_t(2 * n) * 8, st));  // chain-rank records unset
     {
       Timer timer(ctx, 4, n);
-      if (stamped)
-        hipLaunchKernelGGL(k_ruler_walk<true>, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, p->info);
-      else
-        hipLaunchKernelGGL(k_ruler_walk<false>, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, p->info);
+      if (stamped) {
+        KSH_HIP(hipMemsetAsync(p->info, 0xFF, size_t(2 * n) * 8, st));  // chain-rank records unset
+        hipLaunchKernelGGL(k_ruler_walk, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, p->info);
+        hipLaunchKernelGGL(k_ruler_heads, dim3(nblk(n_ends)), dim3(256), 0, st, link, ends, n_ends, p->info, chain_info);
+      } else {
+        KSH_HIP(hipMemsetAsync(rinfo, 0xFF, size_t(n_dense) * 8, st));
+        hipLaunchKernelGGL(k_rank_unset, dim3(nblk(n_ends)), dim3(256), 0, st, ends, n_ends, chain_info);
+        hipLaunchKernelGGL(k_rank_walk<1>, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, chain_info);
+        hipLaunchKernelGGL(k_rank_heads<1>, dim3(nblk(n_ends)), dim3(256), 0, st, link, ends, n_ends, rinfo, chain_info);
+        hipLaunchKernelGGL(k_rank_walk<2>, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, chain_info);
+        hipLaunchKernelGGL(k_rank_heads<2>, dim3(nblk(n_ends)), dim3(256), 0, st, link, ends, n_ends, rinfo, chain_info);
+      }
     }
     int max_rounds = 2;
     for (int64_t x = n_dense; x > 1; x >>= 1) max_rounds++;
@@ -2402,21 +2502,12 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       for (int b = 0; b < 4 && round < max_rounds; b++, round++)
         hipLaunchKernelGGL(k_ruler_jump, dim3(nblk(n_dense)), dim3(256), 0, st, n_dense, rinfo, changed);
       KSH_HIP(hipMemcpyAsync(ctx->h_pinned, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-      if (n_ends < 0)  // the length of the end list rides along with the first of these round trips
-        KSH_HIP(hipMemcpyAsync(ctx->h_pinned + 1, end_before + n_hblocks, 8, hipMemcpyDeviceToHost, st));
       KSH_HIP(hipStreamSynchronize(st));
-      if (n_ends < 0) n_ends = ctx->h_pinned[1];
       if (reinterpret_cast<int*>(ctx->h_pinned)[1])
         return fail(KSH_INVALID_ARGUMENT, "the canonical set holds a k-mer that is its own reverse "
                                           "complement (even k): not supported");
       if (reinterpret_cast<int*>(ctx->h_pinned)[0] == 0) break;
     }
-    p->n_ends = n_ends;
-    // (the chain starts only point at the ruler ahead of them: the order against the jumping is free)
-    if (stamped)
-      hipLaunchKernelGGL(k_ruler_heads<true>, dim3(nblk(n_ends)), dim3(256), 0, st, link, ends, n_ends, p->info, chain_info);
-    else
-      hipLaunchKernelGGL(k_ruler_heads<false>, dim3(nblk(n_ends)), dim3(256), 0, st, link, ends, n_ends, p->info, chain_info);
     KSH_HIP(hipMemsetAsync(d_tot, 0, (3 + kLenSums) * 8, st));
     int* loop_flag = reinterpret_cast<int*>(d_tot + 2 + kLenSums);
     if (stamped) {

@@ -197,7 +197,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     timers = {name: (ctx.timing_read(kind), ctx.timing_units(kind))
-              for name, kind in (("k_adjacency", 3), ("k_ruler_walk", 4), ("k_emit", 5))}
+              for name, kind in (("k_adjacency", 3), ("ranking_walks", 4), ("emit_walks", 5))}
     ctx.enable_timing(False)
 
     st = kss.stats()
@@ -377,7 +377,7 @@ def main():
         if traffic_per_kmer is not None:
             traffic = traffic_per_kmer * kmers_per_launch
         other = {}
-        for name in ("k_ruler_walk", "k_emit"):
+        for name in ("ranking_walks", "emit_walks"):
             (ms, n), units = timers[name]
             other[name] = {"ms_total": ms, "launches": n, "ns_per_kmer": ms * 1e6 / max(units, 1)}
         out = {

@@ -93,8 +93,9 @@ int ksh_ctx_reserve(ksh_ctx* ctx, size_t bytes);
  * the number of timed launches since the last reset.
  * kinds: 0 = pair merge, write pass   1 = pair merge, count pass
  *        2 = sampled-bucket weight count pass
- *        3 = SPSS encode, neighbour probe (k_adjacency: the loop's dominant kernel)
- *        4 = SPSS encode, chain ranking (k_ruler_walk)   5 = SPSS encode, base emit (k_emit)
+ *        3 = SPSS encode, neighbour probe stage (partition + LDS-staged probes: the loop's dominant stage)
+ *        4 = SPSS encode, chain ranking walks (k_rank_walk / k_rank_heads, or the stamping k_ruler_walk /
+ *            k_ruler_heads)   5 = SPSS encode, base emit (k_emit_rulers / k_emit_heads, or k_emit)
  * ksh_ctx_timing_units: the k-mers (kinds 3..5) the timed launches of a kind covered. */
 int ksh_ctx_enable_timing(ksh_ctx* ctx, int enable);
 int ksh_ctx_timing_reset(ksh_ctx* ctx);

@@ -27,9 +27,10 @@ if grep -q "k_adj_fwd_staged" $F; then
 else
   python3 $R/tools/pmc_kernel.py $F $W k_adjacency $O/${TAG}_pmc_adjacency_stage.json
 fi
-for K in k_ruler_walk k_links k_emit k_choose; do
-  python3 $R/tools/pmc_kernel.py $F $W $K $O/${TAG}_pmc_$K.json
-done
+# the walks have a thread per ruler or per end k-mer: their k-mers are those of the same encodes' forward probe
+python3 $R/tools/pmc_kernel.py $F $W k_rank_walk,k_rank_heads,k_rank_unset,k_ruler_jump $O/${TAG}_pmc_ranking_walks.json --units-from k_adj_fwd_staged
+python3 $R/tools/pmc_kernel.py $F $W k_emit_rulers,k_emit_heads $O/${TAG}_pmc_emit_walks.json --units-from k_adj_fwd_staged
+python3 $R/tools/pmc_kernel.py $F $W k_link_cut,k_end_counts,k_end_fill,k_choose_ends $O/${TAG}_pmc_links_and_ends.json --units-from k_adj_fwd_staged
 # keep the merged-back payload small: the per-dispatch CSVs are tens of MB
 S=$(find $O/${TAG}_stats -name "*kernel_stats.csv" | head -1)
 cp $S $O/${TAG}_kernel_stats.csv

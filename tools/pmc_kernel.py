@@ -44,10 +44,16 @@ def main():
     fetch_csv, write_csv, names = args[0], args[1], args[2].split(",")
     out_path = args[3] if len(args) > 3 else None
     units_from = units_from or names[0]
-    f = rows(fetch_csv, names, "FETCH_SIZE")
-    w = rows(write_csv, names, "WRITE_SIZE")
+    # (--units-from may name a kernel outside the stage: one with a thread per k-mer, launched once per
+    # encode like the stage's kernels, when none of those has that shape)
+    extra = [] if units_from in names else [units_from]
+    f = rows(fetch_csv, names + extra, "FETCH_SIZE")
+    w = rows(write_csv, names + extra, "WRITE_SIZE")
     units_f = sum(x[0] for x in f.get(units_from, []))
     units_w = sum(x[0] for x in w.get(units_from, []))
+    for nm in extra:
+        f.pop(nm, None)
+        w.pop(nm, None)
     fetch_kb = sum(x[1] for v in f.values() for x in v)
     write_kb = sum(x[1] for v in w.values() for x in v)
     fb = fetch_kb * 1024 / max(units_f, 1)

@@ -1083,10 +1083,40 @@ __device__ __forceinline__ bool first_phase(uint32_t s) {
   return (((s >> 1) * 0x9E3779B1u) >> 13 ^ s) & 1u;
 }
 
+// What a ranking walk leaves behind for the writing of the strings (k_emit_log_*): where it arrived
+// after how many steps, and the states it passed K, 2K, ... steps in.  A k-mer spells the K bases
+// from its slot on, so the k-mers at steps 0, K, 2K, ... and the one at the arrival spell the
+// whole stretch between them (in either orientation of the string: a k-mer covers the same K
+// slots read forwards or as its reverse complement) -- no second walk, a handful of key reads per
+// stretch instead of one link read per k-mer.  One walk per stretch is enough here too (whichever
+// of the two mirror images ran).
+struct WalkLog {
+  unsigned long long* hdr;  // per walker: steps:32 | arrival state:32; all ones = it did not walk.  NULL: no logs
+  uint32_t* mid;            // mid[j * n_walkers + w] = the state (j + 1) * K steps into walk w
+  int64_t n_walkers;
+  int n_mid;                // entries kept per walker; a longer stretch is walked again when it is written
+  int k;
+  // the stretches longer than that (one in a few hundred): ruler walkers by dense index, head
+  // walkers by end-list index | long_tag
+  uint32_t* long_walkers;
+  unsigned int* long_count;
+  uint32_t long_tag;
+  __device__ __forceinline__ bool is_long(uint32_t steps) const { return steps > uint32_t(n_mid + 1) * uint32_t(k); }
+  __device__ __forceinline__ void arrived(int64_t w, uint32_t steps, uint32_t state) const {
+    if (!hdr) return;
+    hdr[w] = (uint64_t(steps) << 32) | state;
+    if (is_long(steps)) long_walkers[atomicAdd(long_count, 1u)] = uint32_t(w) | long_tag;
+  }
+  __device__ __forceinline__ void passed(int64_t w, int j, uint32_t state) const {
+    if (hdr && j < n_mid) mid[int64_t(j) * n_walkers + w] = state;
+  }
+};
+constexpr int kLogMidRulers = 7, kLogMidHeads = 7;
+
 template <int kPhase>
 __global__ __launch_bounds__(256) void k_rank_walk(const uint32_t* __restrict__ link, int64_t n_states,
                                                     int64_t n_dense, unsigned long long* __restrict__ rinfo,
-                                                    unsigned long long* __restrict__ chain_info) {
+                                                    unsigned long long* __restrict__ chain_info, WalkLog log) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n_dense) return;
   const int64_t s64 = 2 * int64_t(kRulerEvery) * (i >> 1) + (i & 1);
@@ -1096,25 +1126,34 @@ __global__ __launch_bounds__(256) void k_rank_walk(const uint32_t* __restrict__ 
   }
   const uint32_t r = uint32_t(s64);
   if (kPhase == 1 ? !first_phase(r) : rinfo[i] != kRecUnset) return;
-  uint32_t lk = leave_link(link_pair(link, r), r);
+  const uint2 own = link_pair(link, r);
+  uint32_t lk = leave_link(own, r);
   if (lk == kNone) {
     rinfo[i] = make_rinfo(true, 0, r);
+    if (enter_link(own, r) == kNone) log.arrived(i, 0, r);  // a k-mer on its own: no walk arrives at it
     return;
   }
   uint32_t cur = r, steps = 0;
+  int since = 0, n_passed = 0;
   while (true) {
     cur = step_to(cur, lk);
     steps++;
     if (sampled_ruler(cur) || steps >= 0x3FFFFFFFu) {
       rinfo[i] = make_rinfo(false, steps, cur);
       rinfo[dense_index(cur ^ 1)] = make_rinfo(false, steps, r ^ 1);
+      log.arrived(i, steps, cur);
       return;
+    }
+    if (++since == log.k) {
+      since = 0;
+      log.passed(i, n_passed++, cur);
     }
     lk = leave_link(link_pair(link, cur), cur);
     if (lk == kNone) {
       rinfo[i] = make_rinfo(true, steps, cur);
       // the chain that starts at cur ^ 1 (an unsampled k-mer) has ruler r ^ 1 ahead of it
       chain_info[cur >> 1] = make_chain_info(true, steps, dense_index(r ^ 1));
+      log.arrived(i, steps, cur);
       return;
     }
   }
@@ -1124,7 +1163,7 @@ template <int kPhase>
 __global__ __launch_bounds__(256) void k_rank_heads(const uint32_t* __restrict__ link,
                                                      const uint32_t* __restrict__ ends, int64_t n_ends,
                                                      unsigned long long* __restrict__ rinfo,
-                                                     unsigned long long* __restrict__ chain_info) {
+                                                     unsigned long long* __restrict__ chain_info, WalkLog log) {
   const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (e >= n_ends) return;
   const uint32_t t = ends[e];
@@ -1132,24 +1171,36 @@ __global__ __launch_bounds__(256) void k_rank_heads(const uint32_t* __restrict__
   const uint2 own = reinterpret_cast<const uint2*>(link)[t];
   // the one state of t that starts a chain of two or more states, if any
   uint32_t s0;
-  if (own.x == kNone && own.y != kNone) s0 = 2 * t;
-  else if (own.y == kNone && own.x != kNone) s0 = 2 * t + 1;
-  else return;
+  if (own.x == kNone && own.y != kNone) {
+    s0 = 2 * t;
+  } else if (own.y == kNone && own.x != kNone) {
+    s0 = 2 * t + 1;
+  } else {
+    if (kPhase == 1) log.arrived(e, 0, 2 * t);  // a k-mer on its own: no walk arrives at it
+    return;
+  }
   if (kPhase == 1 ? !first_phase(s0) : chain_info[t] != kRecUnset) return;
   uint32_t lk = leave_link(own, s0);
   uint32_t cur = s0, off = 0;
+  int since = 0, n_passed = 0;
   while (true) {
     cur = step_to(cur, lk);
     off++;
     if (sampled_ruler(cur)) {
       chain_info[t] = make_chain_info(true, off, dense_index(cur));
       rinfo[dense_index(cur ^ 1)] = make_rinfo(true, off, s0 ^ 1);  // its walk ends at the chain end s0 ^ 1
+      log.arrived(e, off, cur);
       return;
+    }
+    if (++since == log.k) {
+      since = 0;
+      log.passed(e, n_passed++, cur);
     }
     lk = leave_link(link_pair(link, cur), cur);
     if (lk == kNone || off >= 0x3FFFFFFFu) {
       chain_info[t] = make_chain_info(false, off, cur);
       chain_info[cur >> 1] = make_chain_info(false, off, s0 ^ 1);  // the mirror chain, from cur ^ 1 to s0 ^ 1
+      log.arrived(e, off, cur);
       return;
     }
   }
@@ -2196,6 +2247,142 @@ __global__ __launch_bounds__(256) void k_emit_heads(DevSet<KeyT> set, const uint
   emit_walk<KeyT, kRun>(set, link, first_state, own, set.kmer(t), pl, flip ? (c.len - 1 - c.p) : c.p, bytes);
 }
 
+// ---- the strings from the logs of the ranking walks (WalkLog): one thread per walker that walked.
+// It ranks its first k-mer like k_choose does, looks up the unitig's place, and writes the k-mers
+// its log names -- itself, the ones K, 2K, ... steps in, the one it arrived at -- each at the slot
+// the step count gives (counting down when the walk ran against the string, and then the k-mer is
+// written as its reverse complement).  A stretch longer than the log holds (one in a few hundred)
+// is walked once more -- not here, where one such lane would keep its 63 neighbours waiting for
+// hundreds of dependent reads, but from a list, by k_emit_log_long.
+constexpr uint32_t kLongHead = 0x80000000u;
+constexpr int kLongBlocks = 128;  // workgroups of k_emit_log_rulers that walk the listed long stretches
+
+template <typename KeyT, int kRun, bool kLongPass>
+__device__ __forceinline__ void emit_logged(const DevSet<KeyT>& set, const uint32_t* __restrict__ link,
+                                            const WalkLog& log, int64_t w, uint64_t hdr, uint32_t u,
+                                            uint64_t x_u, const Chosen& c, const UnitigPlace& pl,
+                                            uint8_t* __restrict__ bytes) {
+  const int k = set.k;
+  const uint32_t flip = pl.flags & 1;
+  const uint32_t q_u = flip ? (c.len - 1 - c.p) : c.p;
+  const bool with_string = (u & 1) == (c.d ^ flip);  // the walk ran in string order
+  const uint32_t steps = uint32_t(hdr >> 32), arrival = uint32_t(hdr);
+  const auto emit = [&](uint32_t state, uint32_t step, uint64_t x) {
+    const uint32_t q = with_string ? q_u + step : q_u - step;
+    if (q >= pl.len) return;  // (cannot happen: the guard keeps a corrupt log from writing elsewhere)
+    const uint32_t as_read = with_string ? state : state ^ 1;
+    store_kmer<kRun>(bytes + pl.base + q, (as_read & 1) ? revcomp(x, k) : x, k);
+  };
+  if (!kLongPass) {
+    if (log.is_long(steps)) return;  // on the list (WalkLog::arrived)
+    emit(u, 0, x_u);
+    if (steps == 0) return;
+    const int n_passed = int((steps - 1) / uint32_t(k));
+    for (int j = 0; j < n_passed; j++) {
+      const uint32_t st = log.mid[int64_t(j) * log.n_walkers + w];
+      emit(st, uint32_t(j + 1) * uint32_t(k), set.kmer(st >> 1));
+    }
+    emit(arrival, steps, set.kmer(arrival >> 1));
+  } else {
+    emit(u, 0, x_u);
+    uint32_t cur = u, step = 0;
+    int since = 0;
+    while (step < steps) {
+      const uint32_t lk = leave_link(link_pair(link, cur), cur);
+      if (lk == kNone) return;
+      cur = step_to(cur, lk);
+      step++;
+      if (++since == k || step == steps) {
+        since = 0;
+        emit(cur, step, set.kmer(cur >> 1));
+      }
+    }
+  }
+}
+
+template <typename KeyT, int kRun, bool kLongPass>
+__device__ __forceinline__ void emit_ruler_walker(const DevSet<KeyT>& set, const uint32_t* __restrict__ link,
+                                                  const unsigned long long* __restrict__ rinfo,
+                                                  const WalkLog& log, bool directed, int64_t i, uint64_t x_t,
+                                                  const UnitigPlace* __restrict__ place_at_head,
+                                                  uint8_t* __restrict__ bytes) {
+  const uint64_t hdr = log.hdr[i];
+  if (hdr == kRecUnset) return;
+  const int64_t t = (i >> 1) << kRulerShift;
+  // both states of a sampled k-mer have reached their ends (there is no loop on this path)
+  const ulonglong2 ri = reinterpret_cast<const ulonglong2*>(rinfo)[i >> 1];
+  const Chosen c = choose_from_ends(uint32_t(ri.x), uint32_t((ri.x >> 32) & 0x7FFFFFFFu), uint32_t(ri.y),
+                                    uint32_t((ri.y >> 32) & 0x7FFFFFFFu), directed);
+  emit_logged<KeyT, kRun, kLongPass>(set, link, log, i, hdr, uint32_t(2 * t + (i & 1)), x_t, c,
+                                     place_at_head[c.head_state >> 1], bytes);
+}
+
+template <typename KeyT, int kRun, bool kLongPass>
+__device__ __forceinline__ void emit_head_walker(const DevSet<KeyT>& set, const uint32_t* __restrict__ link,
+                                                 const unsigned long long* __restrict__ rinfo,
+                                                 const unsigned long long* __restrict__ chain_info,
+                                                 const WalkLog& log, bool directed, const uint32_t* __restrict__ ends,
+                                                 int64_t e, const UnitigPlace* __restrict__ place_at_head,
+                                                 uint8_t* __restrict__ bytes) {
+  const uint64_t hdr = log.hdr[e];
+  if (hdr == kRecUnset) return;
+  const uint32_t t = ends[e];
+  const uint2 own = reinterpret_cast<const uint2*>(link)[t];
+  Chosen c;
+  if (!choose_at(t, own, rinfo, chain_info, directed, &c)) return;
+  // the state that walked: the one that starts a chain (state 2t of a k-mer on its own)
+  const uint32_t u = (own.y == kNone && own.x != kNone) ? 2 * t + 1 : 2 * t;
+  emit_logged<KeyT, kRun, kLongPass>(set, link, log, e, hdr, u, set.kmer(t), c, place_at_head[c.head_state >> 1],
+                                     bytes);
+}
+
+// The first kLongBlocks workgroups walk the listed long stretches (rulers' and heads'), striding over
+// the list -- their few hundred dependent reads each run under the rest of the grid, which takes
+// the walkers of the dense ruler array one thread each.
+template <typename KeyT, int kRun>
+__global__ __launch_bounds__(256) void k_emit_log_rulers(DevSet<KeyT> set, const uint32_t* __restrict__ link,
+                                                          const unsigned long long* __restrict__ rinfo,
+                                                          const unsigned long long* __restrict__ chain_info,
+                                                          WalkLog log, WalkLog log_heads, bool directed,
+                                                          const uint32_t* __restrict__ ends,
+                                                          const UnitigPlace* __restrict__ place_at_head,
+                                                          uint8_t* __restrict__ bytes) {
+  __shared__ int64_t s_bucket[2];
+  if (blockIdx.x < kLongBlocks) {
+    const unsigned int n_long = *log.long_count;
+    for (unsigned int at = blockIdx.x * blockDim.x + threadIdx.x; at < n_long; at += kLongBlocks * blockDim.x) {
+      const uint32_t w = log.long_walkers[at];
+      if (w & kLongHead) {
+        emit_head_walker<KeyT, kRun, true>(set, link, rinfo, chain_info, log_heads, directed, ends,
+                                           int64_t(w & ~kLongHead), place_at_head, bytes);
+      } else {
+        emit_ruler_walker<KeyT, kRun, true>(set, link, rinfo, log, directed, int64_t(w),
+                                            set.kmer((int64_t(w) >> 1) << kRulerShift), place_at_head, bytes);
+      }
+    }
+    return;
+  }
+  const int64_t first = int64_t(blockIdx.x - kLongBlocks) * blockDim.x;
+  set.block_bucket_at((first >> 1) << kRulerShift, s_bucket);
+  const int64_t i = first + threadIdx.x;
+  if (i >= log.n_walkers || ((i >> 1) << kRulerShift) >= set.n) return;
+  emit_ruler_walker<KeyT, kRun, false>(set, link, rinfo, log, directed, i,
+                                       set.kmer_from_block((i >> 1) << kRulerShift, s_bucket), place_at_head, bytes);
+}
+
+template <typename KeyT, int kRun>
+__global__ __launch_bounds__(256) void k_emit_log_heads(DevSet<KeyT> set, const uint32_t* __restrict__ link,
+                                                         const unsigned long long* __restrict__ rinfo,
+                                                         const unsigned long long* __restrict__ chain_info,
+                                                         WalkLog log, bool directed,
+                                                         const uint32_t* __restrict__ ends,
+                                                         const UnitigPlace* __restrict__ place_at_head,
+                                                         uint8_t* __restrict__ bytes) {
+  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= log.n_walkers) return;
+  emit_head_walker<KeyT, kRun, false>(set, link, rinfo, chain_info, log, directed, ends, e, place_at_head, bytes);
+}
+
 __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ bytes, int64_t n_bases,
                                                int64_t n_words, uint64_t* __restrict__ words) {
   const int64_t w = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -2252,6 +2439,7 @@ struct EncPlan {
   const unsigned long long *rinfo = nullptr, *chain_info = nullptr;
   const uint32_t* ends = nullptr;  // the end k-mers, ascending (aliases pos)
   int64_t n_ends = 0;
+  WalkLog log_rulers{}, log_heads{};  // hdr == NULL: the strings are written by walking (k_emit_rulers / k_emit_heads)
 };
 
 inline size_t al(size_t x) { return (x + 255) & ~size_t(255); }
@@ -2274,6 +2462,15 @@ inline bool rank_with_stamps() {
   static const bool on = [] {
     const char* e = getenv("KSH_RANK");
     return e && std::string(e) == "stamp";
+  }();
+  return on;
+}
+// KSH_EMIT=walk: the strings are written by a second walk over the chains instead of from the logs of
+// the ranking walks (what a set whose logs do not fit falls back to).
+inline bool emit_by_walking() {
+  static const bool on = [] {
+    const char* e = getenv("KSH_EMIT");
+    return e && std::string(e) == "walk";
   }();
   return on;
 }
@@ -2487,12 +2684,37 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
         hipLaunchKernelGGL(k_ruler_walk, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, p->info);
         hipLaunchKernelGGL(k_ruler_heads, dim3(nblk(n_ends)), dim3(256), 0, st, link, ends, n_ends, p->info, chain_info);
       } else {
+        // the walk logs behind the two record arrays, when they fit (16n bytes in all)
+        WalkLog lr{}, lh{};
+        lr.k = lh.k = g->k;
+        const size_t used = (size_t(n_dense) + size_t(n)) * 8;
+        const size_t log_bytes = size_t(n_dense) * (8 + 4 * kLogMidRulers + 4) + size_t(n_ends) * (8 + 4 * kLogMidHeads + 4) + 64;  // + the long list
+        if (!emit_by_walking() && used + log_bytes <= size_t(2 * n) * 8) {
+          unsigned long long* at8 = p->info + n_dense + n;
+          lr.hdr = at8;
+          lh.hdr = at8 + n_dense;
+          uint32_t* at4 = reinterpret_cast<uint32_t*>(at8 + n_dense + n_ends);
+          lr.mid = at4;
+          lh.mid = at4 + size_t(kLogMidRulers) * n_dense;
+          lr.long_walkers = lh.long_walkers = lh.mid + size_t(kLogMidHeads) * n_ends;  // n_dense + n_ends entries at most
+          lr.long_count = lh.long_count = reinterpret_cast<unsigned int*>(lr.long_walkers + n_dense + n_ends);
+          lr.long_tag = 0;
+          lh.long_tag = kLongHead;
+          KSH_HIP(hipMemsetAsync(lr.long_count, 0, 8, st));
+          lr.n_walkers = n_dense;
+          lh.n_walkers = n_ends;
+          lr.n_mid = kLogMidRulers;
+          lh.n_mid = kLogMidHeads;
+          KSH_HIP(hipMemsetAsync(at8, 0xFF, size_t(n_dense + n_ends) * 8, st));  // nobody has walked yet
+        }
+        p->log_rulers = lr;
+        p->log_heads = lh;
         KSH_HIP(hipMemsetAsync(rinfo, 0xFF, size_t(n_dense) * 8, st));
         hipLaunchKernelGGL(k_rank_unset, dim3(nblk(n_ends)), dim3(256), 0, st, ends, n_ends, chain_info);
-        hipLaunchKernelGGL(k_rank_walk<1>, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, chain_info);
-        hipLaunchKernelGGL(k_rank_heads<1>, dim3(nblk(n_ends)), dim3(256), 0, st, link, ends, n_ends, rinfo, chain_info);
-        hipLaunchKernelGGL(k_rank_walk<2>, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, chain_info);
-        hipLaunchKernelGGL(k_rank_heads<2>, dim3(nblk(n_ends)), dim3(256), 0, st, link, ends, n_ends, rinfo, chain_info);
+        hipLaunchKernelGGL(k_rank_walk<1>, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, chain_info, lr);
+        hipLaunchKernelGGL(k_rank_heads<1>, dim3(nblk(n_ends)), dim3(256), 0, st, link, ends, n_ends, rinfo, chain_info, lh);
+        hipLaunchKernelGGL(k_rank_walk<2>, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, chain_info, lr);
+        hipLaunchKernelGGL(k_rank_heads<2>, dim3(nblk(n_ends)), dim3(256), 0, st, link, ends, n_ends, rinfo, chain_info, lh);
       }
     }
     int max_rounds = 2;
@@ -2692,6 +2914,13 @@ int encode_write_t(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens) {
     if (p->stamped) {                                                                                          \
       hipLaunchKernelGGL((k_emit<KeyT, W>), dim3(nblk(n)), dim3(256), 0, st, set, p->head, p->pos, p->ori,     \
                          place, bytes);                                                                        \
+    } else if (p->log_rulers.hdr) {                                                                            \
+      hipLaunchKernelGGL((k_emit_log_rulers<KeyT, R>), dim3(kLongBlocks + nblk(p->log_rulers.n_walkers)),      \
+                         dim3(256), 0, st, set, p->nbr, p->rinfo, p->chain_info, p->log_rulers, p->log_heads,  \
+                         p->directed, p->ends, place, bytes);                                                  \
+      hipLaunchKernelGGL((k_emit_log_heads<KeyT, R>), dim3(nblk(p->log_heads.n_walkers)), dim3(256), 0, st,    \
+                         set, p->nbr, p->rinfo, p->chain_info, p->log_heads, p->directed, p->ends, place,      \
+                         bytes);                                                                               \
     } else {                                                                                                   \
       hipLaunchKernelGGL((k_emit_rulers<KeyT, R>), dim3(nblk(n_sampled)), dim3(256), 0, st, set, p->nbr,       \
                          p->rinfo, p->chain_info, p->directed, place, bytes);                                  \

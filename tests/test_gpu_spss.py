@@ -334,10 +334,11 @@ def test_encode_branching_sets(ctx):
             assert st["unitigs"] > 700 and st["strings"] < st["unitigs"]
 
 
-@pytest.mark.parametrize("knob", ["KSH_RANK=stamp", "KSH_ADJACENCY=probe", "KSH_FWD=probe", "KSH_RC_SCATTER=direct"])
+@pytest.mark.parametrize("knob", ["KSH_RANK=stamp", "KSH_EMIT=walk", "KSH_ADJACENCY=probe", "KSH_FWD=probe", "KSH_RC_SCATTER=direct"])
 def test_encode_alternative_paths(gpu, knob):
     """The encoder's other routes give the oracle's strings too: the stamping ranking walks with
-    k_choose / k_emit per k-mer (what a set with a non-branching loop falls back to), the in-place
+    k_choose / k_emit per k-mer (what a set with a non-branching loop falls back to), the strings
+    written by a second walk instead of from the ranking walks' logs, the in-place
     neighbour probe, the in-place forward half, the one-pass record scatter.  The switches are read
     once per process, so each runs in a process of its own."""
     import os

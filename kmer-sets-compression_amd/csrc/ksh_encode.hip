@@ -1227,6 +1227,95 @@ __global__ __launch_bounds__(256) void k_ruler_jump(int64_t n_dense,
   *changed = 1;
 }
 
+// ---- the same result in two levels (ranking without stamps): pointer jumping costs a cache-missing
+// read per ruler per round (the ruler records of a 10^8-k-mer set are 50 MB) for log2(rulers per
+// chain) rounds -- 24 for a genome.  The ruler records form linked lists themselves, so they are
+// ranked the way the k-mers are: every 32nd sampled k-mer is a level-2 ruler, the level-2 rulers
+// and the first ruler of every chain (the one whose mirror image reaches a chain end without
+// meeting a ruler: nothing comes before it) walk along the records to the next level-2 ruler or
+// the end, stamping what they pass with (walker, distance so far); pointer jumping then runs over
+// the level-2 rulers only (1/32 of the records, L2-resident), and k_l2_resolve gives every record
+// its end and distance through its stamp.  Records on a loop of rulers stay without an end.
+constexpr int kL2Shift = 5;
+__device__ __forceinline__ bool is_level2(int64_t i) { return ((i >> 1) & ((1 << kL2Shift) - 1)) == 0; }
+__device__ __forceinline__ int64_t level2_index(int64_t i) { return ((i >> (kL2Shift + 1)) << 1) | (i & 1); }
+__device__ __forceinline__ int64_t level2_entry(int64_t j) { return ((j >> 1) << (kL2Shift + 1)) | (j & 1); }
+
+// One thread per ruler record; the level-2 rulers and the chain heads walk.
+//   r2[j]    (level-2 ruler j): end:1 | dist:31 | ref:32 -- the next level-2 ruler (record index) or the end state
+//   head[i]  (chain head i, not level 2): the same
+//   stamp[e] (everything they pass): dist:32 | walker record:32
+__global__ __launch_bounds__(256) void k_l2_walk(const unsigned long long* __restrict__ rinfo, int64_t n_dense,
+                                                  unsigned long long* __restrict__ r2,
+                                                  unsigned long long* __restrict__ head,
+                                                  unsigned long long* __restrict__ stamp) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_dense) return;
+  const bool l2 = is_level2(i);
+  if (!l2 && !(rinfo[i ^ 1] & kEndFlag)) return;  // something comes before it: that walker passes it
+  uint64_t dist = 0;
+  int64_t cur = i;
+  uint64_t out;
+  for (int64_t steps = 0;; steps++) {
+    const uint64_t ri = rinfo[cur];
+    dist += (ri >> 32) & 0x7FFFFFFFu;
+    if (ri & kEndFlag) {
+      out = kEndFlag | ((dist & 0x7FFFFFFFu) << 32) | uint32_t(ri);
+      break;
+    }
+    cur = dense_index(uint32_t(ri));
+    if (is_level2(cur) || steps > n_dense) {
+      out = ((dist & 0x7FFFFFFFu) << 32) | uint32_t(cur);
+      break;
+    }
+    stamp[cur] = (dist << 32) | uint32_t(i);
+  }
+  if (l2) r2[level2_index(i)] = out; else head[i] = out;
+}
+
+// Pointer jumping over the level-2 rulers.
+__global__ __launch_bounds__(256) void k_l2_jump(int64_t n_l2, unsigned long long* __restrict__ r2,
+                                                  int* __restrict__ changed) {
+  const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (j >= n_l2) return;
+  const uint64_t mine = r2[j];
+  if (mine & kEndFlag) return;
+  const uint64_t theirs = r2[level2_index(int64_t(uint32_t(mine)))];
+  const uint32_t dist = uint32_t((mine >> 32) & 0x7FFFFFFFu) + uint32_t((theirs >> 32) & 0x7FFFFFFFu);
+  r2[j] = (theirs & kEndFlag) | (uint64_t(dist & 0x7FFFFFFFu) << 32) | uint32_t(theirs);
+  *changed = 1;
+}
+
+// (end, distance) of a walker of k_l2_walk once the level-2 rulers have theirs; no end flag on a loop.
+__device__ __forceinline__ uint64_t l2_walker_end(int64_t w, const unsigned long long* __restrict__ r2,
+                                                  const unsigned long long* __restrict__ head) {
+  if (is_level2(w)) return r2[level2_index(w)];
+  const uint64_t h = head[w];
+  if (h & kEndFlag) return h;
+  const uint64_t ahead = r2[level2_index(int64_t(uint32_t(h)))];
+  const uint32_t dist = uint32_t((h >> 32) & 0x7FFFFFFFu) + uint32_t((ahead >> 32) & 0x7FFFFFFFu);
+  return (ahead & kEndFlag) | (uint64_t(dist & 0x7FFFFFFFu) << 32) | uint32_t(ahead);
+}
+
+__global__ __launch_bounds__(256) void k_l2_resolve(int64_t n_dense, const unsigned long long* __restrict__ r2,
+                                                     const unsigned long long* __restrict__ head,
+                                                     const unsigned long long* __restrict__ stamp,
+                                                     unsigned long long* __restrict__ rinfo) {
+  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (i >= n_dense) return;
+  const uint64_t mine = rinfo[i];
+  if (mine & kEndFlag) return;  // reaches its end without meeting a ruler
+  if (is_level2(i) || head[i] != kRecUnset) {  // (head and stamp start unset)
+    rinfo[i] = l2_walker_end(i, r2, head);
+    return;
+  }
+  const uint64_t st = stamp[i];
+  if (st == kRecUnset) return;  // a loop of rulers without a level-2 ruler: stays without an end
+  const uint64_t we = l2_walker_end(int64_t(uint32_t(st)), r2, head);
+  const uint32_t dist = uint32_t((we >> 32) & 0x7FFFFFFFu) - uint32_t(st >> 32);
+  rinfo[i] = (we & kEndFlag) | (uint64_t(dist & 0x7FFFFFFFu) << 32) | uint32_t(we);
+}
+
 // A ruler segment is walked twice, once in each direction (the two states of a k-mer lie on
 // mirror-image chains), and the random 8-byte record writes of those walks are what bounds them
 // (31 G random writes/s against 55 G reads/s).  So a walk only stamps the states with d == 0:
@@ -2474,6 +2563,14 @@ inline bool emit_by_walking() {
   }();
   return on;
 }
+// KSH_L2_MIN: ruler records from which the pointer jumping runs in two levels (tests set it low).
+inline int64_t l2_threshold() {
+  static const int64_t v = [] {
+    const char* e = getenv("KSH_L2_MIN");
+    return e ? std::max<int64_t>(4096, atoll(e)) : int64_t(1) << 20;
+  }();
+  return v;
+}
 inline unsigned nblk(int64_t n) { return unsigned(std::max<int64_t>(1, (n + 255) / 256)); }
 
 template <typename T>
@@ -2717,12 +2814,30 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
         hipLaunchKernelGGL(k_rank_heads<2>, dim3(nblk(n_ends)), dim3(256), 0, st, link, ends, n_ends, rinfo, chain_info, lh);
       }
     }
+    // pointer jumping: over all ruler records (with stamps), or in two levels (k_l2_*): the level-2
+    // records, the chain heads' and the stamps live in arrays that k_choose_ends fills afterwards
+    // (worth its four extra launches once a round over all records costs tens of microseconds)
+    const bool two_levels = !stamped && n_dense >= l2_threshold();
+    const int64_t n_jump = two_levels ? (((n_dense - 1) >> (kL2Shift + 1)) << 1) + 2 : n_dense;
+    unsigned long long* r2 = reinterpret_cast<unsigned long long*>(p->uid);        // n_jump * 8 <= 4n
+    unsigned long long* l2_head = reinterpret_cast<unsigned long long*>(p->hlen);  // n_dense * 8 <= 4n
+    unsigned long long* l2_stamp = reinterpret_cast<unsigned long long*>(p->hlast);
+    if (two_levels) {
+      KSH_HIP(hipMemsetAsync(l2_head, 0xFF, size_t(n_dense) * 8, st));
+      KSH_HIP(hipMemsetAsync(l2_stamp, 0xFF, size_t(n_dense) * 8, st));
+      hipLaunchKernelGGL(k_l2_walk, dim3(nblk(n_dense)), dim3(256), 0, st, rinfo, n_dense, r2, l2_head, l2_stamp);
+    }
     int max_rounds = 2;
-    for (int64_t x = n_dense; x > 1; x >>= 1) max_rounds++;
+    for (int64_t x = n_jump; x > 1; x >>= 1) max_rounds++;
+    const int batch = 4;
     for (int round = 0; round < max_rounds;) {
       KSH_HIP(hipMemsetAsync(changed, 0, sizeof(int), st));
-      for (int b = 0; b < 4 && round < max_rounds; b++, round++)
-        hipLaunchKernelGGL(k_ruler_jump, dim3(nblk(n_dense)), dim3(256), 0, st, n_dense, rinfo, changed);
+      for (int b = 0; b < batch && round < max_rounds; b++, round++) {
+        if (two_levels)
+          hipLaunchKernelGGL(k_l2_jump, dim3(nblk(n_jump)), dim3(256), 0, st, n_jump, r2, changed);
+        else
+          hipLaunchKernelGGL(k_ruler_jump, dim3(nblk(n_dense)), dim3(256), 0, st, n_dense, rinfo, changed);
+      }
       KSH_HIP(hipMemcpyAsync(ctx->h_pinned, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
       KSH_HIP(hipStreamSynchronize(st));
       if (reinterpret_cast<int*>(ctx->h_pinned)[1])
@@ -2730,6 +2845,8 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
                                           "complement (even k): not supported");
       if (reinterpret_cast<int*>(ctx->h_pinned)[0] == 0) break;
     }
+    if (two_levels)
+      hipLaunchKernelGGL(k_l2_resolve, dim3(nblk(n_dense)), dim3(256), 0, st, n_dense, r2, l2_head, l2_stamp, rinfo);
     KSH_HIP(hipMemsetAsync(d_tot, 0, (3 + kLenSums) * 8, st));
     int* loop_flag = reinterpret_cast<int*>(d_tot + 2 + kLenSums);
     if (stamped) {

@@ -334,11 +334,12 @@ def test_encode_branching_sets(ctx):
             assert st["unitigs"] > 700 and st["strings"] < st["unitigs"]
 
 
-@pytest.mark.parametrize("knob", ["KSH_RANK=stamp", "KSH_EMIT=walk", "KSH_ADJACENCY=probe", "KSH_FWD=probe", "KSH_RC_SCATTER=direct"])
+@pytest.mark.parametrize("knob", ["KSH_RANK=stamp", "KSH_EMIT=walk", "KSH_L2_MIN=4096", "KSH_ADJACENCY=probe", "KSH_FWD=probe", "KSH_RC_SCATTER=direct"])
 def test_encode_alternative_paths(gpu, knob):
     """The encoder's other routes give the oracle's strings too: the stamping ranking walks with
     k_choose / k_emit per k-mer (what a set with a non-branching loop falls back to), the strings
-    written by a second walk instead of from the ranking walks' logs, the in-place
+    written by a second walk instead of from the ranking walks' logs, the two-level pointer jumping on
+    sets of any size (by default it starts at 2^20 ruler records), the in-place
     neighbour probe, the in-place forward half, the one-pass record scatter.  The switches are read
     once per process, so each runs in a process of its own."""
     import os
@@ -362,6 +363,7 @@ def test_encode_alternative_paths(gpu, knob):
         "    s = synth.phylogeny_sets(k, 3, 30000, seed=k)\n"
         "    check(k, n, kb, s[0], (0, 1)); check(k, n, kb, np.intersect1d(s[0], s[1])); check(k, n, kb, np.setdiff1d(s[0], s[1]))\n"
         "check(23, 14, 4, synth.genome_with_tips(23, 150000, seed=7, every=150), (0, 2))\n"
+        "big = synth.phylogeny_sets(23, 2, 400000, seed=5); check(23, 14, 4, big[0]); check(23, 14, 4, np.intersect1d(big[0], big[1]))\n"
         "a, b = synth.phylogeny_sets(23, 2, 60000, seed=77, rate=0.004); check(23, 14, 4, np.union1d(a, b))\n"
         "for seed in range(24):\n"
         "    k = [5, 7, 9, 11][seed %% 4]\n"

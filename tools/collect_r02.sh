@@ -28,8 +28,8 @@ else
   python3 $R/tools/pmc_kernel.py $F $W k_adjacency $O/${TAG}_pmc_adjacency_stage.json
 fi
 # the walks have a thread per ruler or per end k-mer: their k-mers are those of the same encodes' forward probe
-python3 $R/tools/pmc_kernel.py $F $W k_rank_walk,k_rank_heads,k_rank_unset,k_ruler_jump $O/${TAG}_pmc_ranking_walks.json --units-from k_adj_fwd_staged
-python3 $R/tools/pmc_kernel.py $F $W k_emit_rulers,k_emit_heads $O/${TAG}_pmc_emit_walks.json --units-from k_adj_fwd_staged
+python3 $R/tools/pmc_kernel.py $F $W k_rank_walk,k_rank_heads,k_rank_unset,k_ruler_jump,k_l2_walk,k_l2_jump,k_l2_resolve $O/${TAG}_pmc_ranking_walks.json --units-from k_adj_fwd_staged
+python3 $R/tools/pmc_kernel.py $F $W k_emit_log_rulers,k_emit_log_heads $O/${TAG}_pmc_emit_from_logs.json --units-from k_adj_fwd_staged
 python3 $R/tools/pmc_kernel.py $F $W k_link_cut,k_end_counts,k_end_fill,k_choose_ends $O/${TAG}_pmc_links_and_ends.json --units-from k_adj_fwd_staged
 # keep the merged-back payload small: the per-dispatch CSVs are tens of MB
 S=$(find $O/${TAG}_stats -name "*kernel_stats.csv" | head -1)

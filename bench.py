@@ -410,7 +410,9 @@ def main():
             "phase_seconds_last_build": st["phase_seconds"],
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_adjacency (neighbour probe of the SPSS encode)",
+                "kernel": "neighbour-probe stage of the SPSS encode (k_rc_hist / k_rc_columns / k_rc_scatter_l1+l2 / k_rc_bounds / "
+                          "k_adj_rc / k_fwd_bounds / k_adj_fwd_staged; the in-place k_adjacency for sets outside their range): "
+                          "one timed launch = the whole stage of one encode",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -30,7 +30,8 @@ namespace ksh {
 
 constexpr int kDecThreads = 256;
 constexpr int kMaxLdsBuckets = 16384;   // 64 KiB of u32 counters
-constexpr int kSortLdsBytes = 40960;   // + 2 x 8 KiB of counters stays under 64 KiB
+constexpr int kSortLdsBytes = 45056;   // + 2 x 8 KiB of counters stays under 64 KiB; holds the densest buckets of a
+                                       // canonical 10^8-k-mer set at N = 14 (first base A: 7/4 of the average, 10 700 keys)
 constexpr int kMaxSubBits = 11;
 constexpr int kSortThreads = 1024;      // one workgroup per bucket (two fit a CU by LDS: 2048 threads)
 

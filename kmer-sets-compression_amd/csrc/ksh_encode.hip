@@ -2534,7 +2534,12 @@ struct EncPlan {
 inline size_t al(size_t x) { return (x + 255) & ~size_t(255); }
 
 constexpr int64_t kRcRowsMax = 512;          // workgroups (histogram rows) of the rc partition
-constexpr int64_t kRcWindowBytes = 60 << 10;  // LDS window of k_adj_rc (keys + marks + slice index)
+// LDS window of k_adj_rc (keys + marks + slice index): two workgroups share a CU's 160 KB.  At 10^8
+// k-mers and N = 14 the 16 ranges of the second pass hold 6 100 +- 80 keys together and a bucket
+// whose k-mers start with C 7 600 (canonical sets are 7 : 5 : 3 : 1 dense by first base): both fit
+// 7 980 keys; at 60 KB (6 137 keys) a third of the groups staged the second pass in two batches and
+// half of them the first, every record looked up once per batch (2.03 -> 1.76 ms per 10^8)
+constexpr int64_t kRcWindowBytes = 78 << 10;
 
 // KSH_ADJACENCY=probe selects the round-1 kernel (every probe a search in global memory) for
 // A/B measurements; anything else: the LDS-staged form.
@@ -2704,6 +2709,19 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       int64_t* pb = static_cast<int64_t*>(arena_alloc(ctx, size_t(nb) * 2 * kRcSegs * 8));
       if (!pb) return fail(KSH_INTERNAL, "scratch arena too small");
       hipLaunchKernelGGL((k_rc_bounds<KeyT>), dim3(nblk(nb * 2 * kRcSegs)), dim3(256), 0, st, set, nbits, pb);
+      {
+        // (more than the 64 KB a kernel gets without asking)
+        static const bool raised = [] {
+          const int bytes = int(kRcWindowBytes + 2048);
+          return hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc<KeyT, 1024>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+                 hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc<KeyT, 256>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
+                 hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc<KeyT, 64>),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
+        }();
+        if (!raised) return fail(KSH_INTERNAL, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+      }
       if (n / nb > 2048)
         hipLaunchKernelGGL((k_adj_rc<KeyT, 1024>), dim3(unsigned(nb)), dim3(1024), rc_lds, st, set, nbits, goff,
                            rec, pb, cap, rc0, rc1);

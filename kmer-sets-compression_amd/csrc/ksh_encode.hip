@@ -227,18 +227,37 @@ __global__ __launch_bounds__(1024) void k_rc_hist(const KeyT* __restrict__ keys,
 }
 
 // One thread per group: exclusive running sum down the workgroups' rows; totals[G] = column sum.
-__global__ __launch_bounds__(256) void k_rc_columns(uint32_t* __restrict__ hist_matrix, int64_t n_rows, int nb,
-                                                     int64_t* __restrict__ totals) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= nb) return;
+// (A workgroup takes 64 groups; its 16 teams of 64 threads take a sixteenth of the rows each: the
+// running sum down a column is 1/16 as long a chain of dependent reads, stitched through LDS.)
+constexpr int kColTeams = 16;
+__global__ __launch_bounds__(64 * kColTeams) void k_rc_columns(uint32_t* __restrict__ hist_matrix, int64_t n_rows,
+                                                                int nb, int64_t* __restrict__ totals) {
+  __shared__ uint32_t team_total[kColTeams][64];
+  const int lane = threadIdx.x & 63, team = threadIdx.x >> 6;
+  const int b = blockIdx.x * 64 + lane;
+  const int64_t per_team = (n_rows + kColTeams - 1) / kColTeams;
+  const int64_t g0 = min(int64_t(team) * per_team, n_rows), g1 = min(g0 + per_team, n_rows);
   uint32_t run = 0;
-  for (int64_t g = 0; g < n_rows; g++) {
+  if (b < nb)
+    for (int64_t g = g0; g < g1; g++) run += hist_matrix[g * nb + b];
+  team_total[team][lane] = run;
+  __syncthreads();
+  if (b >= nb) return;
+  uint32_t before = 0, all = 0;
+#pragma unroll
+  for (int t2 = 0; t2 < kColTeams; t2++) {
+    const uint32_t v = team_total[t2][lane];
+    if (t2 < team) before += v;
+    all += v;
+  }
+  run = before;
+  for (int64_t g = g0; g < g1; g++) {
     uint32_t* cell = hist_matrix + g * nb + b;
     const uint32_t c = *cell;
     *cell = run;
     run += c;
   }
-  totals[b] = run;
+  if (team == 0) totals[b] = all;
 }
 
 // hist_matrix holds each row's exclusive base inside a group, goff the groups' starts.
@@ -2664,7 +2683,8 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       // E1b: partition by rc-prefix, LDS-staged probe of the reverse-complement half, forward half
       // in place.  The records live in the (still unused) chain-rank records, rc0 / rc1 in the link
       // array; the records are reset by k_link_cut afterwards.
-      const int64_t rows = std::max<int64_t>(1, std::min<int64_t>(kRcRowsMax, (n + 65535) / 65536));
+      // (a row per 16K k-mers up to the cap: a 10^7-k-mer set still puts a workgroup on every CU)
+      const int64_t rows = std::max<int64_t>(1, std::min<int64_t>(kRcRowsMax, (n + 16383) / 16384));
       const int64_t per_row = ((n + rows - 1) / rows + 1023) / 1024 * 1024;
       uint32_t* hist = static_cast<uint32_t*>(arena_alloc(ctx, size_t(rows) * nb * 4));
       int64_t* totals = static_cast<int64_t*>(arena_alloc(ctx, size_t(nb + 1) * 8));
@@ -2676,7 +2696,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       const size_t hist_lds = size_t(nb) * 4;
       hipLaunchKernelGGL((k_rc_hist<KeyT>), dim3(unsigned(rows)), dim3(1024), hist_lds, st,
                          static_cast<const KeyT*>(sv->d_keys), n, g->k, key_bits(g), nbits, per_row, hist);
-      hipLaunchKernelGGL(k_rc_columns, dim3(unsigned((nb + 255) / 256)), dim3(256), 0, st, hist, rows, int(nb),
+      hipLaunchKernelGGL(k_rc_columns, dim3(unsigned((nb + 63) / 64)), dim3(64 * kColTeams), 0, st, hist, rows, int(nb),
                          totals);
       KSH_TRY(scan_exclusive_i64(ctx, totals, goff, nb, goff + nb));
       static const bool one_level = [] {

@@ -30,8 +30,11 @@ namespace ksh {
 
 constexpr int kDecThreads = 256;
 constexpr int kMaxLdsBuckets = 16384;   // 64 KiB of u32 counters
-constexpr int kSortLdsBytes = 45056;   // + 2 x 8 KiB of counters stays under 64 KiB; holds the densest buckets of a
-                                       // canonical 10^8-k-mer set at N = 14 (first base A: 7/4 of the average, 10 700 keys)
+// LDS window of the bucket sort; with 2 x 8 KiB of counters two workgroups share a CU's 160 KB.  It holds
+// the densest buckets of a canonical 10^8-k-mer set at N = 14 with 4-byte keys (first base A: 7/4 of
+// the average, 10 700 keys) and all but those with 8-byte keys (7 936 keys: at 44 KB = 5 632 keys every
+// bucket of a k = 31 set took the partition-first path for oversize buckets)
+constexpr int kSortLdsBytes = 63488;
 constexpr int kMaxSubBits = 11;
 constexpr int kSortThreads = 1024;      // one workgroup per bucket (two fit a CU by LDS: 2048 threads)
 
@@ -311,7 +314,7 @@ __device__ int block_unique_write(const KeyT* __restrict__ lds, int cnt, KeyT* _
 // set put 30 k keys in a bucket) is first partitioned by its top key bits into `scratch`
 // (same index range as `keys`), then every part is sorted in LDS and written back in order.
 template <typename KeyT>
-__global__ __launch_bounds__(kSortThreads) void k_bucket_sort(const int64_t* __restrict__ offsets,
+__global__ __launch_bounds__(kSortThreads, 8) void k_bucket_sort(const int64_t* __restrict__ offsets,
                                                       KeyT* __restrict__ keys,
                                                       KeyT* __restrict__ scratch,
                                                       int64_t* __restrict__ uniq, int key_bits,
@@ -581,6 +584,13 @@ int decode_write_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int 
   int64_t* new_off = static_cast<int64_t*>(arena_alloc(ctx, size_t(nb + 1) * 8));
   int64_t* below = static_cast<int64_t*>(arena_alloc(ctx, size_t(nb + 1) * 8));
   if (!new_off || !below) return fail(KSH_INTERNAL, "scratch arena too small");
+  {
+    // (more than the 64 KB a kernel gets without asking)
+    static const bool raised =
+        hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_sort<KeyT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, kSortLdsBytes) == hipSuccess;
+    if (!raised) return fail(KSH_INTERNAL, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+  }
   hipLaunchKernelGGL((k_bucket_sort<KeyT>), dim3(unsigned(nb)), dim3(kSortThreads), kSortLdsBytes, ctx->stream,
                      d_offsets, keys, scratch, st.totals, key_bits(g), cutoff, n_below ? below : nullptr);
   if (scratch) pool_free(ctx, scratch);

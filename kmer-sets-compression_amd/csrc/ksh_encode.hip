@@ -519,7 +519,7 @@ struct RcBatch {
 // stages, indexes and stores range w.  kRcThreads follows the group size (1024 for the 6 000-key
 // groups of a 10^8-k-mer set, 256 or 64 for small sets: a workgroup's fixed cost is its barriers).
 template <typename KeyT, int kRcThreads>
-__global__ __launch_bounds__(kRcThreads) void k_adj_rc(DevSet<KeyT> set, int nbits,
+__global__ __launch_bounds__(kRcThreads, (kRcThreads >= 128 ? kRcThreads / 128 : 1)) void k_adj_rc(DevSet<KeyT> set, int nbits,
                                                         const int64_t* __restrict__ goff,
                                                         const RcRecord<KeyT>* __restrict__ rec,
                                                         const int64_t* __restrict__ pb, int cap,

@@ -28,7 +28,7 @@
 
 namespace ksh {
 
-constexpr int kDecThreads = 256;
+constexpr int kDecThreads = 1024;       // (two workgroups per CU by their 64 KB histograms: 2048 threads)
 constexpr int kMaxLdsBuckets = 16384;   // 64 KiB of u32 counters
 // LDS window of the bucket sort; with 2 x 8 KiB of counters two workgroups share a CU's 160 KB.  It holds
 // the densest buckets of a canonical 10^8-k-mer set at N = 14 with 4-byte keys (first base A: 7/4 of
@@ -126,20 +126,39 @@ __global__ __launch_bounds__(kDecThreads) void k_decode(
   }
 }
 
-// One thread per bucket: exclusive running sum down the groups; totals[b] = column sum.
-__global__ __launch_bounds__(256) void k_hist_columns(uint32_t* __restrict__ hist_matrix,
-                                                       int64_t n_groups, int n_buckets,
-                                                       int64_t* __restrict__ totals) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= n_buckets) return;
+// Exclusive running sum down the groups, per bucket; totals[b] = column sum.  A workgroup takes 64
+// buckets, its 16 teams of 64 threads a sixteenth of the groups each, stitched through LDS (the chain
+// of dependent reads down a column is 1/16 as long).
+constexpr int kColTeams = 16;
+__global__ __launch_bounds__(64 * kColTeams) void k_hist_columns(uint32_t* __restrict__ hist_matrix,
+                                                                  int64_t n_groups, int n_buckets,
+                                                                  int64_t* __restrict__ totals) {
+  __shared__ uint32_t team_total[kColTeams][64];
+  const int lane = threadIdx.x & 63, team = threadIdx.x >> 6;
+  const int b = blockIdx.x * 64 + lane;
+  const int64_t per_team = (n_groups + kColTeams - 1) / kColTeams;
+  const int64_t g0 = min(int64_t(team) * per_team, n_groups), g1 = min(g0 + per_team, n_groups);
   uint32_t run = 0;
-  for (int64_t g = 0; g < n_groups; g++) {
+  if (b < n_buckets)
+    for (int64_t g = g0; g < g1; g++) run += hist_matrix[g * n_buckets + b];
+  team_total[team][lane] = run;
+  __syncthreads();
+  if (b >= n_buckets) return;
+  uint32_t before = 0, all = 0;
+#pragma unroll
+  for (int t2 = 0; t2 < kColTeams; t2++) {
+    const uint32_t v = team_total[t2][lane];
+    if (t2 < team) before += v;
+    all += v;
+  }
+  run = before;
+  for (int64_t g = g0; g < g1; g++) {
     uint32_t* cell = hist_matrix + g * n_buckets + b;
     const uint32_t c = *cell;
     *cell = run;
     run += c;
   }
-  totals[b] = run;
+  if (team == 0) totals[b] = all;
 }
 
 // ---- per-bucket sort --------------------------------------------------------------------------
@@ -522,7 +541,7 @@ int decode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int c
                      size_t(nb) * 4, ctx->stream, s->d_words, n_words, s->n_bases, st.end_bits,
                      n_end_words, g->k, key_bits(g), int(nb), canonical_flag, wpg, st.hist, nullptr,
                      static_cast<KeyT*>(nullptr));
-  hipLaunchKernelGGL(k_hist_columns, dim3(unsigned((nb + 255) / 256)), dim3(256), 0, ctx->stream,
+  hipLaunchKernelGGL(k_hist_columns, dim3(unsigned((nb + 63) / 64)), dim3(64 * kColTeams), 0, ctx->stream,
                      st.hist, groups, int(nb), st.totals);
   KSH_TRY(scan_exclusive_i64(ctx, st.totals, d_offsets, nb, d_offsets + nb));
   KSH_HIP(hipGetLastError());

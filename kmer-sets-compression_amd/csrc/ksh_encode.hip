@@ -14,12 +14,20 @@
 // i.e. through link[s ^ 1].  A side has a link when it has exactly one neighbour
 // whose facing side also has exactly one (spss.h:276-313).
 //
-//   k_adjacency   8 membership probes per k-mer (4 Next, 4 Prev, forward or reverse
-//                 complement) -> per side: none / the single neighbour / many
+//   neighbour probe: per side none / the single neighbour / many, from the 8 candidates of a k-mer
+//                 (4 Next, 4 Prev, forward or reverse complement).  Canonical sets: k_rc_* deal the
+//                 k-mers out by the bucket their reverse complement's successors lie in, k_adj_rc
+//                 marks the targets in an LDS window, k_adj_fwd_staged probes the forward half in
+//                 five LDS windows per 512 k-mers; k_adjacency: the same by searches in global
+//                 memory (non-canonical sets, geometries outside the staged kernels' range)
 //   k_link_cut    mutual singles: the k-mers with several neighbours on a side cut the facing entries
-//   k_ruler_*     chains of states ranked through a sparse ruler set: (end, distance to end)
-//   k_choose      per k-mer: the chain that starts at the larger end (spss.h:511,555)
-//   k_loops       non-branching loops, spelled from their smallest k-mer (spss.h:585-610)
+//   k_end_*       the end k-mers (a side without a link), compacted once
+//   k_rank_walk / k_rank_heads / k_ruler_jump / k_l2_*   chains of states ranked through a sparse ruler
+//                 set: every ruler and chain start learns (end, distance to end); no per-k-mer records
+//   k_choose_ends per end k-mer: the chain that starts at the larger end (spss.h:511,555) -> the
+//                 unitigs' heads, lengths, last states
+//   k_ruler_walk / k_ruler_heads / k_choose / k_loops / k_emit   the same with a record per k-mer:
+//                 sets with a non-branching loop (spelled from its smallest k-mer, spss.h:585-610)
 //   k_head_counts / scans / k_unitig_fill   unitig ids in the reference's push order
 //   k_edges       <= 4 edges per unitig side, in the reference's enumeration order
 //   k_match_*     lexicographically-first maximal matching by rounds of mutual minima
@@ -28,7 +36,7 @@
 //                 where the reference's union-by-rank root says (spss.h:1541-1647)
 //   k_walk_* / k_string_*    walks over the path cover ranked by pointer jumping; stitch order and
 //                 orientation (spss.h:1649-1829)
-//   k_emit / k_pack   bases -> 2-bit words, len - K per string
+//   k_emit_log_* / k_pack   the strings' bases from the logs of the ranking walks -> 2-bit words, len - K per string
 //
 // All of it is integer gather/scatter work bounded by HBM random-access rate; no MFMA.
 #include "ksh_internal.h"

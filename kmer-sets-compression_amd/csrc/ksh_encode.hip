@@ -86,6 +86,15 @@ __global__ __launch_bounds__(256) void k_fine_index(const int64_t* __restrict__ 
   if (b == n_buckets - 1 && threadIdx.x == 0) fine[n_buckets << fine_bits] = uint32_t(hi);
 }
 
+// DevSet::coarse: the bucket of every 256th index.
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_coarse_index(DevSet<KeyT> set, int64_t n_entries, uint32_t* __restrict__ coarse) {
+  const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (e >= n_entries) return;
+  const int64_t t = e << kCoarseShift;
+  coarse[e] = uint32_t(set.bucket_search(t < set.n ? t : set.n - 1));
+}
+
 // The neighbours of one side of k-mer x (index t, rx = rc(x)): f(index, same) for each, where
 // same = 1 when the edge joins the same side of both k-mers (the neighbour is reached through a
 // reverse complement).
@@ -2537,6 +2546,7 @@ struct EncPlan {
   int64_t *c01 = nullptr, *c23 = nullptr;
   uint32_t* fine = nullptr;
   int fine_bits = 0;
+  uint32_t* coarse = nullptr;  // DevSet::coarse (sets of at least four k-mers per bucket)
   // unitig level (own allocation)
   char* ublock = nullptr;
   uint32_t *u_head = nullptr, *u_first = nullptr, *u_last = nullptr, *u_len = nullptr,
@@ -2646,7 +2656,8 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   const bool use_fine = fine_bits >= 2;
   const size_t fine_entries = use_fine ? (size_t(nb) << fine_bits) + 1 : 0;
   const size_t bytes = 2 * al(size_t(2 * n) * 4) + al(size_t(2 * n) * 8) + 5 * al(size_t(n) * 4) +
-                       2 * al(size_t(n)) + 2 * al(size_t(n) * 8) + al(fine_entries * 4) + 4096;
+                       2 * al(size_t(n)) + 2 * al(size_t(n) * 8) + al(fine_entries * 4) +
+                       al(size_t((n >> kCoarseShift) + 2) * 4) + 4096;
   KSH_TRY(slot_reserve(ctx, kSlotEncode, bytes));
   KSH_TRY(arena_reserve(ctx, size_t(n / 256 + 4096) * 8 * 2 + (1u << 16) + size_t(n / kHeadSpan + 64) * 8 +
                                  (nb <= (1 << 14) ? size_t(kRcRowsMax) * nb * 4 + size_t(nb + 1) * 16 + size_t(nb) * 260 + 8192 : 0)));
@@ -2665,6 +2676,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   p->c01 = carve<int64_t>(at, size_t(2 * n));  // two arrays of n, one block: later the place records
   p->c23 = p->c01 + n;
   p->fine = use_fine ? carve<uint32_t>(at, fine_entries) : nullptr;
+  p->coarse = n >= 4 * nb ? carve<uint32_t>(at, size_t((n >> kCoarseShift) + 2)) : nullptr;
 
   DevSet<KeyT> set{sv->d_offsets, static_cast<const KeyT*>(sv->d_keys), nb, n, g->k, key_bits(g)};
   hipStream_t st = ctx->stream;
@@ -2674,6 +2686,11 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     set.fine = p->fine;
     set.fine_bits = fine_bits;
     p->fine_bits = fine_bits;
+  }
+  if (p->coarse) {
+    const int64_t n_entries = (n >> kCoarseShift) + 1;
+    hipLaunchKernelGGL((k_coarse_index<KeyT>), dim3(nblk(n_entries)), dim3(256), 0, st, set, n_entries, p->coarse);
+    set.coarse = p->coarse;
   }
   int* flags = static_cast<int*>(arena_alloc(ctx, 16));  // [0] pointer-jumping progress, [1] self_rc
   if (!flags) return fail(KSH_INTERNAL, "scratch arena too small");
@@ -3056,6 +3073,7 @@ int encode_write_t(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens) {
                    key_bits(g)};
   set.fine = p->fine;
   set.fine_bits = p->fine_bits;
+  set.coarse = p->coarse;
   hipStream_t st = ctx->stream;
   // byte staging aliases the array the staged neighbour probe kept its partial results in (dead
   // since then; 2n * 4 bytes >= n_bases needs checking)

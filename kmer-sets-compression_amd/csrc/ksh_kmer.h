@@ -35,6 +35,8 @@ __device__ __forceinline__ uint64_t kmer_prev(uint64_t x, int k, int c) {
   return (x >> 2) | (uint64_t(c) << (2 * (k - 1)));
 }
 
+constexpr int kCoarseShift = 8;
+
 // A resident set seen from a kernel.
 template <typename KeyT>
 struct DevSet {
@@ -52,6 +54,10 @@ struct DevSet {
   // wide (fine_bits <= key_bits - 2).
   const uint32_t* fine = nullptr;
   int fine_bits = 0;
+  // Optional coarse inverse of `off`: coarse[t >> kCoarseShift] = bucket of index (t >> kCoarseShift)
+  // << kCoarseShift, so that the bucket of an arbitrary index is one table read and a step or two
+  // along `off` instead of a binary search over it (kmer(t) for indices that come out of walks).
+  const uint32_t* coarse = nullptr;
 
   __device__ __forceinline__ uint64_t key_mask() const {
     return key_bits == 64 ? ~uint64_t(0) : ((uint64_t(1) << key_bits) - 1);
@@ -138,6 +144,14 @@ struct DevSet {
 
   // Bucket holding index t (largest b with off[b] <= t).
   __device__ int64_t bucket_of(int64_t t) const {
+    if (coarse) {
+      int64_t b = coarse[t >> kCoarseShift];
+      while (off[b + 1] <= t) b++;
+      return b;
+    }
+    return bucket_search(t);
+  }
+  __device__ int64_t bucket_search(int64_t t) const {
     int64_t lo = 0, hi = n_buckets;
     while (lo < hi) {
       const int64_t mid = (lo + hi) >> 1;

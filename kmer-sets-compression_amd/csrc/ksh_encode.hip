@@ -486,7 +486,8 @@ __device__ int64_t lower_bound_kmer(const DevSet<KeyT>& set, uint64_t value) {
   const int64_t b = int64_t(value >> set.key_bits);
   if (b >= set.n_buckets) return set.n;
   const KeyT key = KeyT(value & set.key_mask());
-  int64_t lo = set.off[b], hi = set.off[b + 1];
+  int64_t lo, hi;
+  set.probe_range(b, key, &lo, &hi);  // the key's slice of the fine index (the first key >= it lies in it or right after it)
   while (lo < hi) {
     const int64_t mid = (lo + hi) >> 1;
     if (set.keys[mid] < key) lo = mid + 1; else hi = mid;

@@ -1282,14 +1282,18 @@ __device__ __forceinline__ int64_t level2_entry(int64_t j) { return ((j >> 1) <<
 //   r2[j]    (level-2 ruler j): end:1 | dist:31 | ref:32 -- the next level-2 ruler (record index) or the end state
 //   head[i]  (chain head i, not level 2): the same
 //   stamp[e] (everything they pass): dist:32 | walker record:32
+// (two launches: the level-2 rulers, one thread each -- they are every 32nd pair of records and all of
+// them walk some 32 steps -- and the chain heads, found by a thread per record)
+template <bool kLevel2>
 __global__ __launch_bounds__(256) void k_l2_walk(const unsigned long long* __restrict__ rinfo, int64_t n_dense,
                                                   unsigned long long* __restrict__ r2,
                                                   unsigned long long* __restrict__ head,
                                                   unsigned long long* __restrict__ stamp) {
-  const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t at = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t i = kLevel2 ? level2_entry(at) : at;
   if (i >= n_dense) return;
-  const bool l2 = is_level2(i);
-  if (!l2 && !(rinfo[i ^ 1] & kEndFlag)) return;  // something comes before it: that walker passes it
+  const bool l2 = kLevel2;
+  if (!kLevel2 && (is_level2(i) || !(rinfo[i ^ 1] & kEndFlag))) return;  // level 2, or something comes before it: that walker passes it
   uint64_t dist = 0;
   int64_t cur = i;
   uint64_t out;
@@ -2889,7 +2893,8 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     if (two_levels) {
       KSH_HIP(hipMemsetAsync(l2_head, 0xFF, size_t(n_dense) * 8, st));
       KSH_HIP(hipMemsetAsync(l2_stamp, 0xFF, size_t(n_dense) * 8, st));
-      hipLaunchKernelGGL(k_l2_walk, dim3(nblk(n_dense)), dim3(256), 0, st, rinfo, n_dense, r2, l2_head, l2_stamp);
+      hipLaunchKernelGGL(k_l2_walk<true>, dim3(nblk(n_jump)), dim3(256), 0, st, rinfo, n_dense, r2, l2_head, l2_stamp);
+      hipLaunchKernelGGL(k_l2_walk<false>, dim3(nblk(n_dense)), dim3(256), 0, st, rinfo, n_dense, r2, l2_head, l2_stamp);
     }
     int max_rounds = 2;
     for (int64_t x = n_jump; x > 1; x >>= 1) max_rounds++;

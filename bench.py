@@ -21,15 +21,18 @@ samples, a merge and the encodes of its results run on the rank that owns the no
 device buffers.
 
 Prints ONE JSON line on rank 0.
-  roofline     the loop's dominant kernel (k_adjacency, the neighbour probe of the SPSS encode):
+  roofline     the loop's dominant stage, the neighbour probe of the SPSS encode (the rc partition,
+               k_adj_rc and k_adj_fwd_staged; one timed "launch" = the stage of one encode):
                algorithmic bytes = 5.3 B per k-mer (read key + write adjacency byte
                + packed bases) x the k-mers of a launch, over its HIP-event duration on the
                context's stream, against the 8 TB/s HBM peak; the probe-inclusive figure
                (36 B per k-mer: the key + 8 neighbour lookups) is reported beside it; `traffic`
                from profiles/pmc_adjacency.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes).
-  cpu_baseline the oracle's port of the same loop (first I iterations of a reduced family, same
-               N_proc on both sides), bucket-parallel threads as the reference has them, at
-               n_workers = all host cores and at 1 (rank 0, N = 1 only).
+  cpu_baseline the oracle's port of the same loop, compiled on this host with the reference's release
+               flags (-O3 -march=native -DNDEBUG), bucket-parallel threads as the reference has
+               them: the first I iterations of a 16 x 10^7 family at n_workers = all host cores,
+               the GPU timed on the SAME sample beside it (same I, same N_proc, merge sequence
+               compared); a smaller sample at 1 worker (rank 0, N = 1 only).
   pair_merge   the pair-algebra kernel on configs[1] (4 x 10^7), the round-1 headline, as an
                extra block.
 """
@@ -99,7 +102,8 @@ def main():
                     help="skip the Size / XOR-Hash check of every Get(i) after the timed builds")
     ap.add_argument("--no-pair-merge", action="store_true", help="skip the configs[1] pair-algebra block")
     ap.add_argument("--cpu-sets", type=int, default=16)
-    ap.add_argument("--cpu-size", type=float, default=2e6)
+    ap.add_argument("--cpu-size", type=float, default=1e7, help="k-mers per set of the all-cores CPU sample")
+    ap.add_argument("--cpu-size-1", type=float, default=2e6, help="k-mers per set of the 1-worker CPU sample")
     ap.add_argument("--cpu-iterations", type=int, default=4)
     ap.add_argument("--cpu-workers", type=int, default=0, help="0 = all host cores")
     ap.add_argument("--dump-trace", default="",
@@ -321,39 +325,71 @@ def main():
     # ---- CPU baseline: the oracle's port of the loop, threads as the reference has them
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        # the copy that is timed is compiled here, on the host it runs on, with the reference's release
+        # flags (CMakeLists.txt:5); the portable build the tests load is the fall-back
+        import subprocess
+        import tempfile
+
+        native = os.path.join(tempfile.mkdtemp(prefix="ksh_oracle_"), "libkmersets_oracle_native.so")
+        oracle_build = "-O3 -march=native -DNDEBUG (compiled on this host)"
+        try:
+            subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "native", "NATIVE_OUT=" + native],
+                           check=True, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+            os.environ["KSH_ORACLE_LIB"] = native
+        except Exception:  # noqa: BLE001 -- no compiler on this host: the prebuilt portable copy
+            oracle_build = "-O3 (prebuilt portable copy: the native build failed)"
         import oracle_lib as ol
 
-        cs, csize, ci = args.cpu_sets, int(args.cpu_size), args.cpu_iterations
+        cs, ci = args.cpu_sets, args.cpu_iterations
         # the reference posts n_workers^2 chunks per parallel step, each with its own 2^N key buffers
         # (spss.h:1896-1901): beyond a few dozen workers the chunk set-up dominates, so the "all cores"
         # run is capped at 32 workers (measured on the 256-thread host: 256 workers are 27x SLOWER than 1)
         cores = args.cpu_workers or min(host_cores(), 32)
-        host = synth.phylogeny_sets(k, cs, csize, seed=args.seed)
-        oc = [ol.Set.from_kmers(k, nbits, g.key_bytes, s).compact() for s in host]
-        runs = {}
-        for w in (cores, 1):
+
+        def sample(csize, workers):
+            """The same family at `csize` k-mers per set: the oracle's loop at `workers`, then the GPU's
+            (one untimed build, one timed) on the same containers; both stop after `ci` iterations."""
+            km = synth_torch.phylogeny_sets(k, cs, csize, args.seed, dev)
+            gc = [ctx.spss_encode(synth_torch.device_set(g, x), mode=0) for x in km]
+            del km
+            oc = [ol.Compact.from_strings(c.to_strings(), k, nbits, g.key_bytes) for c in gc]
             c0 = time.perf_counter()
-            okss = ol.KmerSetSet(oc, ids, max_iterations=ci, n_workers=w)
+            okss = ol.KmerSetSet(oc, ids, max_iterations=ci, n_workers=workers)
             cw = time.perf_counter() - c0
-            runs[w] = (okss.stat(3) / cw / 1e6, cw, okss.stat(3), [tuple(r[:5]) for r in okss.iterations()])
-            del okss
-        # the GPU on the same sample: same merges, same N_proc
-        gc = [ctx.spss_encode(capi.DeviceSet.from_kmers(g, s, dev), mode=0) for s in host]
-        gk = capi.DeviceKmerSetSet(ctx, gc, ids, max_iterations=ci)
-        g_it = [tuple(int(x) for x in r) for r in gk.trace()[0]]
-        same = all(g_it == runs[w][3] and gk.stats()["n_processed"] == runs[w][2] for w in runs)
-        gk.close()
-        if not same:
-            raise SystemExit("CPU baseline sample: the oracle's merge sequence differs from the GPU's")
+            o_proc, o_it = okss.stat(3), [tuple(r[:5]) for r in okss.iterations()]
+            del okss, oc
+            capi.DeviceKmerSetSet(ctx, gc, ids, max_iterations=ci).close()
+            torch.cuda.synchronize()
+            g0 = time.perf_counter()
+            gk = capi.DeviceKmerSetSet(ctx, gc, ids, max_iterations=ci)
+            torch.cuda.synchronize()
+            gw = time.perf_counter() - g0
+            g_it = [tuple(int(x) for x in r) for r in gk.trace()[0]]
+            same = g_it == o_it and gk.stats()["n_processed"] == o_proc
+            gk.close()
+            if not same:
+                raise SystemExit("CPU baseline sample: the oracle's merge sequence differs from the GPU's")
+            return {"n_processed": o_proc, "cpu_s": cw, "gpu_s": gw, "cpu_mkmers_per_s": o_proc / cw / 1e6,
+                    "gpu_mkmers_per_s": o_proc / gw / 1e6, "size": csize, "workers": workers}
+
+        big = sample(int(args.cpu_size), cores)
+        one = sample(int(args.cpu_size_1), 1)
         cpu_baseline = {
-            "value": runs[cores][0], "unit": "Mk-mers/s", "cores": cores, "kind": "port",
-            "cpu": cpu_model(), "host_cores_available": host_cores(),
-            "value_1_core": runs[1][0],
+            "value": big["cpu_mkmers_per_s"], "unit": "Mk-mers/s", "cores": cores, "kind": "port",
+            "cpu": cpu_model(), "host_cores_available": host_cores(), "oracle_build": oracle_build,
             "sample": "oracle KmerSetSet (C++ port of lib/core/kmer_set_set.h:109-427 with the reference's "
                       "bucket-parallel / pooled structure), %d sets of %d k-mers of the same family, first %d "
-                      "iterations, N_proc = %d on both sides; %.1f s at %d workers, %.1f s at 1"
-                      % (cs, csize, ci, runs[cores][2], runs[cores][1], cores, runs[1][1]),
-            "checked": "merge sequence (j, k, weight, sizes) and N_proc of the sample: GPU == oracle",
+                      "iterations, N_proc = %d; %.1f s at %d workers"
+                      % (cs, big["size"], ci, big["n_processed"], big["cpu_s"], cores),
+            "gpu_same_sample": {"value": big["gpu_mkmers_per_s"], "seconds": big["gpu_s"],
+                                "speedup_vs_cpu": big["cpu_s"] / big["gpu_s"],
+                                "note": "the same containers, the same %d iterations, the same N_proc, one GPU build "
+                                        "(after one untimed build)" % ci},
+            "value_1_core": one["cpu_mkmers_per_s"],
+            "sample_1_core": "%d sets of %d k-mers, first %d iterations, N_proc = %d; %.1f s at 1 worker; the GPU "
+                             "on the same sample: %.1f Mk-mers/s" % (cs, one["size"], ci, one["n_processed"],
+                                                                      one["cpu_s"], one["gpu_mkmers_per_s"]),
+            "checked": "merge sequence (j, k, weight, sizes) and N_proc of both samples: GPU == oracle",
         }
 
     traffic, traffic_src = None, None

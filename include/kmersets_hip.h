@@ -75,6 +75,13 @@ int ksh_free(int device, void* d_ptr);
 int ksh_memcpy_h2d(int device, void* d_dst, const void* src, size_t bytes);
 int ksh_memcpy_d2h(int device, void* dst, const void* d_src, size_t bytes);
 int ksh_memcpy_d2d(int device, void* d_dst, const void* d_src, size_t bytes);
+/* The same copies ordered after ONE context's stream only (the work of other contexts goes on): for
+ * a host thread with a context of its own and buffers it produced itself or received complete --
+ * the per-node writer threads of KmerSetSet::Dump (lib/core/kmer_set_set.h:497-519), the rank threads
+ * of a rehearsal. */
+int ksh_ctx_memcpy_h2d(ksh_ctx* ctx, void* d_dst, const void* src, size_t bytes);
+int ksh_ctx_memcpy_d2h(ksh_ctx* ctx, void* dst, const void* d_src, size_t bytes);
+int ksh_ctx_memcpy_d2d(ksh_ctx* ctx, void* d_dst, const void* d_src, size_t bytes);
 
 /* A context = one GPU + one HIP stream + a scratch arena.  `stream` may be an
  * existing hipStream_t (e.g. torch's current stream) or NULL for a new one.

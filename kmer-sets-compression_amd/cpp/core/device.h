@@ -1,5 +1,6 @@
 // Host-side plumbing over the C ABI: a per-thread context and RAII device buffers.
-// No HIP headers here: device memory goes through ksh_malloc / ksh_memcpy_*.
+// No HIP headers here: device memory goes through ksh_malloc / ksh_ctx_memcpy_* (copies ordered after
+// the calling thread's own context: the writer threads of KmerSetSet::Dump do not wait for each other).
 #ifndef KSC_CORE_DEVICE_H_
 #define KSC_CORE_DEVICE_H_
 
@@ -43,7 +44,7 @@ class DeviceBuffer {
     Check(ksh_malloc(DeviceIndex(), bytes ? bytes : 16, &ptr_));
   }
   DeviceBuffer(const DeviceBuffer& o) : DeviceBuffer(o.bytes_) {
-    if (bytes_) Check(ksh_memcpy_d2d(DeviceIndex(), ptr_, o.ptr_, bytes_));
+    if (bytes_) Check(ksh_ctx_memcpy_d2d(Ctx(), ptr_, o.ptr_, bytes_));
   }
   DeviceBuffer(DeviceBuffer&& o) noexcept : ptr_(o.ptr_), bytes_(o.bytes_) {
     o.ptr_ = nullptr;
@@ -64,14 +65,14 @@ class DeviceBuffer {
   template <typename T>
   static DeviceBuffer FromHost(const std::vector<T>& v) {
     DeviceBuffer b(v.size() * sizeof(T));
-    if (!v.empty()) Check(ksh_memcpy_h2d(DeviceIndex(), b.ptr_, v.data(), v.size() * sizeof(T)));
+    if (!v.empty()) Check(ksh_ctx_memcpy_h2d(Ctx(), b.ptr_, v.data(), v.size() * sizeof(T)));
     return b;
   }
 
   template <typename T>
   std::vector<T> ToHost(std::size_t count) const {
     std::vector<T> v(count);
-    if (count) Check(ksh_memcpy_d2h(DeviceIndex(), v.data(), ptr_, count * sizeof(T)));
+    if (count) Check(ksh_ctx_memcpy_d2h(Ctx(), v.data(), ptr_, count * sizeof(T)));
     return v;
   }
 

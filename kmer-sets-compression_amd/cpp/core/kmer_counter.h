@@ -68,7 +68,7 @@ class KmerCounter {
     std::int64_t n_frag = 0, n_bases = 0;
     ksc::DeviceBuffer d_text(c.fasta_.size());
     if (!c.fasta_.empty())
-      ksc::Check(ksh_memcpy_h2d(ksc::DeviceIndex(), d_text.get(), c.fasta_.data(), c.fasta_.size()));
+      ksc::Check(ksh_ctx_memcpy_h2d(ksc::Ctx(), d_text.get(), c.fasta_.data(), c.fasta_.size()));
     const int rc = ksh_fasta_plan(ksc::Ctx(), &g, static_cast<const char*>(d_text.get()),
                                   static_cast<std::int64_t>(c.fasta_.size()), &n_frag, &n_bases);
     if (rc == KSH_FAILED_PRECONDITION) return ksc::FailedPreconditionError(ksh_last_error());
@@ -82,7 +82,7 @@ class KmerCounter {
     ksc::DeviceBuffer off(std::size_t(Set::kBucketsNum + 1) * 8);
     std::int64_t n_frag = 0, n_bases = 0;
     ksc::DeviceBuffer d_text(fasta_.size());
-    if (!fasta_.empty()) ksc::Check(ksh_memcpy_h2d(ksc::DeviceIndex(), d_text.get(), fasta_.data(), fasta_.size()));
+    if (!fasta_.empty()) ksc::Check(ksh_ctx_memcpy_h2d(ksc::Ctx(), d_text.get(), fasta_.data(), fasta_.size()));
     ksc::Check(ksh_fasta_plan(ksc::Ctx(), &g, static_cast<const char*>(d_text.get()),
                               static_cast<std::int64_t>(fasta_.size()), &n_frag, &n_bases));
     ksc::DeviceBuffer words(std::size_t((n_bases + 31) / 32) * 8), lens(std::size_t(n_frag) * 4);

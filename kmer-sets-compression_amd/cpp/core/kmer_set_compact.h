@@ -123,7 +123,7 @@ class KmerSetCompact {
     ksc::DeviceBuffer d_text(text.size());
     ksc::Check(ksh_spss_to_text(ksc::Ctx(), &g, &v, static_cast<char*>(d_text.get())));
     ksc::Check(ksh_ctx_sync(ksc::Ctx()));
-    ksc::Check(ksh_memcpy_d2h(ksc::DeviceIndex(), &text[0], d_text.get(), text.size()));
+    ksc::Check(ksh_ctx_memcpy_d2h(ksc::Ctx(), &text[0], d_text.get(), text.size()));
     return text;
   }
 
@@ -132,7 +132,7 @@ class KmerSetCompact {
     if (text.empty()) return c;
     const ksh_geom g = Set::Geom();
     ksc::DeviceBuffer d_text(text.size());
-    ksc::Check(ksh_memcpy_h2d(ksc::DeviceIndex(), d_text.get(), text.data(), text.size()));
+    ksc::Check(ksh_ctx_memcpy_h2d(ksc::Ctx(), d_text.get(), text.data(), text.size()));
     ksc::Check(ksh_spss_from_text_plan(ksc::Ctx(), &g, static_cast<const char*>(d_text.get()),
                                        static_cast<std::int64_t>(text.size()), &c.n_, &c.n_bases_));
     c.words_ = ksc::DeviceBuffer(std::size_t((c.n_bases_ + 31) / 32) * 8);

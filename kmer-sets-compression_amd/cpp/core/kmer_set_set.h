@@ -117,7 +117,6 @@ class KmerSetSet {
                                max_iterations, &kss));
     std::int32_t n_nodes = 0;
     ksc::Check(ksh_kss_size(kss, &n_nodes));
-    const int dev = ksc::DeviceIndex();
     for (std::int32_t i = 0; i < n_nodes; i++) {
       ksh_spss_view v{nullptr, nullptr, 0, 0};
       std::int32_t holder = -1;
@@ -126,8 +125,8 @@ class KmerSetSet {
       my_rank_ = shard.rank;
       if (holder < 0 || holder == shard.rank) ksc::Check(ksh_kss_node(kss, i, &v, nullptr, nullptr));
       ksc::DeviceBuffer words(std::size_t((v.n_bases + 31) / 32) * 8), lens(std::size_t(v.n_strings) * 4);
-      if (v.n_bases) ksc::Check(ksh_memcpy_d2d(dev, words.get(), v.d_words, std::size_t((v.n_bases + 31) / 32) * 8));
-      if (v.n_strings) ksc::Check(ksh_memcpy_d2d(dev, lens.get(), v.d_lens, std::size_t(v.n_strings) * 4));
+      if (v.n_bases) ksc::Check(ksh_ctx_memcpy_d2d(ksc::Ctx(), words.get(), v.d_words, std::size_t((v.n_bases + 31) / 32) * 8));
+      if (v.n_strings) ksc::Check(ksh_ctx_memcpy_d2d(ksc::Ctx(), lens.get(), v.d_lens, std::size_t(v.n_strings) * 4));
       kmer_sets_compact_.push_back(Compact::FromDevice(std::move(words), std::move(lens), v.n_strings, v.n_bases));
       const std::int32_t* ch = nullptr;
       std::int32_t n_ch = 0;

@@ -393,9 +393,16 @@ __global__ __launch_bounds__(256) void k_dsu_reset(unsigned long long* __restric
   if (i < n) a[i] = (unsigned long long)i;
 }
 __global__ __launch_bounds__(256) void k_dsu_unite_pairs(DevDsu dsu, const int32_t* __restrict__ x,
-                                                          const int32_t* __restrict__ y, int64_t m) {
+                                                          const int32_t* __restrict__ y, int64_t m, int64_t n,
+                                                          int* __restrict__ bad) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i < m) dsu.unite(uint32_t(x[i]), uint32_t(y[i]));
+  if (i >= m) return;
+  const uint32_t a = uint32_t(x[i]), b = uint32_t(y[i]);
+  if (a >= uint64_t(n) || b >= uint64_t(n)) {  // (a negative id is a huge unsigned one)
+    *bad = 1;
+    return;
+  }
+  dsu.unite(a, b);
 }
 __global__ __launch_bounds__(256) void k_dsu_roots(DevDsu dsu, int64_t n, int32_t* __restrict__ root) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
@@ -469,6 +476,39 @@ int ksh_memcpy_d2d(int device, void* d_dst, const void* d_src, size_t bytes) {
   if (bytes) {
     KSH_HIP(hipDeviceSynchronize());  // whatever stream produced / still reads the buffer: a context's stream need not be a blocking one
     KSH_HIP(hipMemcpy(d_dst, d_src, bytes, hipMemcpyDeviceToDevice));
+  }
+  return KSH_OK;
+}
+
+// The same three copies ordered after ONE context's stream only (other contexts' work goes on):
+// what a host thread with a context of its own uses for buffers it produced itself, or that were
+// complete before they were handed to it.
+int ksh_ctx_memcpy_h2d(ksh_ctx* ctx, void* d_dst, const void* src, size_t bytes) {
+  if (!ctx) return fail(KSH_INVALID_ARGUMENT, "ctx is NULL");
+  KSH_HIP(hipSetDevice(ctx->device));
+  if (bytes) {
+    KSH_HIP(hipMemcpyAsync(d_dst, src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    KSH_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return KSH_OK;
+}
+
+int ksh_ctx_memcpy_d2h(ksh_ctx* ctx, void* dst, const void* d_src, size_t bytes) {
+  if (!ctx) return fail(KSH_INVALID_ARGUMENT, "ctx is NULL");
+  KSH_HIP(hipSetDevice(ctx->device));
+  if (bytes) {
+    KSH_HIP(hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    KSH_HIP(hipStreamSynchronize(ctx->stream));
+  }
+  return KSH_OK;
+}
+
+int ksh_ctx_memcpy_d2d(ksh_ctx* ctx, void* d_dst, const void* d_src, size_t bytes) {
+  if (!ctx) return fail(KSH_INVALID_ARGUMENT, "ctx is NULL");
+  KSH_HIP(hipSetDevice(ctx->device));
+  if (bytes) {
+    KSH_HIP(hipMemcpyAsync(d_dst, d_src, bytes, hipMemcpyDeviceToDevice, ctx->stream));
+    KSH_HIP(hipStreamSynchronize(ctx->stream));
   }
   return KSH_OK;
 }
@@ -592,13 +632,21 @@ int ksh_dsu_components(ksh_ctx* ctx, int64_t n, const int32_t* d_x, const int32_
   void* words = nullptr;
   KSH_TRY(pool_alloc(ctx, size_t(n) * 8, &words));
   DevDsu dsu{static_cast<unsigned long long*>(words)};
+  arena_reset(ctx);
+  int* d_bad = static_cast<int*>(arena_alloc(ctx, sizeof(int)));
+  if (!d_bad) return fail(KSH_INTERNAL, "scratch arena too small");
+  KSH_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
   hipLaunchKernelGGL(k_dsu_reset, dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, dsu.a, n);
   if (m > 0)
-    hipLaunchKernelGGL(k_dsu_unite_pairs, dim3(unsigned((m + 255) / 256)), dim3(256), 0, ctx->stream, dsu, d_x, d_y, m);
+    hipLaunchKernelGGL(k_dsu_unite_pairs, dim3(unsigned((m + 255) / 256)), dim3(256), 0, ctx->stream, dsu, d_x, d_y, m,
+                       n, d_bad);
   hipLaunchKernelGGL(k_dsu_roots, dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, dsu, n, d_root);
   KSH_HIP(hipGetLastError());
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
   KSH_HIP(hipStreamSynchronize(ctx->stream));
   pool_free(ctx, words);
+  if (*reinterpret_cast<int*>(ctx->h_pinned))
+    return fail(KSH_INVALID_ARGUMENT, "ksh_dsu_components: a pair names a node outside [0, n)");
   return KSH_OK;
 }
 

@@ -605,10 +605,12 @@ int decode_write_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int 
   if (!new_off || !below) return fail(KSH_INTERNAL, "scratch arena too small");
   {
     // (more than the 64 KB a kernel gets without asking)
-    static const bool raised =
-        hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_sort<KeyT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, kSortLdsBytes) == hipSuccess;
-    if (!raised) return fail(KSH_INTERNAL, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+    const uint32_t bit = sizeof(KeyT) == 4 ? 4u : 8u;
+    if (!(ctx->lds_opt_in & bit)) {
+      KSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_sort<KeyT>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, kSortLdsBytes));
+      ctx->lds_opt_in |= bit;
+    }
   }
   hipLaunchKernelGGL((k_bucket_sort<KeyT>), dim3(unsigned(nb)), dim3(kSortThreads), kSortLdsBytes, ctx->stream,
                      d_offsets, keys, scratch, st.totals, key_bits(g), cutoff, n_below ? below : nullptr);

@@ -2575,6 +2575,14 @@ struct EncPlan {
 
 inline size_t al(size_t x) { return (x + 255) & ~size_t(255); }
 
+// Host-side statement of what a kernel's indexing assumes about the scratch it borrows (carved arrays
+// that change hands between stages, LDS byte counts, packed 16-bit fields): checked before the launch.
+#define KSH_BOUND(cond)                                                                              \
+  do {                                                                                               \
+    if (!(cond)) return ::ksh::fail(KSH_INTERNAL, "encode: bound violated: %s (%s:%d)", #cond, __FILE__, __LINE__); \
+  } while (0)
+static_assert(sizeof(RcRecord<uint32_t>) == 8 && sizeof(RcRecord<uint64_t>) == 16, "record sizes the scratch layout assumes");
+
 constexpr int64_t kRcRowsMax = 512;          // workgroups (histogram rows) of the rc partition
 // LDS window of k_adj_rc (keys + marks + slice index): two workgroups share a CU's 160 KB.  At 10^8
 // k-mers and N = 14 the 16 ranges of the second pass hold 6 100 +- 80 keys together and a bucket
@@ -2716,6 +2724,8 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       // (a row per 16K k-mers up to the cap: a 10^7-k-mer set still puts a workgroup on every CU)
       const int64_t rows = std::max<int64_t>(1, std::min<int64_t>(kRcRowsMax, (n + 16383) / 16384));
       const int64_t per_row = ((n + rows - 1) / rows + 1023) / 1024 * 1024;
+      KSH_BOUND(rows >= 1 && rows <= kRcRowsMax && rows * per_row >= n);  // k_rc_hist / k_rc_scatter_*: row r owns [r * per_row, ...)
+      KSH_BOUND(size_t(n) * sizeof(RcRecord<KeyT>) <= al(size_t(2 * n) * 8));  // the records live in `info`
       uint32_t* hist = static_cast<uint32_t*>(arena_alloc(ctx, size_t(rows) * nb * 4));
       int64_t* totals = static_cast<int64_t*>(arena_alloc(ctx, size_t(nb + 1) * 8));
       int64_t* goff = static_cast<int64_t*>(arena_alloc(ctx, size_t(nb + 1) * 8));
@@ -2740,6 +2750,12 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
         // sit in the head array
         RcRecord<KeyT>* tmp_rec = sizeof(KeyT) == 4 ? rec + n : reinterpret_cast<RcRecord<KeyT>*>(p->nbr);
         uint16_t* tmp_g = reinterpret_cast<uint16_t*>(p->head);
+        // intermediate records: u32 keys, the upper half of `info` (2n records of 8 bytes in 16n bytes);
+        // u64 keys, nbr + link (carved back to back: 2 x al(8n) >= 16n); group ids in `head` (2n <= 4n bytes)
+        KSH_BOUND(sizeof(KeyT) == 4 ? size_t(2 * n) * sizeof(RcRecord<KeyT>) <= al(size_t(2 * n) * 8)
+                                    : reinterpret_cast<char*>(p->link) == reinterpret_cast<char*>(p->nbr) + al(size_t(2 * n) * 4) &&
+                                          size_t(n) * sizeof(RcRecord<KeyT>) <= 2 * al(size_t(2 * n) * 4));
+        KSH_BOUND(nb <= 65536);  // tmp_g holds group ids as u16
         uint32_t* cursor = static_cast<uint32_t*>(arena_alloc(ctx, size_t(nb) * 4));
         if (!cursor) return fail(KSH_INTERNAL, "scratch arena too small");
         KSH_HIP(hipMemsetAsync(cursor, 0, size_t(nb) * 4, st));
@@ -2756,21 +2772,25 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       const int cap = int(std::min<int64_t>((kRcWindowBytes - 4 * kRcSegs) / int64_t(sizeof(KeyT) + 6),
                                             std::max<int64_t>(1024, (n / nb) * 5 / 4 + 256)));
       const size_t rc_lds = size_t(cap) * (sizeof(KeyT) + 4) + size_t(cap + 2 * kRcSegs) * 2;
+      // k_adj_rc keeps window positions, lengths and slice-index offsets in 16 bits (sidx, RcBatch::packed)
+      KSH_BOUND(cap >= 1 && cap + 2 * kRcSegs < 65536);
+      KSH_BOUND(rc_lds + 2048 <= size_t(kRcWindowBytes) + 2048 && rc_lds <= size_t(kRcWindowBytes));
       int64_t* pb = static_cast<int64_t*>(arena_alloc(ctx, size_t(nb) * 2 * kRcSegs * 8));
       if (!pb) return fail(KSH_INTERNAL, "scratch arena too small");
       hipLaunchKernelGGL((k_rc_bounds<KeyT>), dim3(nblk(nb * 2 * kRcSegs)), dim3(256), 0, st, set, nbits, pb);
       {
-        // (more than the 64 KB a kernel gets without asking)
-        static const bool raised = [] {
+        // (more than the 64 KB a kernel gets without asking; per context: the attribute is the device's)
+        const uint32_t bit = sizeof(KeyT) == 4 ? 1u : 2u;
+        if (!(ctx->lds_opt_in & bit)) {
           const int bytes = int(kRcWindowBytes + 2048);
-          return hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc<KeyT, 1024>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
-                 hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc<KeyT, 256>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess &&
-                 hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc<KeyT, 64>),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess;
-        }();
-        if (!raised) return fail(KSH_INTERNAL, "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed");
+          KSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc<KeyT, 1024>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+          KSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc<KeyT, 256>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+          KSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc<KeyT, 64>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+          ctx->lds_opt_in |= bit;
+        }
       }
       if (n / nb > 2048)
         hipLaunchKernelGGL((k_adj_rc<KeyT, 1024>), dim3(unsigned(nb)), dim3(1024), rc_lds, st, set, nbits, goff,
@@ -2791,6 +2811,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
         // the records are dead by now: the chunk bounds take their place
         const int64_t n_chunks = (n + kFwdChunk - 1) / kFwdChunk;
         int64_t* bounds = reinterpret_cast<int64_t*>(p->info);  // kFwdBounds * 8 bytes per 512 k-mers
+        KSH_BOUND(size_t(n_chunks + 1) * kFwdBounds * 8 <= al(size_t(2 * n) * 8));
         hipLaunchKernelGGL((k_fwd_bounds<KeyT>), dim3(nblk(n_chunks + 1)), dim3(256), 0, st, set, n_chunks, bounds);
         hipLaunchKernelGGL((k_adj_fwd_staged<KeyT>), dim3(unsigned(n_chunks)), dim3(kFwdChunk), 0, st, set, bounds,
                            rc0, rc1, p->nbr, flags + 1);

@@ -67,6 +67,10 @@ struct ksh_ctx {
   // encode plan state (ksh_encode.hip)
   void* enc_state = nullptr;
 
+  // kernels of this context's device that have been granted more than 64 KB of dynamic LDS
+  // (hipFuncSetAttribute acts on the current device: once per context, not once per process)
+  uint32_t lds_opt_in = 0;
+
   // text -> SPSS plan state (ksh_text.hip), FASTA -> fragments plan state (ksh_fasta.hip);
   // both use slot kSlotText, so a plan of one kind invalidates a pending plan of the other
   void* text_plan = nullptr;

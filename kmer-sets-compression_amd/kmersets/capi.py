@@ -93,6 +93,9 @@ def lib():
         "ksh_memcpy_h2d": (C.c_int, [C.c_int, vp, vp, C.c_size_t]),
         "ksh_memcpy_d2h": (C.c_int, [C.c_int, vp, vp, C.c_size_t]),
         "ksh_memcpy_d2d": (C.c_int, [C.c_int, vp, vp, C.c_size_t]),
+        "ksh_ctx_memcpy_h2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
+        "ksh_ctx_memcpy_d2h": (C.c_int, [vp, vp, vp, C.c_size_t]),
+        "ksh_ctx_memcpy_d2d": (C.c_int, [vp, vp, vp, C.c_size_t]),
         "ksh_ctx_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
         "ksh_ctx_destroy": (C.c_int, [vp]),
         "ksh_ctx_sync": (C.c_int, [vp]),
@@ -728,11 +731,10 @@ class DeviceKmerSetSet:
         n_words = (sv.n_bases + 31) // 32
         words = np.zeros(max(n_words, 1), dtype=np.uint64)
         lens = np.zeros(max(sv.n_strings, 1), dtype=np.uint32)
-        dev = self.ctx.device.index
         if n_words:
-            check(lib().ksh_memcpy_d2h(dev, words.ctypes.data_as(C.c_void_p), sv.d_words, n_words * 8))
+            check(lib().ksh_ctx_memcpy_d2h(self.ctx.h, words.ctypes.data_as(C.c_void_p), sv.d_words, n_words * 8))
         if sv.n_strings:
-            check(lib().ksh_memcpy_d2h(dev, lens.ctypes.data_as(C.c_void_p), sv.d_lens, sv.n_strings * 4))
+            check(lib().ksh_ctx_memcpy_d2h(self.ctx.h, lens.ctypes.data_as(C.c_void_p), sv.d_lens, sv.n_strings * 4))
         return synth.unpack_strings(words[:n_words], lens[: sv.n_strings], self.g.k)
 
     def node_size(self, i):
@@ -755,10 +757,9 @@ class DeviceKmerSetSet:
         off = np.zeros(nb + 1, dtype=np.int64)
         kdt = np.uint32 if g.key_bytes == 4 else np.uint64
         keys = np.zeros(max(n_keys, 1), dtype=kdt)
-        dev = self.ctx.device.index
-        check(lib().ksh_memcpy_d2h(dev, off.ctypes.data_as(C.c_void_p), d_off, (nb + 1) * 8))
+        check(lib().ksh_ctx_memcpy_d2h(self.ctx.h, off.ctypes.data_as(C.c_void_p), d_off, (nb + 1) * 8))
         if n_keys:
-            check(lib().ksh_memcpy_d2h(dev, keys.ctypes.data_as(C.c_void_p), d_keys, n_keys * g.key_bytes))
+            check(lib().ksh_ctx_memcpy_d2h(self.ctx.h, keys.ctypes.data_as(C.c_void_p), d_keys, n_keys * g.key_bytes))
         return synth.from_bucketed(off, keys[:n_keys], g.k, g.n_bucket_bits)
 
     def children(self, i):
@@ -854,13 +855,13 @@ class Comm:
             def d2h(ptr, n):
                 a = np.empty(n, dtype=np.uint8)
                 if n:
-                    check(lib().ksh_memcpy_d2h(dev, a.ctypes.data_as(C.c_void_p), ptr, n))
+                    check(lib().ksh_ctx_memcpy_d2h(ctx.h, a.ctypes.data_as(C.c_void_p), ptr, n))
                 return torch.from_numpy(a)
 
             def h2d(ptr, t):
                 a = t.numpy()
                 if a.size:
-                    check(lib().ksh_memcpy_h2d(dev, ptr, a.ctypes.data_as(C.c_void_p), a.size))
+                    check(lib().ksh_ctx_memcpy_h2d(ctx.h, ptr, a.ctypes.data_as(C.c_void_p), a.size))
 
             def guarded(f):
                 def g(*args):

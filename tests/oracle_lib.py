@@ -39,7 +39,9 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    L = C.CDLL(build())
+    # KSH_ORACLE_LIB: another build of the same sources (bench.py's cpu_baseline leg loads the copy it has
+    # just compiled with -O3 -march=native on the host it runs on)
+    L = C.CDLL(os.environ.get("KSH_ORACLE_LIB") or build())
     vp, i, i64, u64, u32 = C.c_void_p, C.c_int, C.c_int64, C.c_uint64, C.c_uint32
     sig = {
         "ko_kmer_from_string": (u64, [C.c_char_p, i]),

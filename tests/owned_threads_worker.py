@@ -1,0 +1,158 @@
+"""Worker of tests/test_gpu_kmer_set_set.py::test_owned_build_eight_ranks: ksh_kss_build_owned with
+WORLD ranks as WORLD host threads of ONE process, all on GPU 0 -- the rank count the owner-sharded
+build is designed for (8 GPUs of a node: owners[i] = i * 8 // 64, the deal of a check's encodes over
+8 ranks, the roll-back of a deferred check), which a one-GPU box cannot host as processes (it admits
+six processes on its card).  Every rank is a thread with a context (stream, scratch, pool) of its
+own; the transport is the caller-supplied one (ksh_comm_create_custom) over an in-process hub:
+all-gather through a barrier, send / recv through one queue per (source, destination).  The checks
+are those of tests/dist_owned_worker.py: the replicated state against the oracle on every rank, a
+node's set and SPSS on the rank that owns it.
+
+  python owned_threads_worker.py K N KEY_BYTES N_SETS SIZE SEED WORLD [block|striped]
+"""
+import json
+import os
+import queue
+import sys
+import threading
+import traceback
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.join(HERE, "..", "kmer-sets-compression_amd"))
+import oracle_lib as ol  # noqa: E402
+from kmersets import capi, synth  # noqa: E402
+
+TIMEOUT = 300.0
+
+
+class Hub:
+    def __init__(self, world):
+        self.world = world
+        self.barrier = threading.Barrier(world, timeout=TIMEOUT)
+        self.slots = [None] * world
+        self.q = {(s, d): queue.Queue() for s in range(world) for d in range(world)}
+
+
+class ThreadDist:
+    """The part of the torch.distributed interface capi.Comm / capi.OwnedKmerSetSet use, between threads."""
+
+    def __init__(self, hub, rank):
+        self.hub, self.rank = hub, rank
+
+    def get_rank(self):
+        return self.rank
+
+    def get_world_size(self):
+        return self.hub.world
+
+    def get_backend(self):
+        return "threads"
+
+    def barrier(self):
+        self.hub.barrier.wait()
+
+    def all_gather(self, parts, mine):
+        self.hub.slots[self.rank] = mine.clone()
+        self.hub.barrier.wait()
+        for r in range(self.hub.world):
+            parts[r].copy_(self.hub.slots[r])
+        self.hub.barrier.wait()
+
+    def all_reduce(self, t):
+        parts = [torch.empty_like(t) for _ in range(self.hub.world)]
+        self.all_gather(parts, t)
+        t.copy_(torch.stack(parts).sum(dim=0))
+
+    def send(self, t, peer):
+        self.hub.q[(self.rank, peer)].put(t.clone())
+
+    def recv(self, t, peer):
+        t.copy_(self.hub.q[(peer, self.rank)].get(timeout=TIMEOUT))
+
+
+def run_rank(rank, hub, shape, layout, shared, out, errors):
+    try:
+        k, n, kb, n_sets, size, seed = shape
+        world = hub.world
+        dist = ThreadDist(hub, rank)
+        torch.cuda.set_device(0)
+        ctx = capi.Context(0)
+        g = capi.geom(k, n)
+        ocompacts, okss, osets, ids = shared["ocompacts"], shared["okss"], shared["osets"], shared["ids"]
+        owners = capi.block_owners(n_sets, world) if layout == "block" else [i % world for i in range(n_sets)]
+        dcompacts = [capi.DeviceSpss.from_strings(g, c.strings(), ctx.device) if owners[i] == rank else None
+                     for i, c in enumerate(ocompacts)]
+        dkss = capi.OwnedKmerSetSet(ctx, dcompacts, ids, dist, "cpu", owners=owners)
+        it, cp, imp = dkss.trace()
+        assert np.array_equal(it, okss.iterations()), (it, okss.iterations())
+        ocp, oimp = okss.checkpoints()
+        assert np.array_equal(cp, ocp) and np.array_equal(imp, oimp)
+        assert dkss.size() == okss.size() and dkss.meta() == okss.meta()
+        st = dkss.stats()
+        assert st["initial_spss_weight"] == okss.stat(2) and st["n_processed"] == okss.stat(3)
+        assert st["initial_total_size"] == okss.stat(0) and st["final_total_size"] == okss.stat(1)
+        assert st["final_spss_weight"] == shared["final_weight"]
+        held = []
+        for i in range(okss.size()):
+            assert dkss.node_size(i) == shared["node_sizes"][i]
+            if dkss.node_holder(i) == rank:
+                node = okss.node(i)
+                assert np.array_equal(dkss.node_kmers(i), node.to_set().kmers()), "node %d" % i
+                assert dkss.node_strings(i) == node.strings(), "node %d" % i
+                held.append(i)
+        for i in range(n_sets):
+            assert dkss.get_size_and_hash(i) == (osets[i].size(), osets[i].hash()), i
+        cs = dkss.comm_stats()
+        out[rank] = {"held": held, "encodes": dkss.stats()["n_encodes"], "p2p_sets": cs["p2p_sets"],
+                     "sent": cs["p2p_bytes_sent"], "received": cs["p2p_bytes_received"],
+                     "checks_deferred": cs["checks_deferred"], "rollbacks": cs["rollbacks"],
+                     "migrated": cs["sets_migrated"], "iterations": int(len(it)), "checks": int(len(cp)),
+                     "nodes": okss.size()}
+        dist.barrier()
+        dkss.close()
+        ctx.close()
+    except BaseException:  # noqa: BLE001 -- a failed rank must not leave the others waiting at a barrier
+        errors.append("rank %d:\n%s" % (rank, traceback.format_exc()))
+        hub.barrier.abort()
+
+
+def main():
+    k, n, kb, n_sets, size, seed, world = (int(x) for x in sys.argv[1:8])
+    layout = sys.argv[8] if len(sys.argv) > 8 else "block"
+    sets = synth.phylogeny_sets(k, n_sets, size, seed=seed)
+    osets = [ol.Set.from_kmers(k, n, kb, s) for s in sets]
+    ocompacts = [s.compact() for s in osets]
+    ids = synth.sample_bucket_ids(n, seed=seed + 1)
+    okss = ol.KmerSetSet(ocompacts, ids)
+    shared = {"ocompacts": ocompacts, "okss": okss, "osets": osets, "ids": ids,
+              "node_sizes": [okss.node(i).size() for i in range(okss.size())],
+              "final_weight": sum(okss.node(i).weight() for i in range(okss.size()))}
+    capi.lib()
+    hub = Hub(world)
+    out, errors = [None] * world, []
+    threads = [threading.Thread(target=run_rank, args=(r, hub, (k, n, kb, n_sets, size, seed), layout, shared, out, errors))
+               for r in range(world)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    if errors:
+        print("\n".join(errors), file=sys.stderr)
+        raise SystemExit(1)
+    held = sorted(i for o in out for i in o["held"])
+    assert held == list(range(out[0]["nodes"])), "every node lives on exactly one rank"
+    print(json.dumps({"ok": True, "world": world, "iterations": out[0]["iterations"], "nodes": out[0]["nodes"],
+                      "checks": out[0]["checks"], "checks_deferred": out[0]["checks_deferred"],
+                      "rollbacks": out[0]["rollbacks"], "encodes_per_rank": [o["encodes"] for o in out],
+                      "sets_sent_per_rank": [o["p2p_sets"] for o in out],
+                      "bytes_sent": sum(o["sent"] for o in out), "bytes_received": sum(o["received"] for o in out),
+                      "nodes_per_rank": [len(o["held"]) for o in out],
+                      "sets_migrated": sum(o["migrated"] for o in out)}))
+
+
+if __name__ == "__main__":
+    main()

@@ -2,6 +2,7 @@
 finishes such sizes in hours, so it checks the same code at small sizes in the other files):
 
 * configs[2]: 16 canonical k=23 sets of 10^8 k-mers, the whole KmerSetSet loop on one GPU;
+* configs[3]'s workload: 64 canonical k=23 sets of 10^8 k-mers (what bench.py times), one build;
 * the same at k=31 (64-bit keys), 8 sets of 5 * 10^8: configs[4]'s geometry at what one GPU's share is.
 
 Checked: Size and XOR Hash of Get(i) == those of the decoded input for every i (the reference's own
@@ -25,7 +26,7 @@ def ctx(gpu):
     c.close()
 
 
-def _loop_properties(ctx, k, n_sets, size, seed):
+def _loop_properties(ctx, k, n_sets, size, seed, builds=2):
     import torch
 
     g = capi.geom(k, 14)
@@ -39,7 +40,7 @@ def _loop_properties(ctx, k, n_sets, size, seed):
     torch.cuda.empty_cache()
     ids = synth.sample_bucket_ids(14, seed=seed + 1)
     results = []
-    for _ in range(2):
+    for _ in range(builds):
         kss = capi.DeviceKmerSetSet(ctx, compacts, ids)
         st = kss.stats()
         it, cp, imp = kss.trace()
@@ -79,7 +80,7 @@ def _loop_properties(ctx, k, n_sets, size, seed):
         results.append((st["n_processed"], st["final_spss_weight"], st["packed_bytes"], st["length_bytes"], n_nodes,
                         it.tolist(), cp.tolist()))
         kss.close()
-    assert results[0] == results[1]          # deterministic: bytes/k-mer equal across two builds
+    assert all(r == results[0] for r in results)          # deterministic: bytes/k-mer equal across builds
     return results[0]
 
 
@@ -87,6 +88,15 @@ def test_config3_16x1e8_k23(ctx):
     n_proc, weight, packed, lens, nodes, it, cp = _loop_properties(ctx, 23, 16, int(1e8), seed=3)
     assert len(it) >= 8 and nodes > 16
     assert (packed + lens) / (16 * 1e8) < 0.26          # below the 2 bits per k-mer of the unmerged sets
+
+
+def test_config4_64x1e8_k23(ctx):
+    """configs[3]'s sets (the workload of bench.py's headline number) on one GPU: one whole build and
+    the same checks -- every Get(i) against its input by Size and XOR Hash, the DAG, the trace's sizes."""
+    n_proc, weight, packed, lens, nodes, it, cp = _loop_properties(ctx, 23, 64, int(1e8), seed=3, builds=1)
+    assert len(it) >= 32 and nodes > 64
+    assert len(cp) >= 1 and n_proc > 64 * 0.9e8
+    assert (packed + lens) / (64 * 1e8) < 0.20
 
 
 def test_k31_8x5e8(ctx):

@@ -164,6 +164,30 @@ def test_owned_build(gpu, world, shape, layout):
         assert res["rollbacks"] == 1      # this family stops at a check: the interval after it was undone
 
 
+def test_owned_build_eight_ranks(gpu):
+    """The owner-sharded build at the rank count it is designed for: 8 ranks, 64 sets of 2 x 10^5 k-mers
+    (k = 23), block owners (owners[i] = i * 8 // 64) -- the deal of a check's encodes over eight ranks, the
+    deferred checks and the roll-back, all against the oracle.  A one-GPU box admits six processes on its
+    card, so the eight ranks are eight host threads of one process, each with its own context and
+    stream, over an in-process transport (tests/owned_threads_worker.py)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    cmd = [sys.executable, os.path.join(here, "owned_threads_worker.py"), "23", "14", "4", "64", "200000", "21", "8",
+           "block"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert res["ok"] and res["world"] == 8 and res["iterations"] >= 32
+    assert sum(res["nodes_per_rank"]) == res["nodes"] and min(res["nodes_per_rank"]) > 0
+    assert res["bytes_sent"] == res["bytes_received"] and sum(res["sets_sent_per_rank"]) > 0
+    assert min(res["encodes_per_rank"]) > 0
+    assert res["checks_deferred"] == res["checks"] > 0
+
+
 def test_owned_build_without_lookahead(gpu, monkeypatch):
     """KSH_OWNED_LOOKAHEAD=0: every check resolved on the spot -- the same result by the other route."""
     monkeypatch.setenv("KSH_OWNED_LOOKAHEAD", "0")

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round-2 evidence for the contract bench (the whole KmerSetSet constructor on 64 x 1e8, k = 23):
-#   1. the bench line                                    -> gpurun_out/r02/$TAG_bench.json
+#   1. the bench line                                    -> gpurun_out/${KSH_ROUND:-r03}/$TAG_bench.json
 #   2. the same command under rocprofv3 --kernel-trace --stats (one warm-up + one timed build)
 #   3. FETCH_SIZE and WRITE_SIZE passes (separate runs, --kernel-trace only) on the 16 x 1e8 loop,
 #      reduced per kernel by tools/pmc_kernel.py
@@ -8,7 +8,7 @@
 set -e -o pipefail
 TAG=${1:-r02}; shift || true
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/r02
+O=$R/gpurun_out/${KSH_ROUND:-r03}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py "$@" > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err

@@ -4,7 +4,7 @@
 set -e -o pipefail
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/r02
+O=$R/gpurun_out/${KSH_ROUND:-r03}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for kv in "$@"; do export "$kv"; done

@@ -4,7 +4,7 @@
 set -e -o pipefail
 TAG=$1; WHICH=$2
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/r02
+O=$R/gpurun_out/${KSH_ROUND:-r03}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 D=/tmp/encs_$TAG

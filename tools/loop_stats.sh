@@ -4,7 +4,7 @@
 set -e -o pipefail
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/r02
+O=$R/gpurun_out/${KSH_ROUND:-r03}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats -o stats -- python3 $R/bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-verify --no-pair-merge "$@" > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_rocprof_stats.err

@@ -4,7 +4,7 @@
 # at hashed indices of arrays of known size; the counters per launch / 1e8 = bytes counted per access.
 set -e -o pipefail
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-O=$R/gpurun_out/r02
+O=$R/gpurun_out/${KSH_ROUND:-r03}
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 $R/tools/random_access_rate.hip -o /tmp/random_access_rate

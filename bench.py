@@ -220,7 +220,12 @@ def main():
         parts = [torch.zeros_like(v) for _ in range(world)]
         dist.all_gather(parts, v)
         rows = [[int(x) for x in p.tolist()] for p in parts]
-        multi_gpu = {"transport": comm.kind, "encodes_per_rank": [r[0] for r in rows],
+        ranks_seen = comm.ranks_seen()       # every rank's id through the transport's own all-gather
+        multi_gpu = {"transport": comm.kind, "ranks_seen": ranks_seen,
+                     "control_weights": "sharded by pair list + all-gather of int64 per iteration (%d all-gathers)"
+                                        % cs["weight_gathers"] if cs["weight_gathers"] else
+                                        "replicated on the all-gathered samples (no exchange)",
+                     "encodes_per_rank": [r[0] for r in rows],
                      "encoded_kmers_per_rank": [r[1] for r in rows], "sets_sent_per_rank": [r[2] for r in rows],
                      "p2p_bytes_sent_per_rank": [r[3] for r in rows], "allgather_bytes_per_rank": [r[4] for r in rows],
                      "note": "last timed build"}
@@ -427,7 +432,7 @@ def main():
             "higher_is_better": True,
             "scaling": "strong" if world > 1 else "weak",
             "vs_baseline": None,
-            "dtype": "u32" if g.key_bytes == 4 else "u64",
+            "dtype": {2: "u16", 4: "u32", 8: "u64"}[g.key_bytes],
             "data": "synthetic",
             "config": {
                 "workload": "%d canonical k=%d sets of %d k-mers (seeded phylogeny family), the whole KmerSetSet "

@@ -352,12 +352,18 @@ typedef struct ksh_comm_fns {
   int (*allgather)(void* user, const void* d_send, void* d_recv, size_t bytes);
   int (*send)(void* user, const void* d_buf, size_t bytes, int32_t peer);
   int (*recv)(void* user, void* d_buf, size_t bytes, int32_t peer);
+  /* optional (may be NULL): called once when this rank gives the build up at a point where it cannot
+   * follow the exchange protocol any longer; it should make the peers' pending calls fail */
+  void (*abort)(void* user);
 } ksh_comm_fns;
 int ksh_comm_unique_id(unsigned char id[KSH_COMM_ID_BYTES]);
 int ksh_comm_create_rccl(ksh_ctx* ctx, int32_t rank, int32_t world, const unsigned char id[KSH_COMM_ID_BYTES],
                          ksh_comm** out);
 int ksh_comm_create_custom(ksh_ctx* ctx, int32_t rank, int32_t world, const ksh_comm_fns* fns, ksh_comm** out);
 int ksh_comm_destroy(ksh_comm* comm);
+/* Collective: every rank's id through the transport's all-gather (device buffers); *n_ranks = distinct
+ * ids received: the ranks that actually took part (bench.py quotes it as multi_gpu.ranks_seen). */
+int ksh_comm_ranks_seen(ksh_comm* comm, int32_t* n_ranks);
 /* owners[i] in [0, world): the rank that holds input i.  inputs[i] is read on that rank only. */
 int ksh_kss_build_owned(ksh_ctx* ctx, ksh_comm* comm, const ksh_geom* g, const ksh_spss_view* inputs,
                         int32_t n_inputs, const int32_t* owners, const int32_t* bucket_ids, int32_t n_ids,
@@ -367,8 +373,10 @@ int ksh_kss_build_owned(ksh_ctx* ctx, ksh_comm* comm, const ksh_geom* g, const k
  * exchange was deferred by one check (the ranks go on with the next interval instead of waiting for the
  * slowest encoder; KSH_OWNED_LOOKAHEAD=0 turns that off), intervals undone because a deferred check
  * said "stop", sets this rank handed to a less loaded rank for encoding at a check (they live there
- * afterwards; KSH_OWNED_MIGRATE=0 turns that off) }. */
-int ksh_kss_comm_stats(const ksh_kss* k, int64_t stats[7]);
+ * afterwards; KSH_OWNED_MIGRATE=0 turns that off), all-gathers of per-pair int64 weights (one per iteration
+ * with KSH_OWNED_WEIGHTS=sharded: the weight tables dealt out by pair list, lib/core/kmer_set_set.h:205-218,
+ * 385-425; 0 by default: every rank weighs its replica of the samples and nothing is exchanged) }. */
+int ksh_kss_comm_stats(const ksh_kss* k, int64_t stats[8]);
 /* SPSS encodes this process ran for the build, and the k-mers they covered (the sharded build's
  * balance; in a single-GPU build: how many encodes the deferral left). */
 int ksh_kss_encode_counts(const ksh_kss* k, int64_t* n_encodes, int64_t* n_encoded_kmers);

@@ -12,8 +12,8 @@
 // Contains asks the device (ksh_set_contains; the batched overload takes many k-mers in one
 // launch); Find needs the k-mers on the host for its host predicate: they are expanded on the
 // device (ksh_set_kmers) and downloaded once.  n_workers stays in the signatures and is ignored.
-// KeyType keeps its meaning for the host-side accessors; on the device keys are 4 bytes
-// when 2K - N <= 32, else 8.
+// KeyType keeps its meaning for the host-side accessors; on the device keys are 2 bytes when
+// 2K - N <= 16 (the reference's (15, 14, uint16_t)), 4 when <= 32, else 8.
 #ifndef KSC_CORE_KMER_SET_H_
 #define KSC_CORE_KMER_SET_H_
 
@@ -54,7 +54,7 @@ class KmerSet {
  public:
   static constexpr int kBucketsNum = 1 << N;
   static constexpr int kKeyBits = 2 * K - N;
-  static constexpr int kDeviceKeyBytes = kKeyBits <= 32 ? 4 : 8;
+  static constexpr int kDeviceKeyBytes = kKeyBits <= 16 ? 2 : (kKeyBits <= 32 ? 4 : 8);
   static ksh_geom Geom() { return ksh_geom{K, N, kDeviceKeyBytes, 0}; }
 
   KmerSet() = default;
@@ -233,7 +233,12 @@ class KmerSet {
     for (std::uint64_t b : bits) off[(b >> kKeyBits) + 1]++;
     for (int b = 0; b < kBucketsNum; b++) off[b + 1] += off[b];
     ksc::DeviceBuffer keys;
-    if (kDeviceKeyBytes == 4) {
+    if (kDeviceKeyBytes == 2) {
+      std::vector<std::uint16_t> k16(bits.size());
+      for (std::size_t i = 0; i < bits.size(); i++)
+        k16[i] = static_cast<std::uint16_t>(bits[i] & ((std::uint64_t(1) << kKeyBits) - 1));
+      keys = ksc::DeviceBuffer::FromHost(k16);
+    } else if (kDeviceKeyBytes == 4) {
       std::vector<std::uint32_t> k32(bits.size());
       for (std::size_t i = 0; i < bits.size(); i++)
         k32[i] = static_cast<std::uint32_t>(bits[i] & ((std::uint64_t(1) << kKeyBits) - 1));

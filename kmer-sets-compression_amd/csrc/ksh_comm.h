@@ -22,6 +22,7 @@ int comm_side_recv(ksh_comm* c, void* d_buf, size_t bytes, int peer);
 hipStream_t comm_side_stream(ksh_comm* c);
 int comm_side_join_main(ksh_comm* c);
 int comm_side_sync(ksh_comm* c);
+void comm_abort(ksh_comm* c);
 
 }  // namespace ksh
 

@@ -15,6 +15,7 @@
 #include <dlfcn.h>
 
 #include <cstring>
+#include <vector>
 
 #include "ksh_comm.h"
 
@@ -29,6 +30,7 @@ using comm_t = void*;
 using fn_get_unique_id = int (*)(UniqueId*);
 using fn_comm_init_rank = int (*)(comm_t*, int, UniqueId, int);
 using fn_comm_destroy = int (*)(comm_t);
+using fn_comm_abort = int (*)(comm_t);
 using fn_all_gather = int (*)(const void*, void*, size_t, int, comm_t, hipStream_t);
 using fn_send = int (*)(const void*, size_t, int, int, comm_t, hipStream_t);
 using fn_recv = int (*)(void*, size_t, int, int, comm_t, hipStream_t);
@@ -39,6 +41,7 @@ struct Rccl {
   fn_get_unique_id get_unique_id = nullptr;
   fn_comm_init_rank comm_init_rank = nullptr;
   fn_comm_destroy comm_destroy = nullptr;
+  fn_comm_abort comm_abort = nullptr;
   fn_all_gather all_gather = nullptr;
   fn_send send = nullptr;
   fn_recv recv = nullptr;
@@ -62,6 +65,7 @@ int load_rccl(Rccl* r) {
     c.get_unique_id = reinterpret_cast<fn_get_unique_id>(dlsym(lib, "ncclGetUniqueId"));
     c.comm_init_rank = reinterpret_cast<fn_comm_init_rank>(dlsym(lib, "ncclCommInitRank"));
     c.comm_destroy = reinterpret_cast<fn_comm_destroy>(dlsym(lib, "ncclCommDestroy"));
+    c.comm_abort = reinterpret_cast<fn_comm_abort>(dlsym(lib, "ncclCommAbort"));
     c.all_gather = reinterpret_cast<fn_all_gather>(dlsym(lib, "ncclAllGather"));
     c.send = reinterpret_cast<fn_send>(dlsym(lib, "ncclSend"));
     c.recv = reinterpret_cast<fn_recv>(dlsym(lib, "ncclRecv"));
@@ -90,6 +94,7 @@ struct ksh_comm {
   comm_t nccl_side = nullptr;
   hipStream_t side = nullptr;
   hipEvent_t side_ready = nullptr, side_done = nullptr;
+  bool aborted = false;
 };
 
 namespace ksh {
@@ -178,6 +183,25 @@ int comm_side_join_main(ksh_comm* c) {
   return KSH_OK;
 }
 
+// A rank that cannot go on with the protocol (its replica of the control loop failed, a transport call
+// failed) tears the transport down instead of leaving its peers in an exchange it will never join: RCCL:
+// ncclCommAbort on both communicators (pending operations of this rank end; the caller is expected to take
+// the job down, the peers' pending operations do not complete by themselves); custom transport: the
+// caller's abort function, if it gave one.  Idempotent.
+void comm_abort(ksh_comm* c) {
+  if (!c || c->aborted) return;
+  c->aborted = true;
+  if (c->custom) {
+    if (c->fns.abort) c->fns.abort(c->fns.user);
+    return;
+  }
+  if (c->rccl.comm_abort) {
+    if (c->nccl_side) (void)c->rccl.comm_abort(c->nccl_side);
+    if (c->nccl) (void)c->rccl.comm_abort(c->nccl);
+    c->nccl_side = c->nccl = nullptr;
+  }
+}
+
 // The host waits for everything the side channel holds so far.
 int comm_side_sync(ksh_comm* c) {
   KSH_HIP(hipStreamSynchronize(comm_side_stream(c)));
@@ -239,6 +263,10 @@ int ksh_comm_create_rccl(ksh_ctx* ctx, int32_t rank, int32_t world, const unsign
   // the side channel's communicator: rank 0 draws its id, an all-gather on the first one carries it
   {
     auto cleanup = [&](int code, const char* what) {
+      if (c->nccl_side) (void)c->rccl.comm_destroy(c->nccl_side);
+      if (c->side) (void)hipStreamDestroy(c->side);
+      if (c->side_ready) (void)hipEventDestroy(c->side_ready);
+      if (c->side_done) (void)hipEventDestroy(c->side_done);
       (void)c->rccl.comm_destroy(c->nccl);
       delete c;
       return fail(code, "side communicator: %s", what);
@@ -280,6 +308,38 @@ int ksh_comm_create_custom(ksh_ctx* ctx, int32_t rank, int32_t world, const ksh_
   c->custom = true;
   if (fns) c->fns = *fns;
   *out = c;
+  return KSH_OK;
+}
+
+/* Collective (every rank calls it): each rank's id goes round through the transport's all-gather, on
+ * device buffers; *n_ranks = the distinct ids that arrived here.  What a benchmark line quotes as the
+ * number of ranks that took part (bench.py: multi_gpu.ranks_seen). */
+int ksh_comm_ranks_seen(ksh_comm* c, int32_t* n_ranks) {
+  if (!c || !n_ranks) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  *n_ranks = 0;
+  KSH_HIP(hipSetDevice(c->ctx->device));
+  int64_t *d_one = nullptr, *d_all = nullptr;
+  KSH_HIP(hipMalloc(reinterpret_cast<void**>(&d_one), 8));
+  KSH_HIP(hipMalloc(reinterpret_cast<void**>(&d_all), 8 * size_t(c->world)));
+  const int64_t mine = c->rank;
+  std::vector<int64_t> all(size_t(c->world), -1);
+  int rc = KSH_OK;
+  if (hipMemcpyAsync(d_one, &mine, 8, hipMemcpyHostToDevice, c->ctx->stream) != hipSuccess ||
+      hipMemsetAsync(d_all, 0xFF, 8 * size_t(c->world), c->ctx->stream) != hipSuccess)
+    rc = fail(KSH_INTERNAL, "ksh_comm_ranks_seen: staging failed");
+  if (rc == KSH_OK) rc = comm_allgather(c, d_one, d_all, 8);
+  if (rc == KSH_OK && (hipMemcpyAsync(all.data(), d_all, 8 * size_t(c->world), hipMemcpyDeviceToHost, c->ctx->stream) != hipSuccess ||
+                       hipStreamSynchronize(c->ctx->stream) != hipSuccess))
+    rc = fail(KSH_INTERNAL, "ksh_comm_ranks_seen: read-back failed");
+  (void)hipFree(d_one);
+  (void)hipFree(d_all);
+  if (rc != KSH_OK) return rc;
+  std::vector<bool> seen(size_t(c->world), false);
+  for (int64_t r : all)
+    if (r >= 0 && r < c->world && !seen[size_t(r)]) {
+      seen[size_t(r)] = true;
+      (*n_ranks)++;
+    }
   return KSH_OK;
 }
 

@@ -40,8 +40,8 @@ int check_geom(const ksh_geom* g) {
     return fail(KSH_INVALID_ARGUMENT, "n_bucket_bits = %d is not usable with k = %d",
                 g->n_bucket_bits, g->k);
   const int kb = 2 * g->k - g->n_bucket_bits;
-  if (g->key_bytes != 4 && g->key_bytes != 8)
-    return fail(KSH_INVALID_ARGUMENT, "key_bytes = %d (device keys are 4 or 8 bytes)", g->key_bytes);
+  if (g->key_bytes != 2 && g->key_bytes != 4 && g->key_bytes != 8)
+    return fail(KSH_INVALID_ARGUMENT, "key_bytes = %d (device keys are 2, 4 or 8 bytes)", g->key_bytes);
   if (kb > 8 * g->key_bytes)
     return fail(KSH_INVALID_ARGUMENT, "%d key bits do not fit %d key bytes", kb, g->key_bytes);
   return KSH_OK;
@@ -87,6 +87,13 @@ static size_t pool_round(size_t bytes) {
 }
 
 int pool_alloc(ksh_ctx* ctx, size_t bytes, void** out) {
+  if (ctx->inject_skip >= 0 && bytes >= ctx->inject_min_bytes) {
+    if (ctx->inject_skip == 0) {
+      *out = nullptr;
+      return fail(KSH_INTERNAL, "hipMalloc(%zu) failed: out of memory (injected)", bytes);
+    }
+    ctx->inject_skip--;
+  }
   const size_t want = pool_round(bytes);
   auto it = ctx->pool_free_blocks.lower_bound(want);
   if (it != ctx->pool_free_blocks.end() && it->first <= want + want / 4) {
@@ -339,14 +346,17 @@ template <typename KeyT>
 __global__ __launch_bounds__(256) void k_xor_keys(const KeyT* __restrict__ keys, int64_t n,
                                                    unsigned long long* __restrict__ out) {
   constexpr int kPer = 16 / sizeof(KeyT);
-  using Vec = typename std::conditional<sizeof(KeyT) == 4, uint4, ulonglong2>::type;
+  using Vec = typename std::conditional<sizeof(KeyT) <= 4, uint4, ulonglong2>::type;
   unsigned long long acc = 0;
   const int64_t n_vec = n / kPer;
   const int64_t stride = int64_t(gridDim.x) * blockDim.x;
   const Vec* vp = reinterpret_cast<const Vec*>(keys);
   for (int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; i < n_vec; i += stride) {
     Vec v = vp[i];
-    if constexpr (sizeof(KeyT) == 4) {
+    if constexpr (sizeof(KeyT) == 2) {
+      const uint32_t w = v.x ^ v.y ^ v.z ^ v.w;  // eight 16-bit keys, two to a word
+      acc ^= (unsigned long long)((w & 0xFFFFu) ^ (w >> 16));
+    } else if constexpr (sizeof(KeyT) == 4) {
       acc ^= (unsigned long long)(v.x ^ v.y ^ v.z ^ v.w);
     } else {
       acc ^= v.x ^ v.y;
@@ -416,6 +426,30 @@ __global__ __launch_bounds__(256) void k_expand_kmers(DevSet<KeyT> set, uint64_t
   const int64_t t = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   const uint64_t x = set.kmer_in_block(t, s_bucket);
   if (t < set.n) out[t] = x;
+}
+
+template <typename KeyT>
+int launch_contains(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* s, const uint64_t* d_kmers, int64_t n,
+                    uint8_t* d_found) {
+  DevSet<KeyT> set{s->d_offsets, static_cast<const KeyT*>(s->d_keys), n_buckets(g), s->n_keys, g->k, key_bits(g)};
+  hipLaunchKernelGGL(k_contains<KeyT>, dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, set, d_kmers, n, d_found);
+  KSH_HIP(hipGetLastError());
+  return KSH_OK;
+}
+
+template <typename KeyT>
+int launch_expand(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* s, uint64_t* d_kmers) {
+  DevSet<KeyT> set{s->d_offsets, static_cast<const KeyT*>(s->d_keys), n_buckets(g), s->n_keys, g->k, key_bits(g)};
+  hipLaunchKernelGGL(k_expand_kmers<KeyT>, dim3(unsigned((s->n_keys + 255) / 256)), dim3(256), 0, ctx->stream, set, d_kmers);
+  KSH_HIP(hipGetLastError());
+  return KSH_OK;
+}
+
+template <typename KeyT>
+int launch_xor_keys(ksh_ctx* ctx, const ksh_set_view* s, unsigned blocks, unsigned long long* d_acc) {
+  hipLaunchKernelGGL(k_xor_keys<KeyT>, dim3(blocks), dim3(256), 0, ctx->stream, static_cast<const KeyT*>(s->d_keys),
+                     s->n_keys, d_acc);
+  return KSH_OK;
 }
 
 }  // namespace ksh
@@ -657,16 +691,7 @@ int ksh_set_contains(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* s, con
   KSH_TRY(check_view(s, "s"));
   if (n <= 0) return KSH_OK;
   KSH_HIP(hipSetDevice(ctx->device));
-  const unsigned blocks = unsigned((n + 255) / 256);
-  if (g->key_bytes == 4) {
-    DevSet<uint32_t> set{s->d_offsets, static_cast<const uint32_t*>(s->d_keys), n_buckets(g), s->n_keys, g->k, key_bits(g)};
-    hipLaunchKernelGGL(k_contains<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream, set, d_kmers, n, d_found);
-  } else {
-    DevSet<uint64_t> set{s->d_offsets, static_cast<const uint64_t*>(s->d_keys), n_buckets(g), s->n_keys, g->k, key_bits(g)};
-    hipLaunchKernelGGL(k_contains<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream, set, d_kmers, n, d_found);
-  }
-  KSH_HIP(hipGetLastError());
-  return KSH_OK;
+  return KSH_BY_KEY(g->key_bytes, launch_contains, ctx, g, s, d_kmers, n, d_found);
 }
 
 int ksh_set_kmers(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* s, uint64_t* d_kmers) {
@@ -676,16 +701,7 @@ int ksh_set_kmers(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* s, uint64
   if (s->n_keys == 0) return KSH_OK;
   if (!d_kmers) return fail(KSH_INVALID_ARGUMENT, "NULL output");
   KSH_HIP(hipSetDevice(ctx->device));
-  const unsigned blocks = unsigned((s->n_keys + 255) / 256);
-  if (g->key_bytes == 4) {
-    DevSet<uint32_t> set{s->d_offsets, static_cast<const uint32_t*>(s->d_keys), n_buckets(g), s->n_keys, g->k, key_bits(g)};
-    hipLaunchKernelGGL(k_expand_kmers<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream, set, d_kmers);
-  } else {
-    DevSet<uint64_t> set{s->d_offsets, static_cast<const uint64_t*>(s->d_keys), n_buckets(g), s->n_keys, g->k, key_bits(g)};
-    hipLaunchKernelGGL(k_expand_kmers<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream, set, d_kmers);
-  }
-  KSH_HIP(hipGetLastError());
-  return KSH_OK;
+  return KSH_BY_KEY(g->key_bytes, launch_expand, ctx, g, s, d_kmers);
 }
 
 int ksh_ctx_timing_units(ksh_ctx* ctx, int kind, int64_t* units) {
@@ -708,12 +724,7 @@ int ksh_set_hash(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* s, uint64_
   if (s->n_keys > 0) {
     const int64_t per_block = 256 * 16;
     unsigned blocks = unsigned(std::min<int64_t>((s->n_keys + per_block - 1) / per_block, 2048));
-    if (g->key_bytes == 4)
-      hipLaunchKernelGGL(k_xor_keys<uint32_t>, dim3(blocks), dim3(256), 0, ctx->stream,
-                         static_cast<const uint32_t*>(s->d_keys), s->n_keys, d_acc);
-    else
-      hipLaunchKernelGGL(k_xor_keys<uint64_t>, dim3(blocks), dim3(256), 0, ctx->stream,
-                         static_cast<const uint64_t*>(s->d_keys), s->n_keys, d_acc);
+    (void)KSH_BY_KEY(g->key_bytes, launch_xor_keys, ctx, s, blocks, d_acc);
   }
   hipLaunchKernelGGL(k_xor_buckets, dim3(unsigned(std::min<int64_t>((nb + 255) / 256, 1024))),
                      dim3(256), 0, ctx->stream, s->d_offsets, nb, key_bits(g), d_acc);

@@ -605,7 +605,7 @@ int decode_write_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int 
   if (!new_off || !below) return fail(KSH_INTERNAL, "scratch arena too small");
   {
     // (more than the 64 KB a kernel gets without asking)
-    const uint32_t bit = sizeof(KeyT) == 4 ? 4u : 8u;
+    const uint32_t bit = 8u << (sizeof(KeyT) == 2 ? 0 : sizeof(KeyT) == 4 ? 1 : 2);
     if (!(ctx->lds_opt_in & bit)) {
       KSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_bucket_sort<KeyT>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, kSortLdsBytes));
@@ -677,8 +677,7 @@ int ksh_spss_decode_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s
   if (n_buckets(g) > kMaxLdsBuckets)
     return fail(KSH_INVALID_ARGUMENT, "decode supports n_bucket_bits <= 14 (got %d)", g->n_bucket_bits);
   KSH_HIP(hipSetDevice(ctx->device));
-  return g->key_bytes == 4 ? decode_plan_t<uint32_t>(ctx, g, s, canonical_flag, d_offsets, n_keys)
-                           : decode_plan_t<uint64_t>(ctx, g, s, canonical_flag, d_offsets, n_keys);
+  return KSH_BY_KEY(g->key_bytes, decode_plan_t, ctx, g, s, canonical_flag, d_offsets, n_keys);
 }
 
 int ksh_spss_decode_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int canonical_flag,
@@ -688,9 +687,7 @@ int ksh_spss_decode_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* 
   KSH_TRY(check_spss(s));
   if (ctx->dec_kmers > 0 && !d_keys) return fail(KSH_INVALID_ARGUMENT, "d_keys is NULL");
   KSH_HIP(hipSetDevice(ctx->device));
-  return g->key_bytes == 4
-             ? decode_write_t<uint32_t>(ctx, g, s, canonical_flag, d_offsets, d_keys, n_keys, 1, nullptr)
-             : decode_write_t<uint64_t>(ctx, g, s, canonical_flag, d_offsets, d_keys, n_keys, 1, nullptr);
+  return KSH_BY_KEY(g->key_bytes, decode_write_t, ctx, g, s, canonical_flag, d_offsets, d_keys, n_keys, 1, nullptr);
 }
 
 /* KmerCounter::FromReads + ToKmerSet (lib/core/kmer_counter.h:64-133,209-243): the k-mers of
@@ -707,9 +704,7 @@ int ksh_kmer_count_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* r
   if (cutoff < 1) cutoff = 1;  // "count < 0" never holds: a cutoff of 0 keeps every k-mer, like 1
   if (ctx->dec_kmers > 0 && !d_keys) return fail(KSH_INVALID_ARGUMENT, "d_keys is NULL");
   KSH_HIP(hipSetDevice(ctx->device));
-  return g->key_bytes == 4
-             ? decode_write_t<uint32_t>(ctx, g, reads, canonical_flag, d_offsets, d_keys, n_keys, cutoff, n_cut)
-             : decode_write_t<uint64_t>(ctx, g, reads, canonical_flag, d_offsets, d_keys, n_keys, cutoff, n_cut);
+  return KSH_BY_KEY(g->key_bytes, decode_write_t, ctx, g, reads, canonical_flag, d_offsets, d_keys, n_keys, cutoff, n_cut);
 }
 
 }  // extern "C"

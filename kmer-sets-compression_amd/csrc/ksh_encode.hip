@@ -927,6 +927,219 @@ __global__ __launch_bounds__(kFwdChunk) void k_adj_fwd_staged(DevSet<KeyT> set, 
   reinterpret_cast<uint2*>(nbr)[t] = make_uint2(out[0], out[1]);
 }
 
+// ---- the same, software-pipelined.  k_adj_fwd_staged spends a workgroup's life in dependent memory
+// round trips -- the chunk's bound record, then its windows (whose addresses come from that record), then
+// whatever its k-mers probe in global memory because a window overflowed -- with nothing of its own to
+// overlap them.  Here a workgroup is persistent and takes chunks blockIdx.x, + gridDim.x, ...: while it
+// searches chunk c in LDS, the windows, keys and marks of chunk c + G are on their way into registers and
+// the bound record of chunk c + 2G behind them, so a chunk's two staging round trips run under the
+// search of the chunk before.  The Next window holds a range 3 x the expected size (the first-base
+// density skew of canonical sets, above): only T-chunks that lead into A- or C-ranges still overflow.
+template <typename KeyT>
+struct FwdPipeCfg {
+  static constexpr int kCapNext = sizeof(KeyT) == 8 ? 3072 : 6144;  // (33 KB of LDS either way: four workgroups per CU)
+  static constexpr int kCapPrev = 512;
+  static_assert(kCapPrev % kFwdChunk == 0 && kCapNext % kFwdChunk == 0, "staging shape");
+};
+constexpr int kFwdPipeGroupsPerCu = 4;
+
+template <typename KeyT>
+__global__ __launch_bounds__(kFwdChunk) void k_adj_fwd_pipe(DevSet<KeyT> set, const int64_t* __restrict__ bounds,
+                                                            int64_t n_chunks, const uint32_t* __restrict__ rc0,
+                                                            const uint32_t* __restrict__ rc1,
+                                                            uint32_t* __restrict__ nbr, int* __restrict__ self_rc) {
+  constexpr int kCapNext = FwdPipeCfg<KeyT>::kCapNext, kCapPrev = FwdPipeCfg<KeyT>::kCapPrev;
+  constexpr int kPer = kCapNext / kFwdChunk, kPerPrev = kCapPrev / kFwdChunk;
+  __shared__ KeyT s_next[kCapNext];
+  __shared__ KeyT s_prev[4][kCapPrev];
+  __shared__ int64_t s_b[2][2 * kFwdBounds];    // bound records of the chunk being searched and of the next one
+  __shared__ int64_t s_boff[6][kFwdSpan + 1];
+  const int tid = threadIdx.x;
+  const int k = set.k;
+  int64_t chunk = blockIdx.x;
+  if (chunk >= n_chunks) return;
+  const int64_t stride = gridDim.x;
+
+  // what is in flight for a chunk: its keys and marks, the five windows, its bucket offsets
+  struct InFlight {
+    KeyT my_key;
+    uint2 rc;
+    KeyT vn[kPer];
+    KeyT vp[4][kPerPrev];
+    int64_t boff;
+  };
+  // the ranges of a chunk from its bound record (LDS): staged lengths, first indices, first buckets
+  struct Ranges {
+    int len[5];
+    int64_t lo_of[5];
+    int64_t fb[6];
+    bool usable[5];
+  };
+  const auto ranges_of = [&](const int64_t* sb) {
+    Ranges r;
+    const uint64_t x_first = uint64_t(sb[10]), x_last = uint64_t(sb[kFwdBounds + 11]);
+    r.fb[0] = int64_t(kmer_next(x_first, k, 0) >> set.key_bits);
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++) r.fb[1 + cc] = int64_t(kmer_prev(x_first, k, cc) >> set.key_bits);
+    r.fb[5] = int64_t(x_first >> set.key_bits);
+#pragma unroll
+    for (int q = 0; q < 5; q++) {
+      r.lo_of[q] = sb[q];
+      const int64_t l = sb[kFwdBounds + 5 + q] - r.lo_of[q];
+      r.usable[q] = l >= 0 && l <= (q == 0 ? kCapNext : kCapPrev);
+      r.len[q] = r.usable[q] ? int(l) : 0;
+    }
+    if ((x_first >> (2 * k - 2)) != (x_last >> (2 * k - 2))) {
+      r.usable[0] = false;
+      r.len[0] = 0;
+    }
+    return r;
+  };
+  const auto issue = [&](int64_t c, const Ranges& r) {
+    InFlight f;
+    const int64_t t = c * kFwdChunk + tid;
+    f.my_key = 0;
+    f.rc = make_uint2(kNone, kNone);
+    if (t < set.n) {
+      f.my_key = set.keys[t];
+      f.rc = make_uint2(rc0[t], rc1[t]);
+    }
+#pragma unroll
+    for (int u = 0; u < kPer; u++)
+      if (tid + u * kFwdChunk < r.len[0]) f.vn[u] = set.keys[r.lo_of[0] + tid + u * kFwdChunk];
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+      for (int u = 0; u < kPerPrev; u++)
+        if (tid + u * kFwdChunk < r.len[1 + cc]) f.vp[cc][u] = set.keys[r.lo_of[1 + cc] + tid + u * kFwdChunk];
+    f.boff = 0;
+    if (tid < 6 * (kFwdSpan + 1)) {
+      const int q = tid / (kFwdSpan + 1), j = tid % (kFwdSpan + 1);
+      const int64_t b = r.fb[q] + j;
+      f.boff = b <= set.n_buckets ? set.off[b] : set.n;
+    }
+    return f;
+  };
+
+  // prologue: the first chunk's record, then its loads and the second chunk's record
+  if (tid < 2 * kFwdBounds) s_b[0][tid] = bounds[kFwdBounds * chunk + tid];
+  __syncthreads();
+  int cur = 0;
+  Ranges rg = ranges_of(s_b[0]);
+  InFlight fl = issue(chunk, rg);
+  int64_t nb_val = 0;
+  if (tid < 2 * kFwdBounds && chunk + stride < n_chunks) nb_val = bounds[kFwdBounds * (chunk + stride) + tid];
+
+  while (true) {
+    // ---- this chunk's staged data into LDS; the next chunk's record beside it
+#pragma unroll
+    for (int u = 0; u < kPer; u++)
+      if (tid + u * kFwdChunk < rg.len[0]) s_next[tid + u * kFwdChunk] = fl.vn[u];
+#pragma unroll
+    for (int cc = 0; cc < 4; cc++)
+#pragma unroll
+      for (int u = 0; u < kPerPrev; u++)
+        if (tid + u * kFwdChunk < rg.len[1 + cc]) s_prev[cc][tid + u * kFwdChunk] = fl.vp[cc][u];
+    if (tid < 6 * (kFwdSpan + 1)) s_boff[tid / (kFwdSpan + 1)][tid % (kFwdSpan + 1)] = fl.boff;
+    if (tid < 2 * kFwdBounds) s_b[cur ^ 1][tid] = nb_val;
+    const KeyT my_key = fl.my_key;
+    const uint2 rc = fl.rc;
+    __syncthreads();
+    // ---- the next chunk's loads go out before this chunk is searched
+    const int64_t next = chunk + stride;
+    Ranges rg_next = rg;
+    if (next < n_chunks) {
+      rg_next = ranges_of(s_b[cur ^ 1]);
+      fl = issue(next, rg_next);
+      if (tid < 2 * kFwdBounds && next + stride < n_chunks) nb_val = bounds[kFwdBounds * (next + stride) + tid];
+    }
+    // ---- search
+    const int64_t t = chunk * kFwdChunk + tid;
+    if (t < set.n) {
+      int64_t my_b = rg.fb[5];
+      {
+        int j = 0;
+        while (j < kFwdSpan && s_boff[5][j + 1] <= t) j++;
+        my_b += j;
+        if (j == kFwdSpan)
+          while (set.off[my_b + 1] <= t) my_b++;
+      }
+      const uint64_t x = (uint64_t(my_b) << set.key_bits) | uint64_t(my_key);
+      if (revcomp(x, k) == x) *self_rc = 1;
+      int cnt[2] = {0, 0};
+      uint32_t single[2] = {kNone, kNone};
+      const auto bucket_range = [&](int q, int64_t b, int64_t* blo, int64_t* bhi) {
+        const int64_t j = b - rg.fb[q];
+        if (j < 0 || j >= kFwdSpan) return false;
+        *blo = s_boff[q][j];
+        *bhi = s_boff[q][j + 1];
+        return true;
+      };
+      {  // side 1: Next(x, .), neighbour as is
+        const uint64_t g0 = kmer_next(x, k, 0);
+        int64_t blo, bhi;
+        if (rg.usable[0] && bucket_range(0, int64_t(g0 >> set.key_bits), &blo, &bhi)) {
+          const KeyT gkey = KeyT(g0 & set.key_mask());
+          const int64_t hi0 = rg.lo_of[0] + rg.len[0];
+          const int lo = int((blo > rg.lo_of[0] ? blo : rg.lo_of[0]) - rg.lo_of[0]);
+          const int hi = int((bhi < hi0 ? bhi : hi0) - rg.lo_of[0]);
+          if (lo < hi) {
+            int i = lds_lower_bound(s_next, lo, hi, gkey);
+            for (; i < hi && uint64_t(s_next[i]) - uint64_t(gkey) < 4; i++) {
+              const int64_t idx = rg.lo_of[0] + i;
+              if (idx == t) continue;
+              cnt[1]++;
+              single[1] = uint32_t(idx) << 1;
+            }
+          }
+        } else {
+          set.for_group4(g0, [&](int64_t idx) {
+            if (idx == t) return;
+            cnt[1]++;
+            single[1] = uint32_t(idx) << 1;
+          });
+        }
+      }
+#pragma unroll
+      for (int c = 0; c < 4; c++) {  // side 0: Prev(x, c), neighbour as is
+        const uint64_t z = kmer_prev(x, k, c);
+        if (revcomp(z, k) < z) continue;
+        if (z == x) continue;
+        int64_t idx = -1;
+        int64_t blo, bhi;
+        if (rg.usable[1 + c] && bucket_range(1 + c, int64_t(z >> set.key_bits), &blo, &bhi)) {
+          const KeyT zkey = KeyT(z & set.key_mask());
+          const int64_t hi0 = rg.lo_of[1 + c] + rg.len[1 + c];
+          const int lo = int((blo > rg.lo_of[1 + c] ? blo : rg.lo_of[1 + c]) - rg.lo_of[1 + c]);
+          const int hi = int((bhi < hi0 ? bhi : hi0) - rg.lo_of[1 + c]);
+          if (lo < hi) {
+            const int i = lds_lower_bound(s_prev[c], lo, hi, zkey);
+            if (i < hi && s_prev[c][i] == zkey) idx = rg.lo_of[1 + c] + i;
+          }
+        } else {
+          idx = set.find(z);
+        }
+        if (idx < 0) continue;
+        cnt[0]++;
+        single[0] = uint32_t(idx) << 1;
+      }
+      const uint32_t r2[2] = {rc.x, rc.y};
+      uint32_t out[2];
+#pragma unroll
+      for (int side = 0; side < 2; side++) {
+        const int total = cnt[side] + (r2[side] == kNone ? 0 : (r2[side] == kMulti ? 2 : 1));
+        out[side] = total == 0 ? kNone : (total > 1 ? kMulti : (cnt[side] == 1 ? single[side] : r2[side]));
+      }
+      reinterpret_cast<uint2*>(nbr)[t] = make_uint2(out[0], out[1]);
+    }
+    if (next >= n_chunks) break;
+    __syncthreads();  // every thread is done with this chunk's windows
+    chunk = next;
+    cur ^= 1;
+    rg = rg_next;
+  }
+}
+
 // The forward half of the probe, in place, and the verdict per side: rc0 / rc1 are what k_adj_rc
 // found to reach the k-mer's side 0 / side 1 through a reverse complement.
 template <typename KeyT>
@@ -1251,9 +1464,14 @@ __global__ __launch_bounds__(256) void k_rank_unset(const uint32_t* __restrict__
 }
 
 // Pointer jumping over the dense ruler array until every ruler on a path points at its end.
+// (Rounds are launched back to back without a host round trip: a round whose predecessor changed
+// nothing -- *prev == 0, one scalar load -- returns at once and leaves its own flag clear, so all
+// later rounds do too.)
 __global__ __launch_bounds__(256) void k_ruler_jump(int64_t n_dense,
                                                      unsigned long long* __restrict__ rinfo,
+                                                     const int* __restrict__ prev,
                                                      int* __restrict__ changed) {
+  if (prev && *prev == 0) return;
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n_dense) return;
   const uint64_t mine = rinfo[i];
@@ -1316,7 +1534,8 @@ __global__ __launch_bounds__(256) void k_l2_walk(const unsigned long long* __res
 
 // Pointer jumping over the level-2 rulers.
 __global__ __launch_bounds__(256) void k_l2_jump(int64_t n_l2, unsigned long long* __restrict__ r2,
-                                                  int* __restrict__ changed) {
+                                                  const int* __restrict__ prev, int* __restrict__ changed) {
+  if (prev && *prev == 0) return;
   const int64_t j = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (j >= n_l2) return;
   const uint64_t mine = r2[j];
@@ -1808,7 +2027,9 @@ __global__ __launch_bounds__(256) void k_match_best(const uint32_t* __restrict__
                                                      int64_t n_vertices, bool directed,
                                                      unsigned long long* __restrict__ best_prio,
                                                      uint32_t* __restrict__ best_w,
+                                                     const int* __restrict__ prev,
                                                      int* __restrict__ any_live) {
+  if (prev && *prev == 0) return;  // the round before found no live edge: the matching is complete
   const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (v >= n_vertices) return;
   uint32_t bw = kNone;
@@ -1840,7 +2061,9 @@ __global__ __launch_bounds__(256) void k_match_best(const uint32_t* __restrict__
 __global__ __launch_bounds__(256) void k_match_commit(const unsigned long long* __restrict__ best_prio,
                                                        const uint32_t* __restrict__ best_w,
                                                        int64_t n_vertices,
+                                                       const int* __restrict__ live,
                                                        uint32_t* __restrict__ mate) {
+  if (*live == 0) return;  // k_match_best of this round did not run or found nothing
   const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (v >= n_vertices) return;
   const uint32_t w = best_w[v];
@@ -2059,7 +2282,8 @@ __global__ __launch_bounds__(256) void k_walk_init(const uint32_t* __restrict__ 
 }
 
 __global__ __launch_bounds__(256) void k_walk_jump(int64_t n_states, unsigned long long* __restrict__ walk,
-                                                    int* __restrict__ changed) {
+                                                    const int* __restrict__ prev, int* __restrict__ changed) {
+  if (prev && *prev == 0) return;
   const int64_t s = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (s >= n_states) return;
   const unsigned long long mine = walk[s];
@@ -2126,11 +2350,13 @@ __global__ __launch_bounds__(256) void k_string_counts(const uint8_t* __restrict
 // The string of every start: its id (the reference's push order), its length.
 __global__ __launch_bounds__(256) void k_string_ids(
     int64_t n_u, const uint8_t* __restrict__ scls, const int64_t* __restrict__ c01,
-    const int64_t* __restrict__ c2, const int64_t* __restrict__ s_nk, int64_t base1, int64_t base2,
+    const int64_t* __restrict__ c2, const int64_t* __restrict__ s_nk, const int64_t* __restrict__ class_totals,
     bool one_sequence, int k, uint32_t* __restrict__ sid_at, uint32_t* __restrict__ lens,
     int64_t* __restrict__ str_bases) {
   const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (u >= n_u) return;
+  // totals of the two scans (class 0 | class 1 << 32, class 2), still on the device: no host round trip
+  const int64_t base1 = class_totals[0] & 0xFFFFFFFF, base2 = base1 + (class_totals[0] >> 32);
   const uint8_t c = scls[u];
   if (c == 0xFF) return;
   int64_t sid;
@@ -2538,6 +2764,26 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ bytes,
 }
 
 // ---------------------------------------------------------------------------------- host
+// Device control block of one encode plan: every small flag and counter the kernels raise, zeroed by
+// ONE fill when the plan starts (they used to be a dozen memsets of 4..16 bytes, each a launch), and
+// read back in three copies (after the end list, after the unitig counts, at the end).
+constexpr int kJumpRoundsMax = 48;  // pointer-jumping rounds over the rulers: 2 + log2(n) <= 34
+constexpr int kMatchBatch = 8;      // matching rounds enqueued between two looks at their flags (4..6 observed)
+constexpr int kWalkRoundsMax = 40;  // jumping rounds over the path cover: 2 + log2(2 n_u)
+struct EncCtl {
+  int64_t tot[3 + kLenSums];  // [0..1] unitig counts by class, [2 .. 2 + kLenSums) k-mers the unitigs account
+                              // for (partial sums), [2 + kLenSums] (as an int) a ruler on a loop
+  int self_rc;                // a canonical set holds a k-mer equal to its own reverse complement
+  int pad;
+  int64_t t2[2];              // strings by class: class 0 | class 1 << 32, class 2
+  int64_t n_bases;            // total of the string lengths in bases
+  unsigned long long sc_used; // k_loop_cut's scratch cursor
+  unsigned int long_count[2]; // WalkLog::long_count
+  int jump_live[kJumpRoundsMax + 1];
+  int match_live[kMatchBatch + 1];
+  int walk_live[kWalkRoundsMax + 1];
+};
+
 struct EncPlan {
   int64_t n = 0, n_u = 0, n_strings = 0, n_bases = 0;
   int mode = 0;
@@ -2561,7 +2807,7 @@ struct EncPlan {
   unsigned long long *best_prio = nullptr, *sc_used = nullptr;
   uint8_t *visited = nullptr, *scls = nullptr, *u_flip = nullptr;
   int64_t *s_nk = nullptr, *sc01 = nullptr, *sc2 = nullptr, *str_start = nullptr;
-  int* any_live = nullptr;
+  EncCtl* ctl = nullptr;
   int rounds = 0;
   // ranking without stamps (k_choose_ends): the ruler and chain-start records live on in `info`
   // until the strings are written (k_emit_rulers / k_emit_heads)
@@ -2581,7 +2827,8 @@ inline size_t al(size_t x) { return (x + 255) & ~size_t(255); }
   do {                                                                                               \
     if (!(cond)) return ::ksh::fail(KSH_INTERNAL, "encode: bound violated: %s (%s:%d)", #cond, __FILE__, __LINE__); \
   } while (0)
-static_assert(sizeof(RcRecord<uint32_t>) == 8 && sizeof(RcRecord<uint64_t>) == 16, "record sizes the scratch layout assumes");
+static_assert(sizeof(RcRecord<uint16_t>) == 8 && sizeof(RcRecord<uint32_t>) == 8 && sizeof(RcRecord<uint64_t>) == 16,
+              "record sizes the scratch layout assumes");
 
 constexpr int64_t kRcRowsMax = 512;          // workgroups (histogram rows) of the rc partition
 // LDS window of k_adj_rc (keys + marks + slice index): two workgroups share a CU's 160 KB.  At 10^8
@@ -2670,7 +2917,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   const size_t fine_entries = use_fine ? (size_t(nb) << fine_bits) + 1 : 0;
   const size_t bytes = 2 * al(size_t(2 * n) * 4) + al(size_t(2 * n) * 8) + 5 * al(size_t(n) * 4) +
                        2 * al(size_t(n)) + 2 * al(size_t(n) * 8) + al(fine_entries * 4) +
-                       al(size_t((n >> kCoarseShift) + 2) * 4) + 4096;
+                       al(size_t((n >> kCoarseShift) + 2) * 4) + al(sizeof(EncCtl) + size_t(nb) * 4) + 4096;
   KSH_TRY(slot_reserve(ctx, kSlotEncode, bytes));
   KSH_TRY(arena_reserve(ctx, size_t(n / 256 + 4096) * 8 * 2 + (1u << 16) + size_t(n / kHeadSpan + 64) * 8 +
                                  (nb <= (1 << 14) ? size_t(kRcRowsMax) * nb * 4 + size_t(nb + 1) * 16 + size_t(nb) * 260 + 8192 : 0)));
@@ -2690,6 +2937,9 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   p->c23 = p->c01 + n;
   p->fine = use_fine ? carve<uint32_t>(at, fine_entries) : nullptr;
   p->coarse = n >= 4 * nb ? carve<uint32_t>(at, size_t((n >> kCoarseShift) + 2)) : nullptr;
+  p->ctl = reinterpret_cast<EncCtl*>(carve<char>(at, sizeof(EncCtl) + size_t(nb) * 4));
+  uint32_t* rc_cursor = reinterpret_cast<uint32_t*>(p->ctl + 1);  // k_rc_scatter_l2's per-group cursors: zeroed with the block
+  EncCtl* ctl = p->ctl;
 
   DevSet<KeyT> set{sv->d_offsets, static_cast<const KeyT*>(sv->d_keys), nb, n, g->k, key_bits(g)};
   hipStream_t st = ctx->stream;
@@ -2705,14 +2955,13 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     hipLaunchKernelGGL((k_coarse_index<KeyT>), dim3(nblk(n_entries)), dim3(256), 0, st, set, n_entries, p->coarse);
     set.coarse = p->coarse;
   }
-  int* flags = static_cast<int*>(arena_alloc(ctx, 16));  // [0] pointer-jumping progress, [1] self_rc
-  if (!flags) return fail(KSH_INTERNAL, "scratch arena too small");
-  KSH_HIP(hipMemsetAsync(flags, 0, 16, st));
+  KSH_HIP(hipMemsetAsync(ctl, 0, sizeof(EncCtl) + size_t(nb) * 4, st));
+  int* self_rc_flag = &ctl->self_rc;
   {
     Timer timer(ctx, 3, n);
     const int nbits = g->n_bucket_bits;
     if (directed) {
-      hipLaunchKernelGGL((k_adjacency<KeyT, true>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr, flags + 1);
+      hipLaunchKernelGGL((k_adjacency<KeyT, true>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr, self_rc_flag);
     } else if (staged_adjacency() && nbits <= 14 && 2 * g->k >= nbits + 4 &&
                key_bits(g) >= nbits + 2 + (nbits & 1) &&
                n / nb <= 4 * ((kRcWindowBytes - 4 * kRcSegs) / int64_t(sizeof(KeyT) + 6))) {
@@ -2748,18 +2997,16 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
         // later: u32 keys: the upper half of the chain-rank records; u64 keys (16-byte records): the
         // neighbour + link arrays (rc0 / rc1 and nbr are only written after level 2); the group ids
         // sit in the head array
-        RcRecord<KeyT>* tmp_rec = sizeof(KeyT) == 4 ? rec + n : reinterpret_cast<RcRecord<KeyT>*>(p->nbr);
+        RcRecord<KeyT>* tmp_rec = sizeof(RcRecord<KeyT>) == 8 ? rec + n : reinterpret_cast<RcRecord<KeyT>*>(p->nbr);
         uint16_t* tmp_g = reinterpret_cast<uint16_t*>(p->head);
         // intermediate records: u32 keys, the upper half of `info` (2n records of 8 bytes in 16n bytes);
         // u64 keys, nbr + link (carved back to back: 2 x al(8n) >= 16n); group ids in `head` (2n <= 4n bytes)
-        KSH_BOUND(sizeof(KeyT) == 4 ? size_t(2 * n) * sizeof(RcRecord<KeyT>) <= al(size_t(2 * n) * 8)
+        KSH_BOUND(sizeof(RcRecord<KeyT>) == 8 ? size_t(2 * n) * sizeof(RcRecord<KeyT>) <= al(size_t(2 * n) * 8)
                                     : reinterpret_cast<char*>(p->link) == reinterpret_cast<char*>(p->nbr) + al(size_t(2 * n) * 4) &&
                                           size_t(n) * sizeof(RcRecord<KeyT>) <= 2 * al(size_t(2 * n) * 4));
         KSH_BOUND(nb <= 65536);  // tmp_g holds group ids as u16
-        uint32_t* cursor = static_cast<uint32_t*>(arena_alloc(ctx, size_t(nb) * 4));
-        if (!cursor) return fail(KSH_INTERNAL, "scratch arena too small");
-        KSH_HIP(hipMemsetAsync(cursor, 0, size_t(nb) * 4, st));
-        constexpr int kPer = sizeof(KeyT) == 4 ? 4 : 2;
+        uint32_t* cursor = rc_cursor;
+        constexpr int kPer = sizeof(RcRecord<KeyT>) == 8 ? 4 : 2;
         hipLaunchKernelGGL((k_rc_scatter_l1<KeyT, kPer>), dim3(unsigned(rows)), dim3(kL1Threads), 0, st, set, nbits,
                            per_row, hist, goff, tmp_rec, tmp_g);
         hipLaunchKernelGGL((k_rc_scatter_l2<KeyT>), dim3(unsigned((n + kL2Tile - 1) / kL2Tile)), dim3(kL2Threads), 0,
@@ -2780,7 +3027,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       hipLaunchKernelGGL((k_rc_bounds<KeyT>), dim3(nblk(nb * 2 * kRcSegs)), dim3(256), 0, st, set, nbits, pb);
       {
         // (more than the 64 KB a kernel gets without asking; per context: the attribute is the device's)
-        const uint32_t bit = sizeof(KeyT) == 4 ? 1u : 2u;
+        const uint32_t bit = 1u << (sizeof(KeyT) == 2 ? 0 : sizeof(KeyT) == 4 ? 1 : 2);
         if (!(ctx->lds_opt_in & bit)) {
           const int bytes = int(kRcWindowBytes + 2048);
           KSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc<KeyT, 1024>),
@@ -2806,15 +3053,30 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
         return e && std::string(e) == "probe";
       }();
       if (fwd_probe) {
-        hipLaunchKernelGGL((k_adj_fwd<KeyT>), dim3(nblk(n)), dim3(256), 0, st, set, rc0, rc1, p->nbr, flags + 1);
+        hipLaunchKernelGGL((k_adj_fwd<KeyT>), dim3(nblk(n)), dim3(256), 0, st, set, rc0, rc1, p->nbr, self_rc_flag);
       } else {
         // the records are dead by now: the chunk bounds take their place
         const int64_t n_chunks = (n + kFwdChunk - 1) / kFwdChunk;
         int64_t* bounds = reinterpret_cast<int64_t*>(p->info);  // kFwdBounds * 8 bytes per 512 k-mers
         KSH_BOUND(size_t(n_chunks + 1) * kFwdBounds * 8 <= al(size_t(2 * n) * 8));
         hipLaunchKernelGGL((k_fwd_bounds<KeyT>), dim3(nblk(n_chunks + 1)), dim3(256), 0, st, set, n_chunks, bounds);
+        // KSH_FWD=pipe: persistent workgroups that prefetch the next chunk's windows under this chunk's search
+        static const bool fwd_pipe = [] {
+          const char* e = getenv("KSH_FWD");
+          return e && std::string(e) == "pipe";
+        }();
+        if (fwd_pipe) {
+          static const int n_cus = [] {
+            int dev = 0, cus = 256;
+            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+            return cus;
+          }();
+          const int64_t groups = std::min<int64_t>(n_chunks, int64_t(n_cus) * kFwdPipeGroupsPerCu);
+          hipLaunchKernelGGL((k_adj_fwd_pipe<KeyT>), dim3(unsigned(groups)), dim3(kFwdChunk), 0, st, set, bounds, n_chunks,
+                             rc0, rc1, p->nbr, self_rc_flag);
+        } else
         hipLaunchKernelGGL((k_adj_fwd_staged<KeyT>), dim3(unsigned(n_chunks)), dim3(kFwdChunk), 0, st, set, bounds,
-                           rc0, rc1, p->nbr, flags + 1);
+                           rc0, rc1, p->nbr, self_rc_flag);
 #ifdef KSH_FWD_DEBUG
         {
           unsigned long long h[8];
@@ -2828,7 +3090,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
 #endif
       }
     } else {
-      hipLaunchKernelGGL((k_adjacency<KeyT, false>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr, flags + 1);
+      hipLaunchKernelGGL((k_adjacency<KeyT, false>), dim3(nblk(n)), dim3(256), 0, st, set, p->nbr, self_rc_flag);
     }
   }
   if (directed)
@@ -2841,10 +3103,10 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   int64_t* b23 = p->c23 + n_hblocks;  // the front of c23; c01 still holds the ruler records
   // d_tot[0..1]: unitig counts by class; [2 .. 2 + kLenSums): k-mers the unitigs account for (partial
   // sums), [2 + kLenSums]: a ruler on a loop (an int)
-  int64_t* d_tot = static_cast<int64_t*>(arena_alloc(ctx, (3 + kLenSums) * 8));
+  int64_t* d_tot = ctl->tot;
   // the end k-mers, ascending (k_end_counts / k_end_fill): per-workgroup counts -> offsets, total
   int64_t* end_before = static_cast<int64_t*>(arena_alloc(ctx, size_t(n_hblocks + 1) * 8));
-  if (!d_tot || !end_before) return fail(KSH_INTERNAL, "scratch arena too small");
+  if (!end_before) return fail(KSH_INTERNAL, "scratch arena too small");
   uint32_t* ends = p->pos;  // (k_choose writes pos after the last kernel that reads the list)
   hipLaunchKernelGGL(k_end_counts, dim3(unsigned(n_hblocks)), dim3(256), 0, st, link, n, end_before);
   KSH_TRY(scan_exclusive_i64(ctx, end_before, end_before, n_hblocks, end_before + n_hblocks));
@@ -2855,8 +3117,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   KSH_HIP(hipStreamSynchronize(st));
   const int64_t n_ends = ctx->h_pinned[0];
   p->n_ends = n_ends;
-  for (bool stamped = rank_with_stamps();; stamped = true) {
-    int* changed = flags;
+  for (bool stamped = rank_with_stamps(), first_pass = true;; stamped = true, first_pass = false) {
     const int64_t ns2 = 2 * n;
     const int64_t n_dense = 2 * ((n + kRulerEvery - 1) / kRulerEvery);
     // with stamps: ruler records in c01 (n_dense * 8 <= 8n), chain starts in c23, both dead after
@@ -2883,10 +3144,9 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
           lr.mid = at4;
           lh.mid = at4 + size_t(kLogMidRulers) * n_dense;
           lr.long_walkers = lh.long_walkers = lh.mid + size_t(kLogMidHeads) * n_ends;  // n_dense + n_ends entries at most
-          lr.long_count = lh.long_count = reinterpret_cast<unsigned int*>(lr.long_walkers + n_dense + n_ends);
+          lr.long_count = lh.long_count = ctl->long_count;
           lr.long_tag = 0;
           lh.long_tag = kLongHead;
-          KSH_HIP(hipMemsetAsync(lr.long_count, 0, 8, st));
           lr.n_walkers = n_dense;
           lh.n_walkers = n_ends;
           lr.n_mid = kLogMidRulers;
@@ -2917,27 +3177,26 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       hipLaunchKernelGGL(k_l2_walk<true>, dim3(nblk(n_jump)), dim3(256), 0, st, rinfo, n_dense, r2, l2_head, l2_stamp);
       hipLaunchKernelGGL(k_l2_walk<false>, dim3(nblk(n_dense)), dim3(256), 0, st, rinfo, n_dense, r2, l2_head, l2_stamp);
     }
+    // log2(records) + 2 rounds end every chain (a loop of rulers never ends: k_rulers_done sees it); all of
+    // them are enqueued at once, a round after the last one that changed anything returns at its first load
     int max_rounds = 2;
     for (int64_t x = n_jump; x > 1; x >>= 1) max_rounds++;
-    const int batch = 4;
-    for (int round = 0; round < max_rounds;) {
-      KSH_HIP(hipMemsetAsync(changed, 0, sizeof(int), st));
-      for (int b = 0; b < batch && round < max_rounds; b++, round++) {
-        if (two_levels)
-          hipLaunchKernelGGL(k_l2_jump, dim3(nblk(n_jump)), dim3(256), 0, st, n_jump, r2, changed);
-        else
-          hipLaunchKernelGGL(k_ruler_jump, dim3(nblk(n_dense)), dim3(256), 0, st, n_dense, rinfo, changed);
-      }
-      KSH_HIP(hipMemcpyAsync(ctx->h_pinned, flags, 2 * sizeof(int), hipMemcpyDeviceToHost, st));
-      KSH_HIP(hipStreamSynchronize(st));
-      if (reinterpret_cast<int*>(ctx->h_pinned)[1])
-        return fail(KSH_INVALID_ARGUMENT, "the canonical set holds a k-mer that is its own reverse "
-                                          "complement (even k): not supported");
-      if (reinterpret_cast<int*>(ctx->h_pinned)[0] == 0) break;
+    max_rounds = std::min(max_rounds, kJumpRoundsMax);
+    if (!first_pass) {  // the stamping pass after a loop was found: its flags and sums start over
+      KSH_HIP(hipMemsetAsync(ctl->jump_live, 0, sizeof(ctl->jump_live), st));
+      KSH_HIP(hipMemsetAsync(d_tot, 0, (3 + kLenSums) * 8, st));
+      KSH_HIP(hipMemsetAsync(ctl->long_count, 0, sizeof(ctl->long_count), st));
+    }
+    for (int round = 0; round < max_rounds; round++) {
+      const int* prev = round ? &ctl->jump_live[round - 1] : nullptr;
+      if (two_levels)
+        hipLaunchKernelGGL(k_l2_jump, dim3(nblk(n_jump)), dim3(256), 0, st, n_jump, r2, prev, &ctl->jump_live[round]);
+      else
+        hipLaunchKernelGGL(k_ruler_jump, dim3(nblk(n_dense)), dim3(256), 0, st, n_dense, rinfo, prev,
+                           &ctl->jump_live[round]);
     }
     if (two_levels)
       hipLaunchKernelGGL(k_l2_resolve, dim3(nblk(n_dense)), dim3(256), 0, st, n_dense, r2, l2_head, l2_stamp, rinfo);
-    KSH_HIP(hipMemsetAsync(d_tot, 0, (3 + kLenSums) * 8, st));
     int* loop_flag = reinterpret_cast<int*>(d_tot + 2 + kLenSums);
     if (stamped) {
       hipLaunchKernelGGL(k_choose, dim3(nblk(n)), dim3(256), 0, st, p->info, rinfo, chain_info, n, directed,
@@ -2955,8 +3214,12 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     KSH_TRY(scan_exclusive_i64(ctx, b01, b01, n_hblocks, d_tot));
     KSH_TRY(scan_exclusive_i64(ctx, b23, b23, n_hblocks, d_tot + 1));
     KSH_HIP(hipGetLastError());
-    KSH_HIP(hipMemcpyAsync(ctx->h_pinned, d_tot, (3 + kLenSums) * 8, hipMemcpyDeviceToHost, st));
+    static_assert(offsetof(EncCtl, self_rc) == (3 + kLenSums) * 8 && (4 + kLenSums) <= 64, "one copy: tot + self_rc");
+    KSH_HIP(hipMemcpyAsync(ctx->h_pinned, d_tot, (4 + kLenSums) * 8, hipMemcpyDeviceToHost, st));
     KSH_HIP(hipStreamSynchronize(st));
+    if (*reinterpret_cast<int*>(ctx->h_pinned + 3 + kLenSums))
+      return fail(KSH_INVALID_ARGUMENT, "the canonical set holds a k-mer that is its own reverse "
+                                        "complement (even k): not supported");
     p->stamped = stamped;
     p->rinfo = rinfo;
     p->chain_info = chain_info;
@@ -2998,14 +3261,14 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   p->sc01 = carve<int64_t>(at, size_t(n_u + 1));
   p->sc2 = carve<int64_t>(at, size_t(n_u + 1));
   p->str_start = carve<int64_t>(at, size_t(n_u + 1));
-  p->sc_used = carve<unsigned long long>(at, 1);
-  p->any_live = carve<int>(at, 1);
+  p->sc_used = &ctl->sc_used;
 
   hipLaunchKernelGGL(k_unitig_fill, dim3(unsigned(n_hblocks)), dim3(256), 0, st, p->hcls, b01, b23, n, n0,
                      n0 + n1, n0 + n1 + n2, p->ori, p->hlen, p->hlast, p->uid, p->u_head, p->u_first,
                      p->u_last, p->u_len);
 
   int64_t ns = n_u;
+  int walk_rounds = 0;
   if (mode == 1) {
     hipLaunchKernelGGL(k_unitig_strings, dim3(nblk(n_u)), dim3(256), 0, st, p->u_len, n_u, g->k,
                        p->u_sid, p->u_koff, p->u_flip, p->lens, p->str_start);
@@ -3018,16 +3281,22 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     if (slow) {
       hipLaunchKernelGGL(k_match_slow, dim3(1), dim3(64), 0, st, p->edges, p->mate, n_u);
     } else {
-      while (true) {
-        KSH_HIP(hipMemsetAsync(p->any_live, 0, sizeof(int), st));
-        hipLaunchKernelGGL(k_match_best, dim3(nblk(2 * n_u)), dim3(256), 0, st, p->edges, p->mate,
-                           2 * n_u, directed, p->best_prio, p->best_w, p->any_live);
-        hipLaunchKernelGGL(k_match_commit, dim3(nblk(2 * n_u)), dim3(256), 0, st, p->best_prio,
-                           p->best_w, 2 * n_u, p->mate);
-        KSH_HIP(hipMemcpyAsync(ctx->h_pinned, p->any_live, sizeof(int), hipMemcpyDeviceToHost, st));
+      // rounds in batches of kMatchBatch, one look at the flags per batch (4..6 rounds observed: one look)
+      for (bool more = true; more;) {
+        if (p->rounds) KSH_HIP(hipMemsetAsync(ctl->match_live, 0, sizeof(ctl->match_live), st));
+        for (int r = 0; r < kMatchBatch; r++) {
+          hipLaunchKernelGGL(k_match_best, dim3(nblk(2 * n_u)), dim3(256), 0, st, p->edges, p->mate, 2 * n_u, directed,
+                             p->best_prio, p->best_w, r ? &ctl->match_live[r - 1] : nullptr, &ctl->match_live[r]);
+          hipLaunchKernelGGL(k_match_commit, dim3(nblk(2 * n_u)), dim3(256), 0, st, p->best_prio, p->best_w, 2 * n_u,
+                             &ctl->match_live[r], p->mate);
+        }
+        KSH_HIP(hipMemcpyAsync(ctx->h_pinned, ctl->match_live, kMatchBatch * sizeof(int), hipMemcpyDeviceToHost, st));
         KSH_HIP(hipStreamSynchronize(st));
-        p->rounds++;
-        if (*reinterpret_cast<int*>(ctx->h_pinned) == 0) break;
+        const int* live = reinterpret_cast<const int*>(ctx->h_pinned);
+        int ran = 0;
+        while (ran < kMatchBatch && live[ran]) ran++;
+        more = ran == kMatchBatch;
+        p->rounds += more ? kMatchBatch : ran + 1;  // (the round that found nothing counts, as before)
         if (p->rounds > 100000) return fail(KSH_INTERNAL, "matching did not converge");
       }
       // the path extension of fast = false never closes a loop; the greedy matching can:
@@ -3039,7 +3308,6 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       KSH_HIP(hipMemsetAsync(has_terminal, 0, size_t(n_u), st));
       hipLaunchKernelGGL(k_dsu_mark_terminals, dim3(nblk(n_u)), dim3(256), 0, st, dsu, p->mate, n_u, has_terminal);
       hipLaunchKernelGGL(k_dsu_open_paths, dim3(nblk(n_u)), dim3(256), 0, st, dsu, has_terminal, n_u, p->visited);
-      KSH_HIP(hipMemsetAsync(p->sc_used, 0, 8, st));
       hipLaunchKernelGGL(k_loop_cut, dim3(unsigned((n_u + 63) / 64)), dim3(64), 0, st, p->mate, n_u,
                          directed, p->visited, p->sc_nodes, p->sc_parent, p->sc_rank, p->sc_used);
     }
@@ -3048,43 +3316,45 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     unsigned long long* walk = p->best_prio;
     uint32_t* sid_at = p->best_w;
     hipLaunchKernelGGL(k_walk_init, dim3(nblk(2 * n_u)), dim3(256), 0, st, p->mate, p->u_len, 2 * n_u, walk);
-    for (int round = 0;; round += 4) {
-      KSH_HIP(hipMemsetAsync(p->any_live, 0, sizeof(int), st));
-      for (int b = 0; b < 4; b++)
-        hipLaunchKernelGGL(k_walk_jump, dim3(nblk(2 * n_u)), dim3(256), 0, st, 2 * n_u, walk, p->any_live);
-      KSH_HIP(hipMemcpyAsync(ctx->h_pinned, p->any_live, sizeof(int), hipMemcpyDeviceToHost, st));
-      KSH_HIP(hipStreamSynchronize(st));
-      if (*reinterpret_cast<int*>(ctx->h_pinned) == 0) break;
-      if (round > 64) return fail(KSH_INTERNAL, "the path cover still holds a loop");
-    }
+    // log2(2 n_u) + 2 rounds end every walk of a loop-free cover; enqueued at once (a round after the last
+    // one that changed anything returns at its first load), the last flag is looked at with the sizes below
+    walk_rounds = 2;
+    for (int64_t x = 2 * n_u; x > 1; x >>= 1) walk_rounds++;
+    walk_rounds = std::min(walk_rounds, kWalkRoundsMax);
+    for (int round = 0; round < walk_rounds; round++)
+      hipLaunchKernelGGL(k_walk_jump, dim3(nblk(2 * n_u)), dim3(256), 0, st, 2 * n_u, walk,
+                         round ? &ctl->walk_live[round - 1] : nullptr, &ctl->walk_live[round]);
     hipLaunchKernelGGL(k_string_starts, dim3(nblk(n_u)), dim3(256), 0, st, p->mate, p->u_len, walk, n_u,
                        directed, p->scls, p->s_nk);
     hipLaunchKernelGGL(k_string_counts, dim3(nblk(n_u)), dim3(256), 0, st, p->scls, n_u, slow, p->sc01,
                        p->sc2);
     arena_reset(ctx);
-    int64_t* d_t2 = static_cast<int64_t*>(arena_alloc(ctx, 16));
+    int64_t* d_t2 = ctl->t2;
     KSH_TRY(scan_exclusive_i64(ctx, p->sc01, p->sc01, n_u, d_t2));
     KSH_TRY(scan_exclusive_i64(ctx, p->sc2, p->sc2, n_u, d_t2 + 1));
-    KSH_HIP(hipMemcpyAsync(ctx->h_pinned, d_t2, 16, hipMemcpyDeviceToHost, st));
-    KSH_HIP(hipStreamSynchronize(st));
-    const int64_t s0 = ctx->h_pinned[0] & 0xFFFFFFFF, s1 = ctx->h_pinned[0] >> 32,
-                  s2 = ctx->h_pinned[1];
-    ns = s0 + s1 + s2;
-    hipLaunchKernelGGL(k_string_ids, dim3(nblk(n_u)), dim3(256), 0, st, n_u, p->scls, p->sc01, p->sc2, p->s_nk, s0,
-                       s0 + s1, slow, g->k, sid_at, p->lens, p->str_start);
+    // the strings' base counts land at their ids: n_strings <= n_u entries, the rest stay zero
+    KSH_HIP(hipMemsetAsync(p->str_start, 0, size_t(n_u + 1) * 8, st));
+    hipLaunchKernelGGL(k_string_ids, dim3(nblk(n_u)), dim3(256), 0, st, n_u, p->scls, p->sc01, p->sc2, p->s_nk, d_t2,
+                       slow, g->k, sid_at, p->lens, p->str_start);
     hipLaunchKernelGGL(k_string_assign, dim3(nblk(n_u)), dim3(256), 0, st, p->u_len, walk, n_u, p->scls, sid_at,
                        slow, p->u_sid, p->u_koff, p->u_flip);
   }
-  // string starts in bases
+  // string starts in bases (a scan over n_u slots: the slots past the last string hold zero)
   arena_reset(ctx);
-  KSH_TRY(scan_exclusive_i64(ctx, p->str_start, p->str_start, ns, p->str_start + ns));
+  KSH_TRY(scan_exclusive_i64(ctx, p->str_start, p->str_start, n_u, &ctl->n_bases));
   hipLaunchKernelGGL(k_unitig_place, dim3(nblk(n_u)), dim3(256), 0, st, p->u_len, p->u_sid, p->u_koff,
                      p->u_flip, p->str_start, p->lens, p->u_head, n_u, reinterpret_cast<UnitigPlace*>(p->c01));
   KSH_HIP(hipGetLastError());
-  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, p->str_start + ns, 8, hipMemcpyDeviceToHost, st));
+  // one look at everything the unitig level left behind: strings by class, bases, the last walk round's flag
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, ctl->t2, 3 * 8, hipMemcpyDeviceToHost, st));
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned + 3, &ctl->walk_live[walk_rounds > 0 ? walk_rounds - 1 : 0], sizeof(int),
+                         hipMemcpyDeviceToHost, st));
   KSH_HIP(hipStreamSynchronize(st));
+  if (walk_rounds > 0 && *reinterpret_cast<int*>(ctx->h_pinned + 3))
+    return fail(KSH_INTERNAL, "the path cover still holds a loop");
+  if (mode != 1) ns = (ctx->h_pinned[0] & 0xFFFFFFFF) + (ctx->h_pinned[0] >> 32) + ctx->h_pinned[1];
   p->n_strings = ns;
-  p->n_bases = ctx->h_pinned[0];
+  p->n_bases = ctx->h_pinned[2];
   *n_strings = p->n_strings;
   *n_bases = p->n_bases;
   return KSH_OK;
@@ -3172,8 +3442,7 @@ int ksh_spss_encode_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* se
   if (set->n_keys < 0 || !set->d_offsets || (set->n_keys > 0 && !set->d_keys))
     return fail(KSH_INVALID_ARGUMENT, "bad set view");
   KSH_HIP(hipSetDevice(ctx->device));
-  return g->key_bytes == 4 ? encode_plan_t<uint32_t>(ctx, g, set, directed, mode, n_strings, n_bases)
-                           : encode_plan_t<uint64_t>(ctx, g, set, directed, mode, n_strings, n_bases);
+  return KSH_BY_KEY(g->key_bytes, encode_plan_t, ctx, g, set, directed, mode, n_strings, n_bases);
 }
 
 int ksh_spss_encode_write(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens) {
@@ -3182,8 +3451,7 @@ int ksh_spss_encode_write(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens) {
   if (!p) return fail(KSH_FAILED_PRECONDITION, "ksh_spss_encode_write without ksh_spss_encode_plan");
   if (p->n > 0 && (!d_words || !d_lens)) return fail(KSH_INVALID_ARGUMENT, "NULL output");
   KSH_HIP(hipSetDevice(ctx->device));
-  return p->g.key_bytes == 4 ? encode_write_t<uint32_t>(ctx, d_words, d_lens)
-                             : encode_write_t<uint64_t>(ctx, d_words, d_lens);
+  return KSH_BY_KEY(p->g.key_bytes, encode_write_t, ctx, d_words, d_lens);
 }
 
 int ksh_spss_encode_stats(ksh_ctx* ctx, int64_t stats[4]) {

@@ -28,6 +28,12 @@ int fail(int code, const char* fmt, ...);
                          hipGetErrorString(err__), __FILE__, __LINE__);                 \
   } while (0)
 
+// Device key types: the reference's KeyType (lib/core/kmer_set.h:20-31) -- uint16_t for (15, 14), uint32_t for
+// (19, 10) and (23, 14), uint64_t for (31, 14) -- chosen by ksh_geom::key_bytes at run time.
+#define KSH_BY_KEY(key_bytes, FN, ...)                                   \
+  ((key_bytes) == 2 ? FN<uint16_t>(__VA_ARGS__)                          \
+                    : (key_bytes) == 4 ? FN<uint32_t>(__VA_ARGS__) : FN<uint64_t>(__VA_ARGS__))
+
 #define KSH_TRY(expr)              \
   do {                             \
     int rc__ = (expr);             \
@@ -99,6 +105,10 @@ struct ksh_ctx {
   std::multimap<size_t, void*> pool_free_blocks;
   std::unordered_map<void*, size_t> pool_sizes;
   size_t pool_cached_bytes = 0;
+  // test hook (KSH_FAIL_INJECT, ksh_kss_build_owned): once inject_skip allocations of at least
+  // inject_min_bytes have succeeded, every further one fails; -1: off
+  long long inject_skip = -1;
+  size_t inject_min_bytes = 0;
 
   // kernel timers: when enabled, every launch of a timed kind gets its own event
   // pair from a pool; ksh_ctx_timing_read sums them after a stream sync.

@@ -75,7 +75,24 @@ struct ksh_kss {
   // have to return to are parked instead of freed
   const std::unordered_set<void*>* keep_alive = nullptr;
   std::vector<void*>* graveyard = nullptr;
-  int64_t checks_deferred = 0, rollbacks = 0, sets_migrated = 0;
+  int64_t checks_deferred = 0, rollbacks = 0, sets_migrated = 0, weight_gathers = 0;
+  // A rank-local failure of the owner-sharded build (an allocation, a decode, a merge, an encode): the rank
+  // goes on FOLLOWING THE EXCHANGE PROTOCOL with empty stand-ins for what it could not build -- its peers
+  // are heading for exchanges it must not leave them alone in -- every all-gather carries every rank's
+  // status word, and all ranks return the error together after the next one (failed_together).  A
+  // failure that keeps a rank from following the protocol at all (its replica of the control loop, the
+  // transport itself) ends in comm_abort instead (ksh_kss_build_owned).
+  int local_rc = KSH_OK;
+  std::string local_msg;
+  bool failed_together = false;
+  int64_t *zero_off = nullptr, *xfer_off = nullptr;  // 2^N + 1 zeros: what is sent for a set the rank does not have; where offsets arrive
+  int64_t *gx_send = nullptr, *gx_recv = nullptr;    // device staging of gather_i64, allocated once: a gather cannot fail for want of memory
+  size_t gx_cap = 0;                                 // int64 per rank
+  struct Exchange {                                  // the two deferred check exchanges that can be in flight
+    int64_t *d_send = nullptr, *d_recv = nullptr, *h_recv = nullptr;
+    hipEvent_t arrived = nullptr;
+  } xchg[2];
+  size_t xchg_cap = 0;
 };
 
 namespace ksh {
@@ -100,6 +117,19 @@ static void retire(ksh_kss* k, void* p) {
   if (k->keep_alive && k->keep_alive->count(p)) k->graveyard->push_back(p);
   else pool_free(k->ctx, p);
 }
+
+static bool alive(const ksh_kss* k) { return k->local_rc == KSH_OK; }
+// Records the first rank-local failure (the message of the failing call is the thread's last error).
+static void poison(ksh_kss* k, int rc) {
+  if (rc == KSH_OK || k->local_rc != KSH_OK) return;
+  k->local_rc = rc;
+  k->local_msg = ksh_last_error();
+}
+// A rank-local step: skipped once the rank has failed, its failure recorded instead of returned.
+#define KSH_LOCAL(k, expr)             \
+  do {                                 \
+    if (alive(k)) poison((k), (expr)); \
+  } while (0)
 
 static void free_set(ksh_ctx* ctx, KssSet* s) {
   pool_free(ctx, s->off);
@@ -319,22 +349,41 @@ __global__ __launch_bounds__(256) void k_sample_copy(const int64_t* __restrict__
 
 static size_t a16(size_t x) { return (x + 15) & ~size_t(15); }
 
-// All-gather of `count` int64 per rank between host vectors, through device scratch.
+// All-gather of `count` int64 per rank between host vectors, through device staging allocated once per
+// build.  Every rank's status word travels with its values: if any rank has failed, ALL ranks return an
+// error from here (the failed rank its own, the others "rank r failed"), so nobody goes on alone.
 static int gather_i64(ksh_kss* k, const std::vector<int64_t>& send, std::vector<int64_t>* recv) {
   ksh_ctx* ctx = k->ctx;
-  const size_t bytes = send.size() * 8;
-  recv->assign(send.size() * size_t(k->world), 0);
-  if (bytes == 0) return KSH_OK;
-  void *d_send = nullptr, *d_recv = nullptr;
-  KSH_TRY(pool_alloc(ctx, bytes, &d_send));
-  KSH_TRY(pool_alloc(ctx, bytes * size_t(k->world), &d_recv));
-  KSH_HIP(hipMemcpyAsync(d_send, send.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
-  KSH_TRY(comm_allgather(k->comm, d_send, d_recv, bytes));
-  KSH_HIP(hipMemcpyAsync(recv->data(), d_recv, bytes * size_t(k->world), hipMemcpyDeviceToHost, ctx->stream));
+  const size_t count = send.size() + 1, world = size_t(k->world);
+  recv->assign(send.size() * world, 0);
+  if (count > k->gx_cap) {  // (sized for the build's largest gather when it starts; growing may fail: then the rank leaves, see comm_abort)
+    void *a = nullptr, *b = nullptr;
+    KSH_TRY(pool_alloc(ctx, count * 2 * 8, &a));
+    KSH_TRY(pool_alloc(ctx, count * 2 * 8 * world, &b));
+    pool_free(ctx, k->gx_send);
+    pool_free(ctx, k->gx_recv);
+    k->gx_send = static_cast<int64_t*>(a);
+    k->gx_recv = static_cast<int64_t*>(b);
+    k->gx_cap = count * 2;
+  }
+  std::vector<int64_t> out(send), in(count * world);
+  out.push_back(int64_t(k->local_rc));
+  KSH_HIP(hipMemcpyAsync(k->gx_send, out.data(), count * 8, hipMemcpyHostToDevice, ctx->stream));
+  KSH_TRY(comm_allgather(k->comm, k->gx_send, k->gx_recv, count * 8));
+  KSH_HIP(hipMemcpyAsync(in.data(), k->gx_recv, count * 8 * world, hipMemcpyDeviceToHost, ctx->stream));
   KSH_HIP(hipStreamSynchronize(ctx->stream));
-  pool_free(ctx, d_send);
-  pool_free(ctx, d_recv);
-  k->gather_bytes += int64_t(bytes);
+  k->gather_bytes += int64_t(count * 8);
+  int failed = -1;
+  for (size_t r = 0; r < world; r++) {
+    std::copy(in.begin() + r * count, in.begin() + r * count + send.size(), recv->begin() + r * send.size());
+    if (in[r * count + send.size()] != 0 && failed < 0) failed = int(r);
+  }
+  if (failed >= 0) {
+    k->failed_together = true;
+    if (!alive(k)) return fail(k->local_rc, "%s", k->local_msg.c_str());
+    return fail(KSH_INTERNAL, "rank %d failed (status %lld); every rank gives the build up", failed,
+                (long long)in[size_t(failed) * count + send.size()]);
+  }
   return KSH_OK;
 }
 
@@ -370,46 +419,69 @@ static int make_sample(ksh_kss* k, const KssSet& full, const uint8_t* d_flag, co
   return KSH_OK;
 }
 
-static int send_set(ksh_kss* k, const KssSet& s, int peer) {
+// A set goes to `peer`: its offsets, then its keys.  A rank that does not have the set (it failed to build
+// it) sends an empty one in its place.
+static int send_set_on(ksh_kss* k, const KssSet& s, int peer, bool side) {
   const int64_t nb = n_buckets(&k->g);
-  KSH_TRY(comm_send(k->comm, s.off, size_t(nb + 1) * 8, peer));
-  KSH_TRY(comm_send(k->comm, s.keys, size_t(s.n) * k->g.key_bytes, peer));
-  k->p2p_bytes_sent += (nb + 1) * 8 + s.n * k->g.key_bytes;
+  const int64_t* off = s.off ? s.off : k->zero_off;
+  const int64_t n = s.off ? s.n : 0;
+  if (side) {
+    KSH_TRY(comm_side_send(k->comm, off, size_t(nb + 1) * 8, peer));
+    KSH_TRY(comm_side_send(k->comm, s.keys, size_t(n) * k->g.key_bytes, peer));
+  } else {
+    KSH_TRY(comm_send(k->comm, off, size_t(nb + 1) * 8, peer));
+    KSH_TRY(comm_send(k->comm, s.keys, size_t(n) * k->g.key_bytes, peer));
+  }
+  k->p2p_bytes_sent += (nb + 1) * 8 + n * k->g.key_bytes;
   k->p2p_sets++;
   return KSH_OK;
 }
+static int send_set(ksh_kss* k, const KssSet& s, int peer) { return send_set_on(k, s, peer, false); }
 
-static int recv_set(ksh_kss* k, int peer, KssSet* out) {
+// A set arrives from `peer` (side: over the side channel, the context's stream picks the data up when it
+// has arrived).  A rank that cannot hold it -- an allocation fails: the rank is poisoned -- still takes
+// the bytes off the wire, into its encode scratch (which it will not use again), so that the sender is
+// not left in its send; *out stays empty then.
+static int recv_set_on(ksh_kss* k, int peer, KssSet* out, bool side) {
   ksh_ctx* ctx = k->ctx;
   const int64_t nb = n_buckets(&k->g);
-  KSH_TRY(alloc_offsets(ctx, &k->g, out));
-  KSH_TRY(comm_recv(k->comm, out->off, size_t(nb + 1) * 8, peer));
-  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, out->off + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
+  *out = KssSet{};
+  if (side) {
+    KSH_TRY(comm_side_recv(k->comm, k->xfer_off, size_t(nb + 1) * 8, peer));
+    KSH_TRY(comm_side_join_main(k->comm));
+  } else {
+    KSH_TRY(comm_recv(k->comm, k->xfer_off, size_t(nb + 1) * 8, peer));
+  }
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, k->xfer_off + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
   KSH_HIP(hipStreamSynchronize(ctx->stream));
   const int64_t n = ctx->h_pinned[0];
-  KSH_TRY(alloc_keys(ctx, &k->g, n, out));
-  KSH_TRY(comm_recv(k->comm, out->keys, size_t(n) * k->g.key_bytes, peer));
+  KssSet s;
+  KSH_LOCAL(k, alloc_offsets(ctx, &k->g, &s));
+  KSH_LOCAL(k, alloc_keys(ctx, &k->g, n, &s));
+  void* dst = s.keys;
+  if (!alive(k)) {
+    free_set(ctx, &s);
+    const size_t need = size_t(n) * k->g.key_bytes;
+    dst = ctx->slot[kSlotEncode];
+    if (need > ctx->slot_bytes[kSlotEncode])
+      return fail(KSH_INTERNAL, "rank %d cannot take %zu bytes sent to it: %s", k->rank, need, k->local_msg.c_str());
+  } else {
+    KSH_HIP(hipMemcpyAsync(s.off, k->xfer_off, size_t(nb + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  if (side) {
+    KSH_TRY(comm_side_recv(k->comm, dst, size_t(n) * k->g.key_bytes, peer));
+    KSH_TRY(comm_side_join_main(k->comm));
+  } else {
+    KSH_TRY(comm_recv(k->comm, dst, size_t(n) * k->g.key_bytes, peer));
+  }
+  if (!alive(k)) KSH_HIP(hipStreamSynchronize(ctx->stream));  // (the scratch is free again when this returns)
   k->p2p_bytes_received += (nb + 1) * 8 + n * k->g.key_bytes;
+  s.n = alive(k) ? n : 0;
+  *out = s;
   return KSH_OK;
 }
-
-// The same over the side channel (a set handed over for encoding): the context's stream picks the data up
-// when it has arrived.
-static int recv_set_side(ksh_kss* k, int peer, KssSet* out) {
-  ksh_ctx* ctx = k->ctx;
-  const int64_t nb = n_buckets(&k->g);
-  KSH_TRY(alloc_offsets(ctx, &k->g, out));
-  KSH_TRY(comm_side_recv(k->comm, out->off, size_t(nb + 1) * 8, peer));
-  KSH_TRY(comm_side_join_main(k->comm));
-  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, out->off + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
-  KSH_HIP(hipStreamSynchronize(ctx->stream));
-  const int64_t n = ctx->h_pinned[0];
-  KSH_TRY(alloc_keys(ctx, &k->g, n, out));
-  KSH_TRY(comm_side_recv(k->comm, out->keys, size_t(n) * k->g.key_bytes, peer));
-  KSH_TRY(comm_side_join_main(k->comm));
-  k->p2p_bytes_received += (nb + 1) * 8 + n * k->g.key_bytes;
-  return KSH_OK;
-}
+static int recv_set(ksh_kss* k, int peer, KssSet* out) { return recv_set_on(k, peer, out, false); }
+static int recv_set_side(ksh_kss* k, int peer, KssSet* out) { return recv_set_on(k, peer, out, true); }
 
 // Weight table over the samples (every rank computes all of it: 2 % of the data, no exchange).
 static int sample_weights(ksh_kss* k, const std::vector<int32_t>& ids, const std::vector<std::pair<int, int>>& pairs,
@@ -425,6 +497,42 @@ static int sample_weights(ksh_kss* k, const std::vector<int32_t>& ids, const std
   if (!pairs.empty())
     KSH_TRY(ksh_pair_weights(k->ctx, &k->g, views.data(), int32_t(views.size()), ids.data(), int32_t(ids.size()),
                              flat.data(), int32_t(pairs.size()), out->data()));
+  return KSH_OK;
+}
+
+// The same table with the pair list dealt out: the pairs are independent (kmer_set_set.h:205-216,385-425),
+// every rank weighs a contiguous share on its replica of the samples and ONE all-gather of int64 per
+// iteration puts the table on all of them -- the exchange north_star names (KSH_OWNED_WEIGHTS=sharded; the
+// default computes all of it on every rank and exchanges nothing: at 2 % of the data the all-gather's
+// latency, and the lock step it puts the ranks in, cost more than the weighing).  A rank
+// whose share fails reports -1 slots and its status in the same exchange.
+static int sample_weights_sharded(ksh_kss* k, const std::vector<int32_t>& ids, const std::vector<std::pair<int, int>>& pairs,
+                                  std::vector<int64_t>* out) {
+  out->assign(pairs.size(), 0);
+  if (pairs.empty()) return KSH_OK;
+  const size_t world = size_t(k->world), per = (pairs.size() + world - 1) / world;
+  const size_t lo = std::min(pairs.size(), per * size_t(k->rank)), hi = std::min(pairs.size(), lo + per);
+  std::vector<int64_t> send(per, -1), recv;
+  if (hi > lo && alive(k)) {
+    std::vector<ksh_set_view> views;
+    for (const KssSet& s : k->samples) views.push_back(view_of(s));
+    std::vector<int32_t> flat;
+    for (size_t q = lo; q < hi; q++) {
+      flat.push_back(pairs[q].first);
+      flat.push_back(pairs[q].second);
+    }
+    std::vector<int64_t> mine(hi - lo, 0);
+    poison(k, ksh_pair_weights(k->ctx, &k->g, views.data(), int32_t(views.size()), ids.data(), int32_t(ids.size()),
+                               flat.data(), int32_t(hi - lo), mine.data()));
+    if (alive(k)) std::copy(mine.begin(), mine.end(), send.begin());
+  }
+  KSH_TRY(gather_i64(k, send, &recv));
+  k->weight_gathers++;
+  for (size_t q = 0; q < pairs.size(); q++) {
+    const int64_t w = recv[(q / per) * per + q % per];
+    if (w < 0) return fail(KSH_INTERNAL, "rank %zu did not report the weight of pair %zu", q / per, q);
+    (*out)[q] = w;
+  }
   return KSH_OK;
 }
 
@@ -445,31 +553,27 @@ static int ensure_compacts_owned(ksh_kss* k) {
     if (!k->compacts[i].valid) stale.push_back(i);
   if (stale.empty()) return KSH_OK;
   std::vector<int64_t> send(3 * stale.size(), -1), recv;
-  int local_rc = KSH_OK;
-  std::string local_msg;
   for (size_t q = 0; q < stale.size(); q++) {
     const size_t i = stale[q];
     KssCompact c;
     c.holder = k->owner[i];
-    if (k->owner[i] == k->rank && local_rc == KSH_OK) {
+    if (k->owner[i] == k->rank && alive(k) && k->sets[i].off) {
       // a failure must not keep this rank from the all-gather: its slots stay -1, every rank errors out after it
-      local_rc = encode_set(k->ctx, &k->g, k->sets[i], k->canonical, &c);
-      if (local_rc == KSH_OK) {
+      poison(k, encode_set(k->ctx, &k->g, k->sets[i], k->canonical, &c));
+      if (alive(k)) {
         k->n_encodes++;
         k->n_encoded_kmers += k->sets[i].n;
         send[3 * q] = c.n_strings;
         send[3 * q + 1] = c.n_bases;
         send[3 * q + 2] = c.size;
       } else {
-        local_msg = ksh_last_error();
         c = KssCompact{};
       }
       c.holder = k->rank;
     }
     k->compacts[i] = c;
   }
-  KSH_TRY(gather_i64(k, send, &recv));
-  if (local_rc != KSH_OK) return fail(local_rc, "%s", local_msg.c_str());
+  KSH_TRY(gather_i64(k, send, &recv));  // (returns the error on every rank if one of them has failed)
   for (size_t q = 0; q < stale.size(); q++) {
     KssCompact& c = k->compacts[stale[q]];
     const int64_t* from = recv.data() + size_t(c.holder) * send.size() + 3 * q;
@@ -492,6 +596,35 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
   k->owned = true;
   k->owner.assign(owners, owners + n_inputs);
 
+  // ---- what the exchange protocol itself needs, allocated before anything can fail: the staging of the
+  // small all-gathers, the two deferred check exchanges, an empty set's offsets and a landing place for
+  // incoming ones.  (A rank that cannot even get these leaves through comm_abort.)
+  {
+    k->gx_cap = std::max<size_t>(4096, 8 * size_t(n_inputs) + 64);
+    k->xchg_cap = 3 * (4 * size_t(n_inputs) + 64) + 1;
+    KSH_TRY(pool_alloc(ctx, k->gx_cap * 8, reinterpret_cast<void**>(&k->gx_send)));
+    KSH_TRY(pool_alloc(ctx, k->gx_cap * 8 * size_t(world), reinterpret_cast<void**>(&k->gx_recv)));
+    KSH_TRY(pool_alloc(ctx, size_t(nb + 1) * 8, reinterpret_cast<void**>(&k->zero_off)));
+    KSH_TRY(pool_alloc(ctx, size_t(nb + 1) * 8, reinterpret_cast<void**>(&k->xfer_off)));
+    KSH_HIP(hipMemsetAsync(k->zero_off, 0, size_t(nb + 1) * 8, ctx->stream));
+    for (ksh_kss::Exchange& x : k->xchg) {
+      KSH_TRY(pool_alloc(ctx, k->xchg_cap * 8, reinterpret_cast<void**>(&x.d_send)));
+      KSH_TRY(pool_alloc(ctx, k->xchg_cap * 8 * size_t(world), reinterpret_cast<void**>(&x.d_recv)));
+      KSH_HIP(hipHostMalloc(reinterpret_cast<void**>(&x.h_recv), k->xchg_cap * 8 * size_t(world), hipHostMallocDefault));
+      KSH_HIP(hipEventCreateWithFlags(&x.arrived, hipEventDisableTiming));
+    }
+  }
+  // KSH_FAIL_INJECT=rank:skip:min_bytes (tests): on that rank, once `skip` allocations of at least min_bytes
+  // have succeeded, every further one fails -- a GPU that has run out of memory for large blocks
+  if (const char* e = getenv("KSH_FAIL_INJECT")) {
+    int r = -1;
+    long long skip = 0, min_bytes = 0;
+    if (sscanf(e, "%d:%lld:%lld", &r, &skip, &min_bytes) == 3 && r == rank) {
+      ctx->inject_skip = skip;
+      ctx->inject_min_bytes = size_t(min_bytes);
+    }
+  }
+
   // ---- inputs: decoded by their owners only
   for (int32_t i = 0; i < n_inputs; i++) {
     KssCompact c;
@@ -499,15 +632,16 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
     k->sets.emplace_back();
     if (c.holder == rank) {
       if (!inputs[i].d_words && inputs[i].n_bases > 0)
-        return fail(KSH_INVALID_ARGUMENT, "rank %d owns input %d but was not given its container", rank, i);
+        poison(k, fail(KSH_INVALID_ARGUMENT, "rank %d owns input %d but was not given its container", rank, i));
       c.words = const_cast<uint64_t*>(inputs[i].d_words);
       c.lens = const_cast<uint32_t*>(inputs[i].d_lens);
       c.n_strings = inputs[i].n_strings;
       c.n_bases = inputs[i].n_bases;
       c.owned = false;
-      KSH_TRY(ksh_spss_size(ctx, g, &inputs[i], &c.size));
+      KSH_LOCAL(k, ksh_spss_size(ctx, g, &inputs[i], &c.size));
       PhaseTimer pt(k, 0);
-      KSH_TRY(decode_to_set(ctx, g, &inputs[i], k->canonical, &k->sets.back()));
+      KSH_LOCAL(k, decode_to_set(ctx, g, &inputs[i], k->canonical, &k->sets.back()));
+      if (!alive(k)) free_set(ctx, &k->sets.back());
     }
     k->compacts.push_back(c);
   }
@@ -535,20 +669,22 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
     for (int32_t b : ids) flag[size_t(b)] = 1;
     uint8_t* d_flag = nullptr;
     int32_t* d_ids = nullptr;
-    KSH_TRY(pool_alloc(ctx, size_t(nb), reinterpret_cast<void**>(&d_flag)));
-    KSH_TRY(pool_alloc(ctx, std::max<size_t>(ids.size() * 4, 16), reinterpret_cast<void**>(&d_ids)));
-    KSH_HIP(hipMemcpyAsync(d_flag, flag.data(), size_t(nb), hipMemcpyHostToDevice, ctx->stream));
-    KSH_HIP(hipMemcpyAsync(d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    KSH_LOCAL(k, pool_alloc(ctx, size_t(nb), reinterpret_cast<void**>(&d_flag)));
+    KSH_LOCAL(k, pool_alloc(ctx, std::max<size_t>(ids.size() * 4, 16), reinterpret_cast<void**>(&d_ids)));
+    if (alive(k)) {
+      KSH_HIP(hipMemcpyAsync(d_flag, flag.data(), size_t(nb), hipMemcpyHostToDevice, ctx->stream));
+      KSH_HIP(hipMemcpyAsync(d_ids, ids.data(), ids.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    }
     // sample offsets of my inputs and their key counts
     std::vector<int64_t*> my_off(size_t(n_inputs), nullptr);
     std::vector<int64_t> my_n(size_t(n_inputs), -1), all_n;
     for (int32_t i = 0; i < n_inputs; i++) {
       if (k->owner[size_t(i)] != rank) continue;
-      KSH_TRY(pool_alloc(ctx, size_t(nb + 1) * 8, reinterpret_cast<void**>(&my_off[size_t(i)])));
-      KSH_TRY(extract_sample(k, k->sets[size_t(i)], d_flag, d_ids, int32_t(ids.size()), my_off[size_t(i)],
-                             &my_n[size_t(i)]));
+      KSH_LOCAL(k, pool_alloc(ctx, size_t(nb + 1) * 8, reinterpret_cast<void**>(&my_off[size_t(i)])));
+      KSH_LOCAL(k, extract_sample(k, k->sets[size_t(i)], d_flag, d_ids, int32_t(ids.size()), my_off[size_t(i)],
+                                  &my_n[size_t(i)]));
     }
-    KSH_TRY(gather_i64(k, my_n, &all_n));
+    KSH_TRY(gather_i64(k, my_n, &all_n));  // (every rank was alive up to here, or all of them return now)
     std::vector<int64_t> n_of(size_t(n_inputs), 0);
     for (int32_t i = 0; i < n_inputs; i++)
       n_of[size_t(i)] = all_n[size_t(k->owner[size_t(i)]) * size_t(n_inputs) + size_t(i)];
@@ -562,8 +698,13 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
     size_t slot = 16;
     for (size_t p : payload) slot = std::max(slot, p);
     char* d_send = nullptr;
-    KSH_TRY(pool_alloc(ctx, slot, reinterpret_cast<void**>(&d_send)));
-    KSH_HIP(hipMalloc(reinterpret_cast<void**>(&k->sample_block), slot * size_t(world)));
+    KSH_LOCAL(k, pool_alloc(ctx, slot, reinterpret_cast<void**>(&d_send)));
+    if (alive(k) && hipMalloc(reinterpret_cast<void**>(&k->sample_block), slot * size_t(world)) != hipSuccess)
+      poison(k, fail(KSH_INTERNAL, "hipMalloc(%zu) of the samples' receive buffer failed", slot * size_t(world)));
+    {  // the payload exchange needs its buffers on every rank: agree on that first
+      std::vector<int64_t> none, unused;
+      KSH_TRY(gather_i64(k, none, &unused));
+    }
     for (int32_t i = 0; i < n_inputs; i++) {
       if (k->owner[size_t(i)] != rank) continue;
       char* dst = d_send + at_in_payload[size_t(i)];
@@ -591,6 +732,14 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
     pool_free(ctx, d_ids);
   }
 
+  // KSH_OWNED_WEIGHTS=sharded: the weight tables by pair list + one all-gather of int64 per iteration
+  static const bool shard_weights = [] {
+    const char* e = getenv("KSH_OWNED_WEIGHTS");
+    return e && std::string(e) == "sharded";
+  }();
+  const auto weigh = [&](const std::vector<std::pair<int, int>>& pairs, std::vector<int64_t>* w) {
+    return shard_weights && world > 1 ? sample_weights_sharded(k, ids, pairs, w) : sample_weights(k, ids, pairs, w);
+  };
   std::map<std::pair<int, int>, int64_t> weights;
   {
     std::vector<std::pair<int, int>> pairs;
@@ -599,7 +748,7 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
     std::vector<int64_t> w;
     {
       PhaseTimer pt(k, 1);
-      KSH_TRY(sample_weights(k, ids, pairs, &w));
+      KSH_TRY(weigh(pairs, &w));
     }
     for (size_t i = 0; i < pairs.size(); i++) weights[pairs[i]] = w[i];
     k->initial_weights = w;
@@ -646,8 +795,6 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
     int id = 0, iteration = 0;
     std::vector<size_t> stale;
     std::vector<int64_t> send;
-    int local_rc = KSH_OK;
-    std::string local_msg;
     // the state at the check
     std::vector<KssSet> sets, samples;
     std::vector<bool> sample_pooled;
@@ -658,10 +805,7 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
     size_t n_rows = 0, n_exec = 0;
     std::unordered_set<void*> alive;
     std::vector<void*> graveyard;
-    // its exchange, started at the check, waited for at the next one
-    void *d_send = nullptr, *d_recv = nullptr;
-    int64_t* h_recv = nullptr;
-    hipEvent_t arrived = nullptr;
+    // its exchange, started at the check, waited for at the next one: k->xchg[id & 1]
   } pend;
   std::vector<int> pending_of(k->compacts.size(), -1);  // the unresolved check that covers a node's SPSS, or -1
   int n_checks = 0;
@@ -707,7 +851,6 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
     for (size_t q = 0; q < k->compacts.size(); q++)
       if (!k->compacts[q].valid && pending_of[q] < 0) pd->stale.push_back(q);
     pd->send.assign(3 * pd->stale.size(), -1);
-    pd->local_rc = KSH_OK;
     const size_t n_tasks = pd->stale.size();
     std::vector<int> encoder(n_tasks);
     std::vector<double> cost(n_tasks);
@@ -749,9 +892,9 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
       const size_t node = pd->stale[q];
       KssCompact c;
       c.valid = false;
-      if (pd->local_rc == KSH_OK) {
-        pd->local_rc = encode_set(ctx, g, k->sets[node], k->canonical, &c);
-        if (pd->local_rc == KSH_OK) {
+      if (alive(k) && k->sets[node].off) {  // (a failed rank's slots stay -1; its status travels with them)
+        poison(k, encode_set(ctx, g, k->sets[node], k->canonical, &c));
+        if (alive(k)) {
           c.valid = false;  // known here, not yet everywhere
           k->n_encodes++;
           k->n_encoded_kmers += k->sets[node].n;
@@ -759,7 +902,6 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
           pd->send[3 * q + 1] = c.n_bases;
           pd->send[3 * q + 2] = c.size;
         } else {
-          pd->local_msg = ksh_last_error();
           c = KssCompact{};
           c.valid = false;
         }
@@ -773,11 +915,7 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
       const size_t node = pd->stale[q];
       if (encoder[q] == k->owner[node]) continue;
       if (k->owner[node] == rank) {
-        const KssSet& st = k->sets[node];
-        KSH_TRY(comm_side_send(k->comm, st.off, size_t(nb + 1) * 8, encoder[q]));
-        KSH_TRY(comm_side_send(k->comm, st.keys, size_t(st.n) * g->key_bytes, encoder[q]));
-        k->p2p_bytes_sent += (nb + 1) * 8 + st.n * g->key_bytes;
-        k->p2p_sets++;
+        KSH_TRY(send_set_on(k, k->sets[node], encoder[q], true));
         k->sets_migrated++;
         given.push_back(node);
       }
@@ -818,32 +956,36 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
   // a check's exchange starts right after the rank's encodes, on the transport's side channel: it
   // completes when the last rank has got that far, while this one is already in the next interval
   const auto start_exchange = [&](Pending* pd) {
+    ksh_kss::Exchange& x = k->xchg[pd->id & 1];
+    pd->send.push_back(int64_t(k->local_rc));  // the rank's status word, behind its values
     const size_t bytes = pd->send.size() * 8;
-    if (bytes == 0) return KSH_OK;
-    KSH_TRY(pool_alloc(ctx, bytes, &pd->d_send));
-    KSH_TRY(pool_alloc(ctx, bytes * size_t(world), &pd->d_recv));
-    KSH_HIP(hipHostMalloc(reinterpret_cast<void**>(&pd->h_recv), bytes * size_t(world), hipHostMallocDefault));
-    KSH_HIP(hipEventCreateWithFlags(&pd->arrived, hipEventDisableTiming));
-    KSH_HIP(hipMemcpyAsync(pd->d_send, pd->send.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
-    KSH_TRY(comm_side_allgather(k->comm, pd->d_send, pd->d_recv, bytes));  // (every rank gets here, whatever its encodes did)
-    KSH_HIP(hipMemcpyAsync(pd->h_recv, pd->d_recv, bytes * size_t(world), hipMemcpyDeviceToHost,
-                           comm_side_stream(k->comm)));
-    KSH_HIP(hipEventRecord(pd->arrived, comm_side_stream(k->comm)));
+    if (pd->send.size() > k->xchg_cap)
+      return fail(KSH_INTERNAL, "a check with %zu stale nodes: more than the exchange buffers hold", pd->stale.size());
+    KSH_HIP(hipMemcpyAsync(x.d_send, pd->send.data(), bytes, hipMemcpyHostToDevice, ctx->stream));
+    KSH_TRY(comm_side_allgather(k->comm, x.d_send, x.d_recv, bytes));  // (every rank gets here, whatever its encodes did)
+    KSH_HIP(hipMemcpyAsync(x.h_recv, x.d_recv, bytes * size_t(world), hipMemcpyDeviceToHost, comm_side_stream(k->comm)));
+    KSH_HIP(hipEventRecord(x.arrived, comm_side_stream(k->comm)));
     k->gather_bytes += int64_t(bytes);
     return KSH_OK;
   };
+  // waits for a check's exchange; the values rank-major without the status words; an error on EVERY rank
+  // if one of them had failed by then
   const auto finish_exchange = [&](Pending* pd, std::vector<int64_t>* recv) {
-    recv->assign(pd->send.size() * size_t(world), 0);
-    if (pd->send.empty()) return KSH_OK;
-    KSH_HIP(hipEventSynchronize(pd->arrived));
-    std::memcpy(recv->data(), pd->h_recv, recv->size() * 8);
-    pool_free(ctx, pd->d_send);
-    pool_free(ctx, pd->d_recv);
-    (void)hipHostFree(pd->h_recv);
-    (void)hipEventDestroy(pd->arrived);
-    pd->d_send = pd->d_recv = nullptr;
-    pd->h_recv = nullptr;
-    pd->arrived = nullptr;
+    ksh_kss::Exchange& x = k->xchg[pd->id & 1];
+    const size_t count = pd->send.size(), vals = count - 1;
+    recv->assign(vals * size_t(world), 0);
+    KSH_HIP(hipEventSynchronize(x.arrived));
+    int failed = -1;
+    for (size_t r = 0; r < size_t(world); r++) {
+      std::copy(x.h_recv + r * count, x.h_recv + r * count + vals, recv->begin() + r * vals);
+      if (x.h_recv[r * count + vals] != 0 && failed < 0) failed = int(r);
+    }
+    pd->send.pop_back();
+    if (failed >= 0) {
+      k->failed_together = true;
+      if (!alive(k)) return fail(k->local_rc, "%s", k->local_msg.c_str());
+      return fail(KSH_INTERNAL, "rank %d failed; every rank gives the build up", failed);
+    }
     return KSH_OK;
   };
 
@@ -852,7 +994,6 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
     PhaseTimer pt(k, 3);
     std::vector<int64_t> recv;
     KSH_TRY(finish_exchange(pd, &recv));
-    if (pd->local_rc != KSH_OK) return fail(pd->local_rc, "%s", pd->local_msg.c_str());
     const std::vector<KssCompact>& at_check = pd->compacts;
     std::vector<const int64_t*> from(pd->stale.size(), nullptr);
     for (size_t q = 0; q < pd->stale.size(); q++) {
@@ -1006,18 +1147,30 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
       KssSet pulled;
       if (src != ex) KSH_TRY(recv_set(k, src, &pulled));
       const KssSet& set_k = src != ex ? pulled : k->sets[size_t(kk)];
-      const ksh_set_view vj = view_of(k->sets[size_t(j)]), vk = view_of(set_k);
-      const int64_t original_size = vj.n_keys + vk.n_keys;
       KssSet sn, sj, sk;
-      KSH_TRY(alloc_offsets(ctx, g, &sn));
-      KSH_TRY(alloc_offsets(ctx, g, &sj));
-      KSH_TRY(alloc_offsets(ctx, g, &sk));
-      int64_t totals[3];
-      KSH_TRY(ksh_pair_plan(ctx, g, &vj, &vk, sn.off, sj.off, sk.off, totals));
-      KSH_TRY(alloc_keys(ctx, g, totals[0], &sn));
-      KSH_TRY(alloc_keys(ctx, g, totals[1], &sj));
-      KSH_TRY(alloc_keys(ctx, g, totals[2], &sk));
-      KSH_TRY(ksh_pair_write(ctx, g, &vj, &vk, sn.keys, sj.keys, sk.keys));
+      int64_t original_size = -1;
+      // rank-local from here: a failure (an allocation under memory pressure) leaves the three results
+      // empty, the rank goes on with the protocol and every rank hears of it at the next exchange
+      if (alive(k) && !(k->sets[size_t(j)].off && set_k.off))
+        poison(k, fail(KSH_INTERNAL, "iteration %d: rank %d does not hold both sets of the pair", i, rank));
+      if (alive(k)) {
+        const ksh_set_view vj = view_of(k->sets[size_t(j)]), vk = view_of(set_k);
+        original_size = vj.n_keys + vk.n_keys;
+        int64_t totals[3] = {0, 0, 0};
+        KSH_LOCAL(k, alloc_offsets(ctx, g, &sn));
+        KSH_LOCAL(k, alloc_offsets(ctx, g, &sj));
+        KSH_LOCAL(k, alloc_offsets(ctx, g, &sk));
+        KSH_LOCAL(k, ksh_pair_plan(ctx, g, &vj, &vk, sn.off, sj.off, sk.off, totals));
+        KSH_LOCAL(k, alloc_keys(ctx, g, totals[0], &sn));
+        KSH_LOCAL(k, alloc_keys(ctx, g, totals[1], &sj));
+        KSH_LOCAL(k, alloc_keys(ctx, g, totals[2], &sk));
+        KSH_LOCAL(k, ksh_pair_write(ctx, g, &vj, &vk, sn.keys, sj.keys, sk.keys));
+        if (!alive(k)) {
+          free_set(ctx, &sn);
+          free_set(ctx, &sj);
+          free_set(ctx, &sk);
+        }
+      }
       if (src != ex) retire_set(&pulled); else retire_set(&k->sets[size_t(kk)]);
       retire_set(&k->sets[size_t(j)]);
       k->sets[size_t(j)] = sj;
@@ -1067,7 +1220,7 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
       std::vector<int64_t> w;
       {
         PhaseTimer pt(k, 1);
-        KSH_TRY(sample_weights(k, ids, pairs, &w));
+        KSH_TRY(weigh(pairs, &w));
       }
       for (size_t q = 0; q < pairs.size(); q++) weights[pairs[q]] = w[q];
     }
@@ -1590,15 +1743,23 @@ int ksh_kss_build_owned(ksh_ctx* ctx, ksh_comm* comm, const ksh_geom* g, const k
   std::vector<int32_t> ids(bucket_ids, bucket_ids + n_ids);
   int rc = KSH_OK;
   if (n_inputs > 0) rc = build_owned(k, inputs, n_inputs, owners, ids, max_iterations);
+  ctx->inject_skip = -1;
   if (rc != KSH_OK) {
+    // Either every rank returns this error together, after an exchange that carried a failed rank's status
+    // (failed_together) -- or this rank alone cannot follow the protocol any longer (its replica of the control
+    // loop or the transport failed): then the transport is torn down, so that its peers' pending operations
+    // end in errors rather than wait for it.  Whatever the case, a non-OK return means the job is over: the
+    // caller destroys the communicator and its process group.
+    const std::string msg = ksh_last_error();
+    if (!k->failed_together) comm_abort(comm);
     ksh_kss_destroy(k);
-    return rc;
+    return fail(rc, "%s", msg.c_str());
   }
   *out = k;
   return KSH_OK;
 }
 
-int ksh_kss_comm_stats(const ksh_kss* k, int64_t stats[7]) {
+int ksh_kss_comm_stats(const ksh_kss* k, int64_t stats[8]) {
   if (!k || !stats) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
   stats[0] = k->p2p_bytes_sent;
   stats[1] = k->p2p_bytes_received;
@@ -1607,6 +1768,7 @@ int ksh_kss_comm_stats(const ksh_kss* k, int64_t stats[7]) {
   stats[4] = k->checks_deferred;
   stats[5] = k->rollbacks;
   stats[6] = k->sets_migrated;
+  stats[7] = k->weight_gathers;
   return KSH_OK;
 }
 
@@ -1649,6 +1811,16 @@ int ksh_kss_destroy(ksh_kss* k) {
       pool_free(k->ctx, k->samples[i].keys);
     }
   if (k->sample_block) (void)hipFree(k->sample_block);
+  pool_free(k->ctx, k->gx_send);
+  pool_free(k->ctx, k->gx_recv);
+  pool_free(k->ctx, k->zero_off);
+  pool_free(k->ctx, k->xfer_off);
+  for (ksh_kss::Exchange& x : k->xchg) {
+    pool_free(k->ctx, x.d_send);
+    pool_free(k->ctx, x.d_recv);
+    if (x.h_recv) (void)hipHostFree(x.h_recv);
+    if (x.arrived) (void)hipEventDestroy(x.arrived);
+  }
   delete k;
   return KSH_OK;
 }

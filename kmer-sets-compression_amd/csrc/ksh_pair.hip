@@ -45,7 +45,7 @@ struct TileCfg {
 #ifndef KSH_VT32
 #define KSH_VT32 15
 #endif
-  static constexpr int kVT = sizeof(KeyT) == 4 ? KSH_VT32 : 11;  // merged keys per lane, at most (odd)
+  static constexpr int kVT = sizeof(KeyT) <= 4 ? KSH_VT32 : 11;  // merged keys per lane, at most (odd)
   static constexpr int kTile = kThreads * kVT - 1;          // largest diagonal span (+1: tie fix-up)
   static constexpr int kCap = kThreads * kVT;               // keys in a tile, at most
   static constexpr int kPer = 16 / int(sizeof(KeyT));       // keys per 16-byte vector
@@ -1101,8 +1101,7 @@ int ksh_pair_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const 
   KSH_TRY(check_view(a, "a"));
   KSH_TRY(check_view(b, "b"));
   KSH_HIP(hipSetDevice(ctx->device));
-  return g->key_bytes == 4 ? pair_plan_t<uint32_t>(ctx, g, a, b, d_off_i, d_off_amb, d_off_bma, totals)
-                           : pair_plan_t<uint64_t>(ctx, g, a, b, d_off_i, d_off_amb, d_off_bma, totals);
+  return KSH_BY_KEY(g->key_bytes, pair_plan_t, ctx, g, a, b, d_off_i, d_off_amb, d_off_bma, totals);
 }
 
 int ksh_pair_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
@@ -1112,8 +1111,7 @@ int ksh_pair_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const
   KSH_TRY(check_view(a, "a"));
   KSH_TRY(check_view(b, "b"));
   KSH_HIP(hipSetDevice(ctx->device));
-  return g->key_bytes == 4 ? pair_write_t<uint32_t>(ctx, g, a, b, d_keys_i, d_keys_amb, d_keys_bma)
-                           : pair_write_t<uint64_t>(ctx, g, a, b, d_keys_i, d_keys_amb, d_keys_bma);
+  return KSH_BY_KEY(g->key_bytes, pair_write_t, ctx, g, a, b, d_keys_i, d_keys_amb, d_keys_bma);
 }
 
 int ksh_pair_algebra(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
@@ -1127,8 +1125,7 @@ int ksh_pair_algebra(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, con
   KSH_TRY(check_view(b, "b"));
   KSH_HIP(hipSetDevice(ctx->device));
   ksh_pair_job job{*a, *b, d_off_i, d_off_amb, d_off_bma, d_keys_i, d_keys_amb, d_keys_bma, {0, 0, 0}};
-  const int rc = g->key_bytes == 4 ? pair_algebra_batch_t<uint32_t>(ctx, g, &job, 1)
-                                   : pair_algebra_batch_t<uint64_t>(ctx, g, &job, 1);
+  const int rc = KSH_BY_KEY(g->key_bytes, pair_algebra_batch_t, ctx, g, &job, 1);
   if (rc != KSH_OK) return rc;
   totals[0] = job.totals[0];
   totals[1] = job.totals[1];
@@ -1148,8 +1145,7 @@ int ksh_pair_algebra_batch(ksh_ctx* ctx, const ksh_geom* g, ksh_pair_job* jobs, 
       return fail(KSH_INVALID_ARGUMENT, "jobs[%d] has a NULL output", i);
   }
   KSH_HIP(hipSetDevice(ctx->device));
-  return g->key_bytes == 4 ? pair_algebra_batch_t<uint32_t>(ctx, g, jobs, n_jobs)
-                           : pair_algebra_batch_t<uint64_t>(ctx, g, jobs, n_jobs);
+  return KSH_BY_KEY(g->key_bytes, pair_algebra_batch_t, ctx, g, jobs, n_jobs);
 }
 
 int ksh_set_union_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a,
@@ -1159,8 +1155,7 @@ int ksh_set_union_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a,
   KSH_TRY(check_view(a, "a"));
   KSH_TRY(check_view(b, "b"));
   KSH_HIP(hipSetDevice(ctx->device));
-  return g->key_bytes == 4 ? union_plan_t<uint32_t>(ctx, g, a, b, d_off_u, total)
-                           : union_plan_t<uint64_t>(ctx, g, a, b, d_off_u, total);
+  return KSH_BY_KEY(g->key_bytes, union_plan_t, ctx, g, a, b, d_off_u, total);
 }
 
 int ksh_set_union_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a,
@@ -1170,8 +1165,7 @@ int ksh_set_union_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a,
   KSH_TRY(check_view(a, "a"));
   KSH_TRY(check_view(b, "b"));
   KSH_HIP(hipSetDevice(ctx->device));
-  return g->key_bytes == 4 ? union_write_t<uint32_t>(ctx, g, a, b, d_keys_u)
-                           : union_write_t<uint64_t>(ctx, g, a, b, d_keys_u);
+  return KSH_BY_KEY(g->key_bytes, union_write_t, ctx, g, a, b, d_keys_u);
 }
 
 int ksh_set_diff(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const ksh_set_view* b,
@@ -1181,8 +1175,7 @@ int ksh_set_diff(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* a, const k
   KSH_TRY(check_view(a, "a"));
   KSH_TRY(check_view(b, "b"));
   KSH_HIP(hipSetDevice(ctx->device));
-  return g->key_bytes == 4 ? set_diff_t<uint32_t>(ctx, g, a, b, diff)
-                           : set_diff_t<uint64_t>(ctx, g, a, b, diff);
+  return KSH_BY_KEY(g->key_bytes, set_diff_t, ctx, g, a, b, diff);
 }
 
 int ksh_pair_weights(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sets, int32_t n_sets,
@@ -1205,9 +1198,7 @@ int ksh_pair_weights(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sets, 
       return fail(KSH_INVALID_ARGUMENT, "pairs[%d] = %d is outside [0, n_sets)", p, pairs[p]);
   for (int32_t i = 0; i < n_sets; i++) KSH_TRY(check_view(&sets[i], "sets[i]"));
   KSH_HIP(hipSetDevice(ctx->device));
-  return g->key_bytes == 4
-             ? pair_weights_t<uint32_t>(ctx, g, sets, n_sets, bucket_ids, n_ids, pairs, n_pairs, weights)
-             : pair_weights_t<uint64_t>(ctx, g, sets, n_sets, bucket_ids, n_ids, pairs, n_pairs, weights);
+  return KSH_BY_KEY(g->key_bytes, pair_weights_t, ctx, g, sets, n_sets, bucket_ids, n_ids, pairs, n_pairs, weights);
 }
 
 }  // extern "C"

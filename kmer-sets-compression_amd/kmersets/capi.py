@@ -45,9 +45,12 @@ COMM_P2P_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int32
 KSH_COMM_ID_BYTES = 128
 
 
+COMM_ABORT_FN = C.CFUNCTYPE(None, C.c_void_p)
+
+
 class CommFns(C.Structure):
     _fields_ = [("user", C.c_void_p), ("allgather", COMM_ALLGATHER_FN), ("send", COMM_P2P_FN),
-                ("recv", COMM_P2P_FN)]
+                ("recv", COMM_P2P_FN), ("abort", COMM_ABORT_FN)]
 
 
 class PairJob(C.Structure):
@@ -146,6 +149,7 @@ def lib():
         "ksh_kss_build_owned": (C.c_int, [vp, vp, GP, C.POINTER(SpssView), i32, C.POINTER(i32), C.POINTER(i32), i32,
                                           C.c_int, i32, C.POINTER(vp)]),
         "ksh_kss_comm_stats": (C.c_int, [vp, C.POINTER(i64)]),
+        "ksh_comm_ranks_seen": (C.c_int, [vp, C.POINTER(i32)]),
         "ksh_kss_encode_counts": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
         "ksh_kss_weighed_counts": (C.c_int, [vp, C.POINTER(i64), C.POINTER(i64)]),
         "ksh_kss_phase_seconds": (C.c_int, [vp, C.POINTER(C.c_double)]),
@@ -183,9 +187,15 @@ def check(rc):
 
 
 def geom(k, n_bucket_bits, key_bytes=None):
+    """Device geometry of the reference's <K, N, KeyType>.  key_bytes: the reference's KeyType size (1, 2, 4
+    or 8; None: the narrowest the key bits fit); device keys are 2, 4 or 8 bytes (uint8_t widens to 2)."""
+    kb = 2 * k - n_bucket_bits
     if key_bytes is None:
-        key_bytes = 4 if 2 * k - n_bucket_bits <= 32 else 8
-    return Geom(k, n_bucket_bits, 4 if key_bytes <= 4 else 8, 0)
+        key_bytes = 2 if kb <= 16 else (4 if kb <= 32 else 8)
+    return Geom(k, n_bucket_bits, 2 if key_bytes <= 2 else (4 if key_bytes <= 4 else 8), 0)
+
+
+KEY_DTYPE = {2: np.uint16, 4: np.uint32, 8: np.uint64}
 
 
 class DeviceSet:
@@ -222,7 +232,7 @@ class DeviceSet:
     def from_numpy(cls, g, offsets, keys, device):
         import torch
 
-        kdt = np.uint32 if g.key_bytes == 4 else np.uint64
+        kdt = KEY_DTYPE[g.key_bytes]
         keys = np.ascontiguousarray(keys, dtype=kdt)
         off_t = torch.from_numpy(np.ascontiguousarray(offsets, dtype=np.int64)).to(device)
         raw = torch.from_numpy(keys.view(np.uint8).copy()) if keys.size else torch.zeros(0, dtype=torch.uint8)
@@ -250,7 +260,7 @@ class DeviceSet:
         return SetView(po, pk, self.n_keys)
 
     def to_numpy(self):
-        kdt = np.uint32 if self.g.key_bytes == 4 else np.uint64
+        kdt = KEY_DTYPE[self.g.key_bytes]
         keys = self.keys[: self.n_keys * self.g.key_bytes].cpu().numpy().view(kdt)
         return self.offsets.cpu().numpy(), keys
 
@@ -755,7 +765,7 @@ class DeviceKmerSetSet:
         g = self.g
         nb = 1 << g.n_bucket_bits
         off = np.zeros(nb + 1, dtype=np.int64)
-        kdt = np.uint32 if g.key_bytes == 4 else np.uint64
+        kdt = KEY_DTYPE[g.key_bytes]
         keys = np.zeros(max(n_keys, 1), dtype=kdt)
         check(lib().ksh_ctx_memcpy_d2h(self.ctx.h, off.ctypes.data_as(C.c_void_p), d_off, (nb + 1) * 8))
         if n_keys:
@@ -892,11 +902,23 @@ class Comm:
                 dist.recv(t, peer)
                 h2d(d_buf, t)
 
-            self._keep = (COMM_ALLGATHER_FN(allgather), COMM_P2P_FN(send), COMM_P2P_FN(recv))
+            def abort(_u):
+                # a rank gives the build up where it cannot follow the protocol: the transport's own abort, if any
+                f = getattr(dist, "abort", None)
+                if f is not None:
+                    f()
+
+            self._keep = (COMM_ALLGATHER_FN(allgather), COMM_P2P_FN(send), COMM_P2P_FN(recv), COMM_ABORT_FN(abort))
             self._fns = CommFns(None, *self._keep)
             check(lib().ksh_comm_create_custom(ctx.h, self.rank, self.world, C.byref(self._fns), C.byref(h)))
             self.kind = "custom"
         self.h = h
+
+    def ranks_seen(self):
+        """Collective: the ranks whose ids arrived here through the transport's all-gather."""
+        n = C.c_int32()
+        check(lib().ksh_comm_ranks_seen(self.h, C.byref(n)))
+        return n.value
 
     def close(self):
         if getattr(self, "h", None):
@@ -950,10 +972,10 @@ class OwnedKmerSetSet(DeviceKmerSetSet):
     __del__ = close
 
     def comm_stats(self):
-        st = (C.c_int64 * 7)()
+        st = (C.c_int64 * 8)()
         check(lib().ksh_kss_comm_stats(self.h, st))
         return dict(zip(["p2p_bytes_sent", "p2p_bytes_received", "p2p_sets", "gather_bytes", "checks_deferred",
-                         "rollbacks", "sets_migrated"], [int(x) for x in st]))
+                         "rollbacks", "sets_migrated", "weight_gathers"], [int(x) for x in st]))
 
     def node_table(self):
         """(size, XOR hash) of every node, from the ranks that hold them (one all-gather)."""

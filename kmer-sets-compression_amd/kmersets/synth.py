@@ -176,7 +176,7 @@ def to_bucketed(kmers, k, n_bits, key_bytes):
     offsets = np.zeros((1 << n_bits) + 1, dtype=np.int64)
     np.cumsum(np.bincount(buckets, minlength=1 << n_bits), out=offsets[1:])
     keys = kmers & U((1 << key_bits) - 1)
-    return offsets, keys.astype(np.uint32 if key_bytes <= 4 else np.uint64)
+    return offsets, keys.astype(np.uint16 if key_bytes <= 2 else (np.uint32 if key_bytes <= 4 else np.uint64))
 
 
 def from_bucketed(offsets, keys, k, n_bits):

@@ -114,7 +114,9 @@ def device_set(g, kmers):
     offsets = torch.zeros(nb + 1, dtype=torch.int64, device=kmers.device)
     torch.cumsum(counts, 0, out=offsets[1:])
     keys = kmers & ((1 << key_bits) - 1)
-    if g.key_bytes == 4:
+    if g.key_bytes == 2:
+        raw = keys.to(torch.int16).contiguous().view(torch.uint8)   # (the low 16 bits, as a bit pattern)
+    elif g.key_bytes == 4:
         raw = keys.to(torch.int32).contiguous().view(torch.uint8)
     else:
         raw = keys.contiguous().view(torch.uint8)

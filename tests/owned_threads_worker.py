@@ -8,7 +8,11 @@ all-gather through a barrier, send / recv through one queue per (source, destina
 are those of tests/dist_owned_worker.py: the replicated state against the oracle on every rank, a
 node's set and SPSS on the rank that owns it.
 
-  python owned_threads_worker.py K N KEY_BYTES N_SETS SIZE SEED WORLD [block|striped]
+  python owned_threads_worker.py K N KEY_BYTES N_SETS SIZE SEED WORLD [block|striped] [expect_fail]
+
+expect_fail (with KSH_FAIL_INJECT=rank:skip:min_bytes in the environment: that rank's large allocations start
+failing): every rank's ksh_kss_build_owned must return an error -- the failed rank its own, the others "rank r
+failed" -- and none may be left waiting in an exchange.
 """
 import json
 import os
@@ -74,7 +78,7 @@ class ThreadDist:
         t.copy_(self.hub.q[(peer, self.rank)].get(timeout=TIMEOUT))
 
 
-def run_rank(rank, hub, shape, layout, shared, out, errors):
+def run_rank(rank, hub, shape, layout, shared, out, errors, expect_fail=False):
     try:
         k, n, kb, n_sets, size, seed = shape
         world = hub.world
@@ -86,6 +90,13 @@ def run_rank(rank, hub, shape, layout, shared, out, errors):
         owners = capi.block_owners(n_sets, world) if layout == "block" else [i % world for i in range(n_sets)]
         dcompacts = [capi.DeviceSpss.from_strings(g, c.strings(), ctx.device) if owners[i] == rank else None
                      for i, c in enumerate(ocompacts)]
+        if expect_fail:
+            try:
+                capi.OwnedKmerSetSet(ctx, dcompacts, ids, dist, "cpu", owners=owners)
+                out[rank] = {"raised": False, "message": ""}
+            except capi.KshError as e:
+                out[rank] = {"raised": True, "message": str(e)}
+            return
         dkss = capi.OwnedKmerSetSet(ctx, dcompacts, ids, dist, "cpu", owners=owners)
         it, cp, imp = dkss.trace()
         assert np.array_equal(it, okss.iterations()), (it, okss.iterations())
@@ -110,7 +121,8 @@ def run_rank(rank, hub, shape, layout, shared, out, errors):
         out[rank] = {"held": held, "encodes": dkss.stats()["n_encodes"], "p2p_sets": cs["p2p_sets"],
                      "sent": cs["p2p_bytes_sent"], "received": cs["p2p_bytes_received"],
                      "checks_deferred": cs["checks_deferred"], "rollbacks": cs["rollbacks"],
-                     "migrated": cs["sets_migrated"], "iterations": int(len(it)), "checks": int(len(cp)),
+                     "migrated": cs["sets_migrated"], "weight_gathers": cs["weight_gathers"],
+                     "iterations": int(len(it)), "checks": int(len(cp)),
                      "nodes": okss.size()}
         dist.barrier()
         dkss.close()
@@ -123,6 +135,7 @@ def run_rank(rank, hub, shape, layout, shared, out, errors):
 def main():
     k, n, kb, n_sets, size, seed, world = (int(x) for x in sys.argv[1:8])
     layout = sys.argv[8] if len(sys.argv) > 8 else "block"
+    expect_fail = len(sys.argv) > 9 and sys.argv[9] == "expect_fail"
     sets = synth.phylogeny_sets(k, n_sets, size, seed=seed)
     osets = [ol.Set.from_kmers(k, n, kb, s) for s in sets]
     ocompacts = [s.compact() for s in osets]
@@ -134,7 +147,8 @@ def main():
     capi.lib()
     hub = Hub(world)
     out, errors = [None] * world, []
-    threads = [threading.Thread(target=run_rank, args=(r, hub, (k, n, kb, n_sets, size, seed), layout, shared, out, errors))
+    threads = [threading.Thread(target=run_rank, args=(r, hub, (k, n, kb, n_sets, size, seed), layout, shared, out, errors,
+                                                        expect_fail))
                for r in range(world)]
     for t in threads:
         t.start()
@@ -143,6 +157,10 @@ def main():
     if errors:
         print("\n".join(errors), file=sys.stderr)
         raise SystemExit(1)
+    if expect_fail:
+        print(json.dumps({"ok": True, "world": world, "raised": [o["raised"] for o in out],
+                          "messages": [o["message"] for o in out]}))
+        return
     held = sorted(i for o in out for i in o["held"])
     assert held == list(range(out[0]["nodes"])), "every node lives on exactly one rank"
     print(json.dumps({"ok": True, "world": world, "iterations": out[0]["iterations"], "nodes": out[0]["nodes"],
@@ -150,7 +168,7 @@ def main():
                       "rollbacks": out[0]["rollbacks"], "encodes_per_rank": [o["encodes"] for o in out],
                       "sets_sent_per_rank": [o["p2p_sets"] for o in out],
                       "bytes_sent": sum(o["sent"] for o in out), "bytes_received": sum(o["received"] for o in out),
-                      "nodes_per_rank": [len(o["held"]) for o in out],
+                      "nodes_per_rank": [len(o["held"]) for o in out], "weight_gathers": out[0]["weight_gathers"],
                       "sets_migrated": sum(o["migrated"] for o in out)}))
 
 

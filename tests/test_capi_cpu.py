@@ -45,4 +45,5 @@ def test_geometry_validation_is_host_side(lib):
     g = capi.geom(23, 14)
     assert (g.k, g.n_bucket_bits, g.key_bytes) == (23, 14, 4)
     assert capi.geom(31, 14).key_bytes == 8
-    assert capi.geom(15, 14).key_bytes == 4   # u16 keys of the reference widen to u32 on device
+    assert capi.geom(15, 14).key_bytes == 2   # the reference's (15, 14, uint16_t)
+    assert capi.geom(9, 10, 1).key_bytes == 2 and capi.geom(19, 10).key_bytes == 4

@@ -188,6 +188,54 @@ def test_owned_build_eight_ranks(gpu):
     assert res["checks_deferred"] == res["checks"] > 0
 
 
+@pytest.mark.parametrize("inject", ["1:4:150000", "2:1:150000", "0:7:150000"])
+def test_owned_build_failure_reaches_every_rank(gpu, inject):
+    """A rank whose large allocations start failing in the middle of the owner-sharded build (the injected
+    stand-in for a GPU out of memory: in a merge, while a set arrives, during the decode of its inputs)
+    must not leave the others waiting in an exchange: it goes on following the protocol with empty
+    stand-ins, its status travels with the next all-gather, and EVERY rank's ksh_kss_build_owned returns
+    an error -- the failed rank its own, the others "rank r failed".  3 rank threads, striped owners (the
+    merges pull sets across ranks), tests/owned_threads_worker.py."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, KSH_FAIL_INJECT=inject)
+    cmd = [sys.executable, os.path.join(here, "owned_threads_worker.py"), "23", "14", "4", "12", "60000", "5", "3",
+           "striped", "expect_fail"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert res["raised"] == [True, True, True], res
+    failed = int(inject.split(":")[0])
+    assert "injected" in res["messages"][failed]
+    for r_, m in enumerate(res["messages"]):
+        if r_ != failed:
+            assert "rank %d failed" % failed in m, res
+
+
+def test_owned_build_sharded_weights(gpu):
+    """KSH_OWNED_WEIGHTS=sharded: the weight tables dealt out by pair list, one all-gather of per-pair int64
+    weights per iteration (lib/core/kmer_set_set.h:205-218,385-425; the collective north_star names) -- the
+    same trace, checkpoints, DAG and nodes as the oracle, by the other control mode.  4 rank threads."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, KSH_OWNED_WEIGHTS="sharded")
+    cmd = [sys.executable, os.path.join(here, "owned_threads_worker.py"), "23", "14", "4", "16", "40000", "9", "4",
+           "block"]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert res["ok"] and res["iterations"] > 0
+    assert res["weight_gathers"] >= res["iterations"] + 1      # the initial table + one per iteration (+ an undone interval's)
+
+
 def test_owned_build_without_lookahead(gpu, monkeypatch):
     """KSH_OWNED_LOOKAHEAD=0: every check resolved on the spot -- the same result by the other route."""
     monkeypatch.setenv("KSH_OWNED_LOOKAHEAD", "0")

@@ -7,7 +7,12 @@ single-GPU measurements of the same run (its `phase_seconds`), so the output is 
 wall time with every check resolved on the spot (KSH_OWNED_LOOKAHEAD=0) and with the checks deferred
 by one, which is what the code does; it is arithmetic, not a measurement.
 
-  owned_schedule.py trace.json [--gpus 8] [--link-gbs 64]
+Both control modes are reported: the replicated control loop (the default: every rank weighs its replica of
+the samples, nothing is exchanged, the merges of other ranks are not waited for) and KSH_OWNED_WEIGHTS=sharded
+(the weight tables dealt out by pair list, ONE all-gather of int64 per iteration: the weighing shrinks by N,
+every iteration pays the all-gather's latency and waits for the rank that runs the iteration's full merge).
+
+  owned_schedule.py trace.json [--gpus 8] [--link-gbs 64] [--allgather-us 40]
 """
 import argparse
 import json
@@ -18,6 +23,8 @@ def main():
     ap.add_argument("trace")
     ap.add_argument("--gpus", type=int, default=8)
     ap.add_argument("--link-gbs", type=float, default=64.0, help="one xGMI link, one direction, GB/s")
+    ap.add_argument("--allgather-us", type=float, default=40.0,
+                    help="one small all-gather of int64 over RCCL incl. its host staging, microseconds (assumed)")
     args = ap.parse_args()
     d = json.load(open(args.trace))
     n0, key_bytes, world = d["n_inputs"], d["key_bytes"], args.gpus
@@ -164,6 +171,15 @@ def main():
     # the merges run on one rank each while the others go on: a rank's own share of them is about 1 / N
     out["expected_total_implemented_merges_spread_s"] = decode + control + t_merge / world + t_p2p + t_impl
     out["speedup_implemented_merges_spread"] = t1 / out["expected_total_implemented_merges_spread_s"]
+    # ---- KSH_OWNED_WEIGHTS=sharded: the weighing by pair list + one all-gather per iteration.  The exchange
+    # sits behind the iteration's full merge on the rank that runs it (same stream), so every rank waits for
+    # every merge: they are charged in full.
+    control_sharded = control / world + (len(rows) + 1) * args.allgather_us * 1e-6
+    out["control_sharded_s"] = control_sharded
+    out["allgather_us_assumed"] = args.allgather_us
+    out["expected_total_sharded_control_s"] = decode + control_sharded + t_merge + t_p2p + t_impl
+    out["speedup_sharded_control"] = t1 / out["expected_total_sharded_control_s"]
+    out["note"] = "arithmetic over the measured single-GPU phases and merge sequence: modelled, not measured"
     print(json.dumps(out, indent=1))
 
 

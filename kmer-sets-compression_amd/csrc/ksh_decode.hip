@@ -132,7 +132,8 @@ __global__ __launch_bounds__(kDecThreads) void k_decode(
 constexpr int kColTeams = 16;
 __global__ __launch_bounds__(64 * kColTeams) void k_hist_columns(uint32_t* __restrict__ hist_matrix,
                                                                   int64_t n_groups, int n_buckets,
-                                                                  int64_t* __restrict__ totals) {
+                                                                  int64_t* __restrict__ totals,
+                                                                  unsigned long long* __restrict__ max_total) {
   __shared__ uint32_t team_total[kColTeams][64];
   const int lane = threadIdx.x & 63, team = threadIdx.x >> 6;
   const int b = blockIdx.x * 64 + lane;
@@ -158,7 +159,21 @@ __global__ __launch_bounds__(64 * kColTeams) void k_hist_columns(uint32_t* __res
     *cell = run;
     run += c;
   }
-  if (team == 0) totals[b] = all;
+  if (team == 0) {
+    totals[b] = all;
+    // the largest bucket (the sort needs a scratch copy when one exceeds its LDS window): one atomic per wave
+    unsigned long long m = all;
+    if (int(blockIdx.x + 1) * 64 <= n_buckets) {  // a full wave (the others returned above: every lane for itself)
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const unsigned long long o = __shfl_xor(m, d, 64);
+        m = o > m ? o : m;
+      }
+      if (lane == 0 && max_total) atomicMax(max_total, m);
+    } else if (max_total) {
+      atomicMax(max_total, m);
+    }
+  }
 }
 
 // ---- per-bucket sort --------------------------------------------------------------------------
@@ -522,7 +537,7 @@ int decode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int c
   int64_t n_words, n_end_words, groups, wpg;
   decode_geometry(s, &n_words, &n_end_words, &groups, &wpg);
   const size_t bytes = a256(size_t(groups) * nb * 4) + a256(size_t(n_end_words) * 8) +
-                       a256(size_t(s->n_strings + 1) * 8) + a256(size_t(nb + 1) * 8);
+                       a256(size_t(s->n_strings + 1) * 8) + a256(size_t(nb + 2) * 8);
   KSH_TRY(slot_reserve(ctx, kSlotDecode, bytes));
   KSH_TRY(arena_reserve(ctx, size_t(s->n_strings / 256 + 4096) * 8 + (1u << 16)));
   arena_reset(ctx);
@@ -541,15 +556,19 @@ int decode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int c
                      size_t(nb) * 4, ctx->stream, s->d_words, n_words, s->n_bases, st.end_bits,
                      n_end_words, g->k, key_bits(g), int(nb), canonical_flag, wpg, st.hist, nullptr,
                      static_cast<KeyT*>(nullptr));
+  unsigned long long* d_max = reinterpret_cast<unsigned long long*>(st.totals + nb + 1);
+  KSH_HIP(hipMemsetAsync(d_max, 0, 8, ctx->stream));
   hipLaunchKernelGGL(k_hist_columns, dim3(unsigned((nb + 63) / 64)), dim3(64 * kColTeams), 0, ctx->stream,
-                     st.hist, groups, int(nb), st.totals);
+                     st.hist, groups, int(nb), st.totals, d_max);
   KSH_TRY(scan_exclusive_i64(ctx, st.totals, d_offsets, nb, d_offsets + nb));
   KSH_HIP(hipGetLastError());
   // consistency: the strings must tile the base stream exactly
   KSH_HIP(hipMemcpyAsync(ctx->h_pinned, d_offsets + nb, 8, hipMemcpyDeviceToHost, ctx->stream));
   KSH_HIP(hipMemcpyAsync(ctx->h_pinned + 1, st.str_start + s->n_strings, 8, hipMemcpyDeviceToHost,
                          ctx->stream));
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned + 2, d_max, 8, hipMemcpyDeviceToHost, ctx->stream));
   KSH_HIP(hipStreamSynchronize(ctx->stream));
+  ctx->dec_max_bucket = ctx->h_pinned[2];
   if (ctx->h_pinned[1] != s->n_bases)
     return fail(KSH_INVALID_ARGUMENT, "spss: sum of string lengths (%lld) != n_bases (%lld)",
                 (long long)ctx->h_pinned[1], (long long)s->n_bases);
@@ -586,12 +605,8 @@ int decode_write_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int 
   // the bucket offsets (128 KiB to the host).
   KeyT* scratch = nullptr;
   {
-    std::vector<int64_t> h_off(static_cast<size_t>(nb + 1));
-    KSH_HIP(hipMemcpyAsync(h_off.data(), d_offsets, size_t(nb + 1) * 8, hipMemcpyDeviceToHost,
-                           ctx->stream));
-    KSH_HIP(hipStreamSynchronize(ctx->stream));
-    int64_t max_bucket = 0;
-    for (int64_t b = 0; b < nb; b++) max_bucket = std::max(max_bucket, h_off[b + 1] - h_off[b]);
+    // (the largest bucket came back with the plan's sizes: no copy of the offsets, no round trip here)
+    const int64_t max_bucket = ctx->dec_max_bucket;
     if (max_bucket > int64_t(kSortLdsBytes / sizeof(KeyT))) {
       void* ptr = nullptr;
       KSH_TRY(pool_alloc(ctx, size_t(ctx->dec_kmers) * sizeof(KeyT), &ptr));

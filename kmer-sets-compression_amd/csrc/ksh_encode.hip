@@ -227,15 +227,16 @@ template <typename KeyT>
 __global__ __launch_bounds__(1024) void k_rc_hist(const KeyT* __restrict__ keys, int64_t n, int k, int key_bits,
                                                    int nbits, int64_t per_row,
                                                    uint32_t* __restrict__ hist_matrix) {
+  // (nbits = bits of the group id: the bucket bits N, or N + 1 when a group is half a bucket)
   extern __shared__ uint32_t lds_hist[];
   const int nb = 1 << nbits;
   for (int b = threadIdx.x; b < nb; b += blockDim.x) lds_hist[b] = 0u;
   __syncthreads();
   const int64_t t_begin = int64_t(blockIdx.x) * per_row;
   const int64_t t_end = min(t_begin + per_row, n);
-  const int low_bits = key_bits - 2;
+  const int low_bits = 2 * k - 2 - nbits;
   for (int64_t t = t_begin + threadIdx.x; t < t_end; t += blockDim.x) {
-    const uint64_t rx = revcomp(uint64_t(keys[t]), k);  // its top N + 2 bits are those of rc(x)
+    const uint64_t rx = revcomp(uint64_t(keys[t]), k);  // its top nbits + 2 bits are those of rc(x)
     atomicAdd(&lds_hist[uint32_t(rx >> low_bits) & uint32_t(nb - 1)], 1u);
   }
   __syncthreads();
@@ -298,7 +299,7 @@ __global__ __launch_bounds__(1024) void k_rc_scatter(DevSet<KeyT> set, int nbits
   if (t_begin >= t_end) return;
   // the buckets this row's k-mers lie in (uniform addresses: every thread searches for itself)
   const int64_t b_first = set.bucket_of(t_begin), b_last = set.bucket_of(t_end - 1);
-  const int k = set.k, low_bits = set.key_bits - 2;
+  const int k = set.k, low_bits = 2 * set.k - 2 - nbits;
   const uint64_t low_mask = (uint64_t(1) << low_bits) - 1;
   for (int64_t t = t_begin + threadIdx.x; t < t_end; t += blockDim.x) {
     const uint64_t key = uint64_t(set.keys[t]);
@@ -346,6 +347,10 @@ __global__ __launch_bounds__(kL1Threads) void k_rc_scatter_l1(DevSet<KeyT> set, 
   __shared__ RcRecord<KeyT> s_rec[kTile];
   __shared__ uint16_t s_g[kTile];
   __shared__ uint32_t s_cur[kSg], s_cnt[kSg], s_lbase[kSg + 1];
+  // the offsets of the buckets the row's k-mers lie in: a k-mer's bucket is a search in LDS, not a chain of
+  // dependent global loads per k-mer (round 2: 8 loads per k-mer, 77 % of the kernel's wave cycles waiting)
+  constexpr int kOffCap = 1024;
+  __shared__ int64_t s_off[kOffCap];
   const int tid = threadIdx.x;
   const int nb = 1 << nbits, lo_bits = nbits - kSgBits;
   const uint32_t* my_row = hist_matrix + int64_t(blockIdx.x) * nb;
@@ -365,8 +370,13 @@ __global__ __launch_bounds__(kL1Threads) void k_rc_scatter_l1(DevSet<KeyT> set, 
   __syncthreads();
   if (t_begin >= t_end) return;
   const int64_t b_first = set.bucket_of(t_begin), b_last = set.bucket_of(t_end - 1);
-  const int k = set.k, low_bits = set.key_bits - 2;
+  const int k = set.k, low_bits = 2 * set.k - 2 - nbits;
   const uint64_t low_mask = (uint64_t(1) << low_bits) - 1;
+  const int n_span = int(min<int64_t>(b_last - b_first + 1, kOffCap + 1));
+  const bool off_staged = n_span <= kOffCap;
+  if (off_staged)
+    for (int j = tid; j < n_span; j += kL1Threads) s_off[j] = set.off[b_first + j];
+  __syncthreads();
   for (int64_t t0 = t_begin; t0 < t_end; t0 += kTile) {
     const int tile_n = int(min<int64_t>(kTile, t_end - t0));
     RcRecord<KeyT> mine[kPer];
@@ -377,10 +387,19 @@ __global__ __launch_bounds__(kL1Threads) void k_rc_scatter_l1(DevSet<KeyT> set, 
       grp[j] = 0xFFFFFFFFu;
       if (t >= t_end) continue;
       const uint64_t key = uint64_t(set.keys[t]);
-      int64_t lo = b_first, hi = b_last;
-      while (lo < hi) {
-        const int64_t mid = (lo + hi + 1) >> 1;
-        if (set.off[mid] <= t) lo = mid; else hi = mid - 1;
+      int64_t lo = b_first, hi = b_last;  // largest b in the row's span with off[b] <= t
+      if (off_staged) {
+        int l2 = 0, h2 = n_span - 1;
+        while (l2 < h2) {
+          const int mid = (l2 + h2 + 1) >> 1;
+          if (s_off[mid] <= t) l2 = mid; else h2 = mid - 1;
+        }
+        lo = b_first + l2;
+      } else {
+        while (lo < hi) {
+          const int64_t mid = (lo + hi + 1) >> 1;
+          if (set.off[mid] <= t) lo = mid; else hi = mid - 1;
+        }
       }
       const uint64_t rx = revcomp((uint64_t(lo) << set.key_bits) | key, k);
       grp[j] = uint32_t(rx >> low_bits) & uint32_t(nb - 1);
@@ -424,7 +443,7 @@ __global__ __launch_bounds__(kL2Threads) void k_rc_scatter_l2(int64_t n, int nbi
                                                                const uint16_t* __restrict__ tmp_g,
                                                                uint32_t* __restrict__ cursor,
                                                                RcRecord<KeyT>* __restrict__ rec) {
-  constexpr int kBins = 2 << kSgBits;  // two super-groups' worth of groups when a super-group has 2^kSgBits groups
+  constexpr int kBins = 512;  // two super-groups' worth of groups: a super-group has at most 2^(15 - kSgBits) of them
   __shared__ RcRecord<KeyT> s_rec[kL2Tile];
   __shared__ uint16_t s_bin[kL2Tile];
   __shared__ uint32_t s_cnt[kBins], s_lbase[kBins], s_gbase[kBins];
@@ -456,12 +475,26 @@ __global__ __launch_bounds__(kL2Threads) void k_rc_scatter_l2(int64_t n, int nbi
     }
   }
   __syncthreads();
-  for (int b = tid; b < kBins; b += kL2Threads) {
-    uint32_t before = 0;
-    for (int b2 = 0; b2 < b; b2++) before += s_cnt[b2];
-    s_lbase[b] = before;
-    const uint32_t c = s_cnt[b];
-    s_gbase[b] = c ? uint32_t(goff[base_g + b]) + atomicAdd(&cursor[base_g + b], c) : 0u;
+  {
+    // exclusive scan of the bin counts: thread t holds bins 2t, 2t + 1 (kBins == 2 * kL2Threads)
+    static_assert(kBins == 2 * kL2Threads, "two bins per thread");
+    __shared__ uint32_t s_wave[kL2Threads / 64];
+    const uint32_t c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
+    uint32_t inc = c0 + c1;
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    uint32_t before = inc - (c0 + c1);
+    for (int w = 0; w < wv; w++) before += s_wave[w];
+    s_lbase[2 * tid] = before;
+    s_lbase[2 * tid + 1] = before + c0;
+    s_gbase[2 * tid] = c0 ? uint32_t(goff[base_g + 2 * tid]) + atomicAdd(&cursor[base_g + 2 * tid], c0) : 0u;
+    s_gbase[2 * tid + 1] = c1 ? uint32_t(goff[base_g + 2 * tid + 1]) + atomicAdd(&cursor[base_g + 2 * tid + 1], c1) : 0u;
   }
   __syncthreads();
 #pragma unroll
@@ -504,13 +537,21 @@ constexpr int kRcSegs = 16;
 // pb[32 * G + 2 * seg + which]: the index range of the set with the (N + 4)-bit prefix
 // [c][tb][G] (seg = 4 c + tb), for every group G: one thread per bound, all searches in flight
 // together instead of a chain of dependent loads at the head of every k_adj_rc workgroup.
+// (nbits = bits of the group id.  pb0[2 * G + which], when the groups are finer than buckets: the range with
+// the nbits-bit prefix G, where pass 0 looks; with whole buckets that is the bucket's offsets.)
 template <typename KeyT>
-__global__ __launch_bounds__(256) void k_rc_bounds(DevSet<KeyT> set, int nbits, int64_t* __restrict__ pb) {
+__global__ __launch_bounds__(256) void k_rc_bounds(DevSet<KeyT> set, int nbits, int64_t* __restrict__ pb,
+                                                    int64_t* __restrict__ pb0) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (i >= (int64_t(2 * kRcSegs) << nbits)) return;
-  const uint64_t grp = uint64_t(i) >> 5, seg = (uint64_t(i) >> 1) & 15, which = uint64_t(i) & 1;
-  const uint64_t prefix = (seg << nbits) | grp;
-  pb[i] = lower_bound_kmer(set, (prefix + which) << (2 * set.k - 4 - nbits));
+  const int64_t n_pb = int64_t(2 * kRcSegs) << nbits;
+  if (i < n_pb) {
+    const uint64_t grp = uint64_t(i) >> 5, seg = (uint64_t(i) >> 1) & 15, which = uint64_t(i) & 1;
+    const uint64_t prefix = (seg << nbits) | grp;
+    pb[i] = lower_bound_kmer(set, (prefix + which) << (2 * set.k - 4 - nbits));
+  } else if (pb0 && i - n_pb < (int64_t(2) << nbits)) {
+    const uint64_t j = uint64_t(i - n_pb);
+    pb0[j] = lower_bound_kmer(set, ((j >> 1) + (j & 1)) << (2 * set.k - nbits));
+  }
 }
 struct RcBatch {
   int64_t seg_lo[kRcSegs], seg_hi[kRcSegs];  // the pass's target ranges (indices of the set)
@@ -525,23 +566,24 @@ struct RcBatch {
   int64_t next_pos;                          // ... and how far it got
 };
 
-// One workgroup per group G.  Pass 0: range = bucket G, a record looks for the members of
-// Next(rx, .) and marks their side 0.  Pass 1: 16 ranges [c][tb][G], a record looks for its
-// canonical Prev(rx, c) in range (c, its tb) and marks side 1.
+// One workgroup per group G (a bucket, or half a bucket: gbits = N + extra bits of rx below its top base).
+// Pass 0: range = the keys with the gbits-bit prefix G, a record looks for the members of Next(rx, .)
+// and marks their side 0.  Pass 1: 16 ranges [c][tb][G], a record looks for its canonical Prev(rx, c)
+// in range (c, its tb) and marks side 1.
 // LDS: cap keys | cap marks | cap + 2 * kRcSegs slice bounds (u16).  A range's slice index has
 // the largest power of two <= its length many slices over the key bits the range's keys differ in.
-// A wave's life here is memory round trips, so each is taken once: a thread's records are read
-// into registers up front and serve both passes, the 32 range bounds of pass 1 are searched
-// while bucket G is being staged, every staging loop issues all its loads before the first LDS
-// store, and in pass 1 team w (a sixteenth of the workgroup: a wave when it has 1024 threads)
-// stages, indexes and stores range w.  kRcThreads follows the group size (1024 for the 6 000-key
-// groups of a 10^8-k-mer set, 256 or 64 for small sets: a workgroup's fixed cost is its barriers).
+// A wave's life here is memory round trips and barriers, so each is taken once: the next record is
+// requested before this record's look-ups, the range bounds of both passes arrive with the group's
+// record range, every staging loop issues all its loads before the first LDS store, in pass 1
+// team w (a sixteenth of the workgroup) stages, indexes and stores range w, and a pass whose ranges
+// fit the window together -- all but the densest groups -- is laid out by sixteen lanes at once and
+// ends after its one batch (round 2: one thread planned every batch and every pass took a second
+// trip through the planner to learn that nothing was left).  kRcThreads follows the group size.
 template <typename KeyT, int kRcThreads>
-__global__ __launch_bounds__(kRcThreads, (kRcThreads >= 128 ? kRcThreads / 128 : 1)) void k_adj_rc(DevSet<KeyT> set, int nbits,
-                                                        const int64_t* __restrict__ goff,
-                                                        const RcRecord<KeyT>* __restrict__ rec,
-                                                        const int64_t* __restrict__ pb, int cap,
-                                                        uint32_t* __restrict__ rc0, uint32_t* __restrict__ rc1) {
+__global__ __launch_bounds__(kRcThreads, (kRcThreads >= 512 ? 8 : (kRcThreads >= 128 ? kRcThreads / 128 : 1))) void k_adj_rc(
+    DevSet<KeyT> set, int gbits, const int64_t* __restrict__ goff, const RcRecord<KeyT>* __restrict__ rec,
+    const int64_t* __restrict__ pb, const int64_t* __restrict__ pb0, int cap, uint32_t* __restrict__ rc0,
+    uint32_t* __restrict__ rc1) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   KeyT* skeys = reinterpret_cast<KeyT*>(lds_raw);
   uint32_t* slots = reinterpret_cast<uint32_t*>(lds_raw + size_t(cap) * sizeof(KeyT));
@@ -552,71 +594,122 @@ __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 128 ? kRcThreads / 128 :
   constexpr int kTeam = kRcThreads / kRcSegs;
   const int tid = threadIdx.x, lane = tid % kTeam, wave = tid / kTeam;
   const int64_t grp = blockIdx.x;
-  const int k = set.k, low_bits = set.key_bits - 2;
+  const int k = set.k, low_bits = 2 * set.k - 2 - gbits;
+  const int extra = gbits - int(2 * set.k - set.key_bits);  // group bits beyond the bucket bits
   const uint64_t low_mask = (uint64_t(1) << low_bits) - 1;
   const uint64_t kmask = kmer_mask(k);
   const int64_t r0 = goff[grp], r1 = goff[grp + 1];
+  // pass 0's range: the bucket's offsets, or the searched bounds of a finer group
+  const int64_t p0_lo = pb0 ? pb0[2 * grp] : set.off[grp], p0_hi = pb0 ? pb0[2 * grp + 1] : set.off[grp + 1];
+  // the bits of a bucket key that a pass-0 target of this group starts with (the group bits below the bucket's)
+  const uint64_t gkey_top = extra > 0 ? (uint64_t(grp) & ((uint64_t(1) << extra) - 1)) << (set.key_bits - extra) : 0;
   if (tid < 2 * kRcSegs) prev_bounds[tid] = pb[2 * kRcSegs * grp + tid];
   for (int pass = 0; pass < 2; pass++) {
     const int n_seg = pass == 0 ? 1 : kRcSegs;
-    // key bits that vary inside a range: all of them in bucket G, all but the top 4 in [c][tb][G]
-    const int seg_bits = pass == 0 ? set.key_bits : set.key_bits - 4;
+    // key bits that vary inside a range: all below the group's in its own range, four fewer in [c][tb][G]
+    const int seg_bits = (pass == 0 ? set.key_bits : set.key_bits - 4) - extra;
     const uint64_t seg_mask = seg_bits >= 64 ? ~uint64_t(0) : ((uint64_t(1) << seg_bits) - 1);
     uint32_t* out = pass == 0 ? rc0 : rc1;
     __syncthreads();
-    if (tid == 0) {
-      if (pass == 0) {
-        bt.seg_lo[0] = set.off[grp];
-        bt.seg_hi[0] = set.off[grp + 1];
-      } else {
-        for (int s2 = 0; s2 < kRcSegs; s2++) {
-          bt.seg_lo[s2] = prev_bounds[2 * s2];
-          bt.seg_hi[s2] = prev_bounds[2 * s2 + 1];
+    // slices of a range of `take` keys: the largest power of two <= take, each at least 4 values wide
+    const auto slice_lg = [&](int take) {
+      int lg = take >= 2 ? 31 - __builtin_clz(unsigned(take)) : 0;
+      if (lg > seg_bits - 2) lg = seg_bits - 2 > 0 ? seg_bits - 2 : 0;
+      return lg;
+    };
+    // one thread lays out the next batch from the cursor (ranges that do not fit the window together)
+    const auto plan_serial = [&]() {
+      int used = 0, iused = 0, seg = bt.next_seg;
+      int64_t pos = bt.next_pos;
+      for (int s2 = 0; s2 < n_seg; s2++) {
+        bt.win_len[s2] = 0;
+        bt.packed[s2] = 0;
+      }
+      while (seg < n_seg) {
+        const int64_t avail = bt.seg_hi[seg] - pos;
+        const int take = int(avail < int64_t(cap - used) ? avail : int64_t(cap - used));
+        const int lg = slice_lg(take);
+        bt.win_lo[seg] = pos;
+        bt.win_len[seg] = take;
+        bt.win_off[seg] = used;
+        bt.idx_off[seg] = iused;
+        bt.idx_shift[seg] = seg_bits - lg;
+        bt.packed[seg] = (unsigned long long)(take) | ((unsigned long long)(used) << 16) |
+                         ((unsigned long long)(iused) << 32) | ((unsigned long long)(seg_bits - lg) << 48);
+        iused += (1 << lg) + 1;
+        used += take;
+        pos += take;
+        if (pos < bt.seg_hi[seg]) break;  // the window is full
+        seg++;
+        if (seg < n_seg) pos = bt.seg_lo[seg];
+      }
+      bt.used = used;
+      bt.next_seg = seg;
+      bt.next_pos = pos;
+    };
+    // the pass's first batch: the first wave, lane s for range s; everything at once when it fits
+    if (tid < 64) {
+      const int s2 = tid;
+      int64_t lo = 0, hi = 0;
+      if (s2 < n_seg) {
+        lo = pass == 0 ? p0_lo : prev_bounds[2 * s2];
+        hi = pass == 0 ? p0_hi : prev_bounds[2 * s2 + 1];
+        bt.seg_lo[s2] = lo;
+        bt.seg_hi[s2] = hi;
+      }
+      const int64_t len64 = hi - lo;
+      const int len = int(len64 < int64_t(cap) + 1 ? len64 : int64_t(cap) + 1);
+      const int lg = slice_lg(len);
+      int inc = len, iinc = s2 < n_seg ? (1 << lg) + 1 : 0;
+#pragma unroll
+      for (int d = 1; d < kRcSegs; d <<= 1) {
+        const int o = __shfl_up(inc, d, 64), io = __shfl_up(iinc, d, 64);
+        if (s2 >= d) {
+          inc += o;
+          iinc += io;
         }
       }
-      bt.next_seg = 0;
-      bt.next_pos = bt.seg_lo[0];
+      const int total = __shfl(inc, kRcSegs - 1, 64);  // (lanes past n_seg hold empty ranges)
+      if (total <= cap) {
+        if (s2 < n_seg) {
+          const int used = inc - len, iused = iinc - ((1 << lg) + 1);
+          bt.win_lo[s2] = lo;
+          bt.win_len[s2] = len;
+          bt.win_off[s2] = used;
+          bt.idx_off[s2] = iused;
+          bt.idx_shift[s2] = seg_bits - lg;
+          bt.packed[s2] = (unsigned long long)(len) | ((unsigned long long)(used) << 16) |
+                          ((unsigned long long)(iused) << 32) | ((unsigned long long)(seg_bits - lg) << 48);
+        }
+        if (s2 == 0) {
+          bt.used = total;
+          bt.next_seg = n_seg;
+          bt.next_pos = 0;
+        }
+      } else if (s2 == 0) {
+        bt.next_seg = 0;
+        bt.next_pos = lo;
+      }
+      // (the serial planner reads seg_lo / seg_hi written by the other lanes of this wave: same wave, in order)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (total > cap && s2 == 0) plan_serial();
     }
     while (true) {
       __syncthreads();
-      if (tid == 0) {
-        int used = 0, iused = 0, seg = bt.next_seg;
-        int64_t pos = bt.next_pos;
-        for (int s2 = 0; s2 < n_seg; s2++) {
-          bt.win_len[s2] = 0;
-          bt.packed[s2] = 0;
-        }
-        while (seg < n_seg) {
-          const int64_t avail = bt.seg_hi[seg] - pos;
-          const int take = int(avail < int64_t(cap - used) ? avail : int64_t(cap - used));
-          bt.win_lo[seg] = pos;
-          bt.win_len[seg] = take;
-          bt.win_off[seg] = used;
-          bt.idx_off[seg] = iused;
-          // slices: the largest power of two <= take, each at least 4 values wide
-          int lg = take >= 2 ? 31 - __builtin_clz(unsigned(take)) : 0;
-          if (lg > seg_bits - 2) lg = seg_bits - 2 > 0 ? seg_bits - 2 : 0;
-          bt.idx_shift[seg] = seg_bits - lg;
-          bt.packed[seg] = (unsigned long long)(take) | ((unsigned long long)(used) << 16) |
-                           ((unsigned long long)(iused) << 32) | ((unsigned long long)(seg_bits - lg) << 48);
-          iused += (1 << lg) + 1;
-          used += take;
-          pos += take;
-          if (pos < bt.seg_hi[seg]) break;  // the window is full
-          seg++;
-          if (seg < n_seg) pos = bt.seg_lo[seg];
-        }
-        bt.used = used;
-        bt.next_seg = seg;
-        bt.next_pos = pos;
-      }
-      __syncthreads();
-      if (bt.used == 0) break;  // every range of the pass has been staged and stored
+      if (bt.used == 0) break;  // an empty pass
       // who stages what: pass 0, the whole workgroup its one range; pass 1, team w range w
       const int my_seg = pass == 0 ? 0 : wave;
       const int my_id = pass == 0 ? tid : lane, my_step = pass == 0 ? kRcThreads : kTeam;
       const int64_t my_lo = bt.win_lo[my_seg];
       const int my_len = bt.win_len[my_seg], my_off = bt.win_off[my_seg];
+      const bool last_batch = bt.next_seg >= n_seg;
+      // the first record of this thread is requested ahead of the staging loads (it used to follow the slice
+      // index: one more exposed round trip per batch); the next one ahead of each record's look-ups
+      RcRecord<KeyT> nxt;
+      nxt.t = kNone;
+      if (r0 + tid < r1) nxt = rec[r0 + tid];
       for (int base = 0; base < my_len; base += 4 * my_step) {
         KeyT v[4];
 #pragma unroll
@@ -647,10 +740,6 @@ __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 128 ? kRcThreads / 128 :
         }
       }
       __syncthreads();
-      // the record of the next turn is requested before this turn's look-ups
-      RcRecord<KeyT> nxt;
-      nxt.t = kNone;
-      if (r0 + tid < r1) nxt = rec[r0 + tid];
 #pragma unroll 1
       for (int64_t r = r0 + tid; r < r1; r += kRcThreads) {
         const RcRecord<KeyT> rr = nxt;
@@ -658,8 +747,8 @@ __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 128 ? kRcThreads / 128 :
         const uint64_t low = uint64_t(rr.key) & low_mask;
         const uint32_t mark = (rr.t << 1) | 1u;
         if (pass == 0) {
-          const uint64_t gkey = low << 2;
-          const int sl = int(gkey >> bt.idx_shift[0]);
+          const uint64_t gkey = gkey_top | (low << 2);  // the bucket key of Next(rx, A)
+          const int sl = int((gkey & seg_mask) >> bt.idx_shift[0]);
           for (int i = sidx[sl], end = sidx[sl + 1]; i < end; i++) {
             const uint64_t d = uint64_t(skeys[i]) - gkey;  // members: gkey .. gkey + 3
             if (d < 4 && bt.win_lo[0] + i != int64_t(rr.t)) mark_hit(&slots[i], mark);
@@ -685,6 +774,9 @@ __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 128 ? kRcThreads / 128 :
       }
       __syncthreads();
       for (int i = my_id; i < my_len; i += my_step) out[my_lo + i] = slots[my_off + i];
+      if (last_batch) break;  // (the usual case: the pass was one batch)
+      __syncthreads();
+      if (tid == 0) plan_serial();
     }
   }
 }
@@ -762,13 +854,14 @@ __device__ __forceinline__ int lds_lower_bound(const KeyT* a, int lo, int hi, Ke
 // KSH_FWD_DEBUG=1: how often the staged forward probe falls back to global probes (per k-mer and cause)
 __device__ unsigned long long g_fwd_dbg[8];
 
-template <typename KeyT>
-__global__ __launch_bounds__(kFwdChunk) void k_adj_fwd_staged(DevSet<KeyT> set, const int64_t* __restrict__ bounds,
+template <typename KeyT, int kFwdCapNext = FwdCfg<KeyT>::kCapNext>
+__global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_fwd_staged(DevSet<KeyT> set, const int64_t* __restrict__ bounds,
                                                               const uint32_t* __restrict__ rc0,
                                                               const uint32_t* __restrict__ rc1,
                                                               uint32_t* __restrict__ nbr,
                                                               int* __restrict__ self_rc) {
-  constexpr int kFwdCapNext = FwdCfg<KeyT>::kCapNext, kFwdCapPrev = FwdCfg<KeyT>::kCapPrev;
+  constexpr int kFwdCapPrev = FwdCfg<KeyT>::kCapPrev;
+  static_assert(kFwdCapNext % kFwdChunk == 0, "staging shape");
   __shared__ KeyT s_next[kFwdCapNext];
   __shared__ KeyT s_prev[4][kFwdCapPrev];
   __shared__ int64_t s_b[2 * kFwdBounds];     // this boundary's and the next one's records
@@ -927,219 +1020,13 @@ __global__ __launch_bounds__(kFwdChunk) void k_adj_fwd_staged(DevSet<KeyT> set, 
   reinterpret_cast<uint2*>(nbr)[t] = make_uint2(out[0], out[1]);
 }
 
-// ---- the same, software-pipelined.  k_adj_fwd_staged spends a workgroup's life in dependent memory
-// round trips -- the chunk's bound record, then its windows (whose addresses come from that record), then
-// whatever its k-mers probe in global memory because a window overflowed -- with nothing of its own to
-// overlap them.  Here a workgroup is persistent and takes chunks blockIdx.x, + gridDim.x, ...: while it
-// searches chunk c in LDS, the windows, keys and marks of chunk c + G are on their way into registers and
-// the bound record of chunk c + 2G behind them, so a chunk's two staging round trips run under the
-// search of the chunk before.  The Next window holds a range 3 x the expected size (the first-base
-// density skew of canonical sets, above): only T-chunks that lead into A- or C-ranges still overflow.
-template <typename KeyT>
-struct FwdPipeCfg {
-  static constexpr int kCapNext = sizeof(KeyT) == 8 ? 3072 : 6144;  // (33 KB of LDS either way: four workgroups per CU)
-  static constexpr int kCapPrev = 512;
-  static_assert(kCapPrev % kFwdChunk == 0 && kCapNext % kFwdChunk == 0, "staging shape");
-};
-constexpr int kFwdPipeGroupsPerCu = 4;
-
-template <typename KeyT>
-__global__ __launch_bounds__(kFwdChunk) void k_adj_fwd_pipe(DevSet<KeyT> set, const int64_t* __restrict__ bounds,
-                                                            int64_t n_chunks, const uint32_t* __restrict__ rc0,
-                                                            const uint32_t* __restrict__ rc1,
-                                                            uint32_t* __restrict__ nbr, int* __restrict__ self_rc) {
-  constexpr int kCapNext = FwdPipeCfg<KeyT>::kCapNext, kCapPrev = FwdPipeCfg<KeyT>::kCapPrev;
-  constexpr int kPer = kCapNext / kFwdChunk, kPerPrev = kCapPrev / kFwdChunk;
-  __shared__ KeyT s_next[kCapNext];
-  __shared__ KeyT s_prev[4][kCapPrev];
-  __shared__ int64_t s_b[2][2 * kFwdBounds];    // bound records of the chunk being searched and of the next one
-  __shared__ int64_t s_boff[6][kFwdSpan + 1];
-  const int tid = threadIdx.x;
-  const int k = set.k;
-  int64_t chunk = blockIdx.x;
-  if (chunk >= n_chunks) return;
-  const int64_t stride = gridDim.x;
-
-  // what is in flight for a chunk: its keys and marks, the five windows, its bucket offsets
-  struct InFlight {
-    KeyT my_key;
-    uint2 rc;
-    KeyT vn[kPer];
-    KeyT vp[4][kPerPrev];
-    int64_t boff;
-  };
-  // the ranges of a chunk from its bound record (LDS): staged lengths, first indices, first buckets
-  struct Ranges {
-    int len[5];
-    int64_t lo_of[5];
-    int64_t fb[6];
-    bool usable[5];
-  };
-  const auto ranges_of = [&](const int64_t* sb) {
-    Ranges r;
-    const uint64_t x_first = uint64_t(sb[10]), x_last = uint64_t(sb[kFwdBounds + 11]);
-    r.fb[0] = int64_t(kmer_next(x_first, k, 0) >> set.key_bits);
-#pragma unroll
-    for (int cc = 0; cc < 4; cc++) r.fb[1 + cc] = int64_t(kmer_prev(x_first, k, cc) >> set.key_bits);
-    r.fb[5] = int64_t(x_first >> set.key_bits);
-#pragma unroll
-    for (int q = 0; q < 5; q++) {
-      r.lo_of[q] = sb[q];
-      const int64_t l = sb[kFwdBounds + 5 + q] - r.lo_of[q];
-      r.usable[q] = l >= 0 && l <= (q == 0 ? kCapNext : kCapPrev);
-      r.len[q] = r.usable[q] ? int(l) : 0;
-    }
-    if ((x_first >> (2 * k - 2)) != (x_last >> (2 * k - 2))) {
-      r.usable[0] = false;
-      r.len[0] = 0;
-    }
-    return r;
-  };
-  const auto issue = [&](int64_t c, const Ranges& r) {
-    InFlight f;
-    const int64_t t = c * kFwdChunk + tid;
-    f.my_key = 0;
-    f.rc = make_uint2(kNone, kNone);
-    if (t < set.n) {
-      f.my_key = set.keys[t];
-      f.rc = make_uint2(rc0[t], rc1[t]);
-    }
-#pragma unroll
-    for (int u = 0; u < kPer; u++)
-      if (tid + u * kFwdChunk < r.len[0]) f.vn[u] = set.keys[r.lo_of[0] + tid + u * kFwdChunk];
-#pragma unroll
-    for (int cc = 0; cc < 4; cc++)
-#pragma unroll
-      for (int u = 0; u < kPerPrev; u++)
-        if (tid + u * kFwdChunk < r.len[1 + cc]) f.vp[cc][u] = set.keys[r.lo_of[1 + cc] + tid + u * kFwdChunk];
-    f.boff = 0;
-    if (tid < 6 * (kFwdSpan + 1)) {
-      const int q = tid / (kFwdSpan + 1), j = tid % (kFwdSpan + 1);
-      const int64_t b = r.fb[q] + j;
-      f.boff = b <= set.n_buckets ? set.off[b] : set.n;
-    }
-    return f;
-  };
-
-  // prologue: the first chunk's record, then its loads and the second chunk's record
-  if (tid < 2 * kFwdBounds) s_b[0][tid] = bounds[kFwdBounds * chunk + tid];
-  __syncthreads();
-  int cur = 0;
-  Ranges rg = ranges_of(s_b[0]);
-  InFlight fl = issue(chunk, rg);
-  int64_t nb_val = 0;
-  if (tid < 2 * kFwdBounds && chunk + stride < n_chunks) nb_val = bounds[kFwdBounds * (chunk + stride) + tid];
-
-  while (true) {
-    // ---- this chunk's staged data into LDS; the next chunk's record beside it
-#pragma unroll
-    for (int u = 0; u < kPer; u++)
-      if (tid + u * kFwdChunk < rg.len[0]) s_next[tid + u * kFwdChunk] = fl.vn[u];
-#pragma unroll
-    for (int cc = 0; cc < 4; cc++)
-#pragma unroll
-      for (int u = 0; u < kPerPrev; u++)
-        if (tid + u * kFwdChunk < rg.len[1 + cc]) s_prev[cc][tid + u * kFwdChunk] = fl.vp[cc][u];
-    if (tid < 6 * (kFwdSpan + 1)) s_boff[tid / (kFwdSpan + 1)][tid % (kFwdSpan + 1)] = fl.boff;
-    if (tid < 2 * kFwdBounds) s_b[cur ^ 1][tid] = nb_val;
-    const KeyT my_key = fl.my_key;
-    const uint2 rc = fl.rc;
-    __syncthreads();
-    // ---- the next chunk's loads go out before this chunk is searched
-    const int64_t next = chunk + stride;
-    Ranges rg_next = rg;
-    if (next < n_chunks) {
-      rg_next = ranges_of(s_b[cur ^ 1]);
-      fl = issue(next, rg_next);
-      if (tid < 2 * kFwdBounds && next + stride < n_chunks) nb_val = bounds[kFwdBounds * (next + stride) + tid];
-    }
-    // ---- search
-    const int64_t t = chunk * kFwdChunk + tid;
-    if (t < set.n) {
-      int64_t my_b = rg.fb[5];
-      {
-        int j = 0;
-        while (j < kFwdSpan && s_boff[5][j + 1] <= t) j++;
-        my_b += j;
-        if (j == kFwdSpan)
-          while (set.off[my_b + 1] <= t) my_b++;
-      }
-      const uint64_t x = (uint64_t(my_b) << set.key_bits) | uint64_t(my_key);
-      if (revcomp(x, k) == x) *self_rc = 1;
-      int cnt[2] = {0, 0};
-      uint32_t single[2] = {kNone, kNone};
-      const auto bucket_range = [&](int q, int64_t b, int64_t* blo, int64_t* bhi) {
-        const int64_t j = b - rg.fb[q];
-        if (j < 0 || j >= kFwdSpan) return false;
-        *blo = s_boff[q][j];
-        *bhi = s_boff[q][j + 1];
-        return true;
-      };
-      {  // side 1: Next(x, .), neighbour as is
-        const uint64_t g0 = kmer_next(x, k, 0);
-        int64_t blo, bhi;
-        if (rg.usable[0] && bucket_range(0, int64_t(g0 >> set.key_bits), &blo, &bhi)) {
-          const KeyT gkey = KeyT(g0 & set.key_mask());
-          const int64_t hi0 = rg.lo_of[0] + rg.len[0];
-          const int lo = int((blo > rg.lo_of[0] ? blo : rg.lo_of[0]) - rg.lo_of[0]);
-          const int hi = int((bhi < hi0 ? bhi : hi0) - rg.lo_of[0]);
-          if (lo < hi) {
-            int i = lds_lower_bound(s_next, lo, hi, gkey);
-            for (; i < hi && uint64_t(s_next[i]) - uint64_t(gkey) < 4; i++) {
-              const int64_t idx = rg.lo_of[0] + i;
-              if (idx == t) continue;
-              cnt[1]++;
-              single[1] = uint32_t(idx) << 1;
-            }
-          }
-        } else {
-          set.for_group4(g0, [&](int64_t idx) {
-            if (idx == t) return;
-            cnt[1]++;
-            single[1] = uint32_t(idx) << 1;
-          });
-        }
-      }
-#pragma unroll
-      for (int c = 0; c < 4; c++) {  // side 0: Prev(x, c), neighbour as is
-        const uint64_t z = kmer_prev(x, k, c);
-        if (revcomp(z, k) < z) continue;
-        if (z == x) continue;
-        int64_t idx = -1;
-        int64_t blo, bhi;
-        if (rg.usable[1 + c] && bucket_range(1 + c, int64_t(z >> set.key_bits), &blo, &bhi)) {
-          const KeyT zkey = KeyT(z & set.key_mask());
-          const int64_t hi0 = rg.lo_of[1 + c] + rg.len[1 + c];
-          const int lo = int((blo > rg.lo_of[1 + c] ? blo : rg.lo_of[1 + c]) - rg.lo_of[1 + c]);
-          const int hi = int((bhi < hi0 ? bhi : hi0) - rg.lo_of[1 + c]);
-          if (lo < hi) {
-            const int i = lds_lower_bound(s_prev[c], lo, hi, zkey);
-            if (i < hi && s_prev[c][i] == zkey) idx = rg.lo_of[1 + c] + i;
-          }
-        } else {
-          idx = set.find(z);
-        }
-        if (idx < 0) continue;
-        cnt[0]++;
-        single[0] = uint32_t(idx) << 1;
-      }
-      const uint32_t r2[2] = {rc.x, rc.y};
-      uint32_t out[2];
-#pragma unroll
-      for (int side = 0; side < 2; side++) {
-        const int total = cnt[side] + (r2[side] == kNone ? 0 : (r2[side] == kMulti ? 2 : 1));
-        out[side] = total == 0 ? kNone : (total > 1 ? kMulti : (cnt[side] == 1 ? single[side] : r2[side]));
-      }
-      reinterpret_cast<uint2*>(nbr)[t] = make_uint2(out[0], out[1]);
-    }
-    if (next >= n_chunks) break;
-    __syncthreads();  // every thread is done with this chunk's windows
-    chunk = next;
-    cur ^= 1;
-    rg = rg_next;
-  }
-}
-
+// (Measured and dropped, round 3: the same kernel software-pipelined -- persistent workgroups that take
+// chunks blockIdx.x, + gridDim.x, ..., with the windows, keys and marks of the next chunk on their way into
+// registers and the bound record of the one after it behind them while this chunk is searched, and a Next
+// window twice as large.  The data in flight cost 22 more vector registers (80: three workgroups per CU
+// instead of four, and a few spills), and the kernel took 2.34 ms per 10^8 k-mers against 1.93, 207 us
+// against 181 on a 9 x 10^6 difference set: four short-lived workgroups per CU in different phases overlap
+// their round trips better than three long-lived ones that prefetch.  profiles/r03_fwd_pipe_ab.txt)
 // The forward half of the probe, in place, and the verdict per side: rc0 / rc1 are what k_adj_rc
 // found to reach the k-mer's side 0 / side 1 through a reverse complement.
 template <typename KeyT>
@@ -2917,10 +2804,10 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   const size_t fine_entries = use_fine ? (size_t(nb) << fine_bits) + 1 : 0;
   const size_t bytes = 2 * al(size_t(2 * n) * 4) + al(size_t(2 * n) * 8) + 5 * al(size_t(n) * 4) +
                        2 * al(size_t(n)) + 2 * al(size_t(n) * 8) + al(fine_entries * 4) +
-                       al(size_t((n >> kCoarseShift) + 2) * 4) + al(sizeof(EncCtl) + size_t(nb) * 4) + 4096;
+                       al(size_t((n >> kCoarseShift) + 2) * 4) + al(sizeof(EncCtl) + size_t(2 * nb) * 4) + 4096;
   KSH_TRY(slot_reserve(ctx, kSlotEncode, bytes));
   KSH_TRY(arena_reserve(ctx, size_t(n / 256 + 4096) * 8 * 2 + (1u << 16) + size_t(n / kHeadSpan + 64) * 8 +
-                                 (nb <= (1 << 14) ? size_t(kRcRowsMax) * nb * 4 + size_t(nb + 1) * 16 + size_t(nb) * 260 + 8192 : 0)));
+                                 (nb <= (1 << 14) ? size_t(kRcRowsMax) * 2 * nb * 4 + size_t(2 * nb + 1) * 16 + size_t(2 * nb) * 280 + 8192 : 0)));
   arena_reset(ctx);
   char* at = ctx->slot[kSlotEncode];
   p->nbr = carve<uint32_t>(at, size_t(2 * n));
@@ -2937,7 +2824,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   p->c23 = p->c01 + n;
   p->fine = use_fine ? carve<uint32_t>(at, fine_entries) : nullptr;
   p->coarse = n >= 4 * nb ? carve<uint32_t>(at, size_t((n >> kCoarseShift) + 2)) : nullptr;
-  p->ctl = reinterpret_cast<EncCtl*>(carve<char>(at, sizeof(EncCtl) + size_t(nb) * 4));
+  p->ctl = reinterpret_cast<EncCtl*>(carve<char>(at, sizeof(EncCtl) + size_t(2 * nb) * 4));
   uint32_t* rc_cursor = reinterpret_cast<uint32_t*>(p->ctl + 1);  // k_rc_scatter_l2's per-group cursors: zeroed with the block
   EncCtl* ctl = p->ctl;
 
@@ -2955,7 +2842,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     hipLaunchKernelGGL((k_coarse_index<KeyT>), dim3(nblk(n_entries)), dim3(256), 0, st, set, n_entries, p->coarse);
     set.coarse = p->coarse;
   }
-  KSH_HIP(hipMemsetAsync(ctl, 0, sizeof(EncCtl) + size_t(nb) * 4, st));
+  KSH_HIP(hipMemsetAsync(ctl, 0, sizeof(EncCtl) + size_t(2 * nb) * 4, st));
   int* self_rc_flag = &ctl->self_rc;
   {
     Timer timer(ctx, 3, n);
@@ -2975,24 +2862,57 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       const int64_t per_row = ((n + rows - 1) / rows + 1023) / 1024 * 1024;
       KSH_BOUND(rows >= 1 && rows <= kRcRowsMax && rows * per_row >= n);  // k_rc_hist / k_rc_scatter_*: row r owns [r * per_row, ...)
       KSH_BOUND(size_t(n) * sizeof(RcRecord<KeyT>) <= al(size_t(2 * n) * 8));  // the records live in `info`
-      uint32_t* hist = static_cast<uint32_t*>(arena_alloc(ctx, size_t(rows) * nb * 4));
-      int64_t* totals = static_cast<int64_t*>(arena_alloc(ctx, size_t(nb + 1) * 8));
-      int64_t* goff = static_cast<int64_t*>(arena_alloc(ctx, size_t(nb + 1) * 8));
-      if (!hist || !totals || !goff) return fail(KSH_INTERNAL, "scratch arena too small");
-      RcRecord<KeyT>* rec = reinterpret_cast<RcRecord<KeyT>*>(p->info);
-      uint32_t* rc0 = p->link;
-      uint32_t* rc1 = p->link + n;
-      const size_t hist_lds = size_t(nb) * 4;
-      hipLaunchKernelGGL((k_rc_hist<KeyT>), dim3(unsigned(rows)), dim3(1024), hist_lds, st,
-                         static_cast<const KeyT*>(sv->d_keys), n, g->k, key_bits(g), nbits, per_row, hist);
-      hipLaunchKernelGGL(k_rc_columns, dim3(unsigned((nb + 63) / 64)), dim3(64 * kColTeams), 0, st, hist, rows, int(nb),
-                         totals);
-      KSH_TRY(scan_exclusive_i64(ctx, totals, goff, nb, goff + nb));
       static const bool one_level = [] {
         const char* e = getenv("KSH_RC_SCATTER");
         return e && std::string(e) == "direct";
       }();
-      if (n >= (int64_t(1) << 20) && nbits > kSgBits && nbits <= 16 && !one_level) {
+      static const bool half_groups = [] {
+        const char* e = getenv("KSH_RC_GROUPS");
+        return e && std::string(e) == "half";
+      }();
+      // (with KSH_RC_GROUPS=half the two-level scatter starts at 2^12 k-mers, so that small test sets take the route)
+      const bool two_level = n >= (int64_t(1) << (half_groups ? 12 : 20)) && nbits > kSgBits && nbits <= 16 && !one_level;
+      // Group bits.  KSH_RC_GROUPS=half deals the records into HALF buckets (one more bit of rx): the LDS
+      // window of a group halves and four workgroups of 512 threads share a CU instead of two of 1024.
+      // Measured on a 10^8-k-mer genome set (profiles/r03_rc_groups_ab.txt): k_adj_rc 1.62 -> 1.54 ms, and the
+      // finer histogram and scatter took it back twice over (k_rc_hist + 0.09, k_rc_scatter_l2 + 0.09,
+      // columns / bounds + 0.03 ms): not the default.  The kernels take the group bits as a parameter either way.
+      const int extra = (half_groups && two_level && nbits == 14 && key_bits(g) >= 2 * ((nbits + 1 + 2 + 1) / 2)) ? 1 : 0;
+      const int gbits = nbits + extra;
+      const int64_t ng = int64_t(1) << gbits;  // groups
+      uint32_t* hist = static_cast<uint32_t*>(arena_alloc(ctx, size_t(rows) * ng * 4));
+      int64_t* totals = static_cast<int64_t*>(arena_alloc(ctx, size_t(ng + 1) * 8));
+      int64_t* goff = static_cast<int64_t*>(arena_alloc(ctx, size_t(ng + 1) * 8));
+      if (!hist || !totals || !goff) return fail(KSH_INTERNAL, "scratch arena too small");
+      RcRecord<KeyT>* rec = reinterpret_cast<RcRecord<KeyT>*>(p->info);
+      uint32_t* rc0 = p->link;
+      uint32_t* rc1 = p->link + n;
+      const size_t hist_lds = size_t(ng) * 4;
+      {
+        // (more than the 64 KB a kernel gets without asking; per context: the attribute is the device's)
+        const uint32_t bit = 1u << (sizeof(KeyT) == 2 ? 0 : sizeof(KeyT) == 4 ? 1 : 2);
+        if (!(ctx->lds_opt_in & bit)) {
+          const int bytes = int(kRcWindowBytes + 2048);
+          KSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc<KeyT, 1024>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+          KSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc<KeyT, 512>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+          KSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc<KeyT, 256>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+          KSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc<KeyT, 64>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+          KSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rc_hist<KeyT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, int(size_t(4) << 15)));
+          ctx->lds_opt_in |= bit;
+        }
+      }
+      KSH_BOUND(hist_lds <= (size_t(4) << 15) && ng <= 65536);  // k_rc_hist's LDS histogram; group ids travel as u16
+      hipLaunchKernelGGL((k_rc_hist<KeyT>), dim3(unsigned(rows)), dim3(1024), hist_lds, st,
+                         static_cast<const KeyT*>(sv->d_keys), n, g->k, key_bits(g), gbits, per_row, hist);
+      hipLaunchKernelGGL(k_rc_columns, dim3(unsigned((ng + 63) / 64)), dim3(64 * kColTeams), 0, st, hist, rows, int(ng),
+                         totals);
+      KSH_TRY(scan_exclusive_i64(ctx, totals, goff, ng, goff + ng));
+      if (two_level) {
         // two levels of run-wise writes; the intermediate records borrow arrays that are written
         // later: u32 keys: the upper half of the chain-rank records; u64 keys (16-byte records): the
         // neighbour + link arrays (rc0 / rc1 and nbr are only written after level 2); the group ids
@@ -3004,50 +2924,43 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
         KSH_BOUND(sizeof(RcRecord<KeyT>) == 8 ? size_t(2 * n) * sizeof(RcRecord<KeyT>) <= al(size_t(2 * n) * 8)
                                     : reinterpret_cast<char*>(p->link) == reinterpret_cast<char*>(p->nbr) + al(size_t(2 * n) * 4) &&
                                           size_t(n) * sizeof(RcRecord<KeyT>) <= 2 * al(size_t(2 * n) * 4));
-        KSH_BOUND(nb <= 65536);  // tmp_g holds group ids as u16
-        uint32_t* cursor = rc_cursor;
+        KSH_BOUND(gbits - kSgBits <= 8);  // k_rc_scatter_l2: two super-groups' groups in its 512 bins
+        uint32_t* cursor = rc_cursor;     // (2^gbits zeroed words behind the control block)
         constexpr int kPer = sizeof(RcRecord<KeyT>) == 8 ? 4 : 2;
-        hipLaunchKernelGGL((k_rc_scatter_l1<KeyT, kPer>), dim3(unsigned(rows)), dim3(kL1Threads), 0, st, set, nbits,
+        hipLaunchKernelGGL((k_rc_scatter_l1<KeyT, kPer>), dim3(unsigned(rows)), dim3(kL1Threads), 0, st, set, gbits,
                            per_row, hist, goff, tmp_rec, tmp_g);
         hipLaunchKernelGGL((k_rc_scatter_l2<KeyT>), dim3(unsigned((n + kL2Tile - 1) / kL2Tile)), dim3(kL2Threads), 0,
-                           st, n, nbits, goff, tmp_rec, tmp_g, cursor, rec);
+                           st, n, gbits, goff, tmp_rec, tmp_g, cursor, rec);
       } else {
-        hipLaunchKernelGGL((k_rc_scatter<KeyT>), dim3(unsigned(rows)), dim3(1024), hist_lds, st, set, nbits, 0, 0,
+        hipLaunchKernelGGL((k_rc_scatter<KeyT>), dim3(unsigned(rows)), dim3(1024), hist_lds, st, set, gbits, 0, 0,
                            per_row, hist, goff, rec);
       }
-      // LDS window: a bucket with a quarter to spare (larger ranges are staged in batches)
+      // LDS window: a group's range with some to spare (larger ranges are staged in batches).  Half-bucket
+      // groups: 15 % to spare, so that four workgroups (window + 1 KB of static LDS each) share a CU's 160 KB.
+      const int64_t per_group = n / ng;
       const int cap = int(std::min<int64_t>((kRcWindowBytes - 4 * kRcSegs) / int64_t(sizeof(KeyT) + 6),
-                                            std::max<int64_t>(1024, (n / nb) * 5 / 4 + 256)));
+                                            std::max<int64_t>(1024, extra ? per_group * 23 / 20 + 256 : per_group * 5 / 4 + 256)));
       const size_t rc_lds = size_t(cap) * (sizeof(KeyT) + 4) + size_t(cap + 2 * kRcSegs) * 2;
       // k_adj_rc keeps window positions, lengths and slice-index offsets in 16 bits (sidx, RcBatch::packed)
       KSH_BOUND(cap >= 1 && cap + 2 * kRcSegs < 65536);
       KSH_BOUND(rc_lds + 2048 <= size_t(kRcWindowBytes) + 2048 && rc_lds <= size_t(kRcWindowBytes));
-      int64_t* pb = static_cast<int64_t*>(arena_alloc(ctx, size_t(nb) * 2 * kRcSegs * 8));
-      if (!pb) return fail(KSH_INTERNAL, "scratch arena too small");
-      hipLaunchKernelGGL((k_rc_bounds<KeyT>), dim3(nblk(nb * 2 * kRcSegs)), dim3(256), 0, st, set, nbits, pb);
-      {
-        // (more than the 64 KB a kernel gets without asking; per context: the attribute is the device's)
-        const uint32_t bit = 1u << (sizeof(KeyT) == 2 ? 0 : sizeof(KeyT) == 4 ? 1 : 2);
-        if (!(ctx->lds_opt_in & bit)) {
-          const int bytes = int(kRcWindowBytes + 2048);
-          KSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc<KeyT, 1024>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-          KSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc<KeyT, 256>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-          KSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc<KeyT, 64>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
-          ctx->lds_opt_in |= bit;
-        }
-      }
-      if (n / nb > 2048)
-        hipLaunchKernelGGL((k_adj_rc<KeyT, 1024>), dim3(unsigned(nb)), dim3(1024), rc_lds, st, set, nbits, goff,
-                           rec, pb, cap, rc0, rc1);
-      else if (n / nb > 256)
-        hipLaunchKernelGGL((k_adj_rc<KeyT, 256>), dim3(unsigned(nb)), dim3(256), rc_lds, st, set, nbits, goff,
-                           rec, pb, cap, rc0, rc1);
+      int64_t* pb = static_cast<int64_t*>(arena_alloc(ctx, size_t(ng) * 2 * kRcSegs * 8));
+      int64_t* pb0 = extra ? static_cast<int64_t*>(arena_alloc(ctx, size_t(ng) * 2 * 8)) : nullptr;
+      if (!pb || (extra && !pb0)) return fail(KSH_INTERNAL, "scratch arena too small");
+      hipLaunchKernelGGL((k_rc_bounds<KeyT>), dim3(nblk(ng * 2 * kRcSegs + (extra ? ng * 2 : 0))), dim3(256), 0, st, set,
+                         gbits, pb, pb0);
+      if (per_group > 4096)
+        hipLaunchKernelGGL((k_adj_rc<KeyT, 1024>), dim3(unsigned(ng)), dim3(1024), rc_lds, st, set, gbits, goff,
+                           rec, pb, pb0, cap, rc0, rc1);
+      else if (per_group > 1024)
+        hipLaunchKernelGGL((k_adj_rc<KeyT, 512>), dim3(unsigned(ng)), dim3(512), rc_lds, st, set, gbits, goff,
+                           rec, pb, pb0, cap, rc0, rc1);
+      else if (per_group > 256)
+        hipLaunchKernelGGL((k_adj_rc<KeyT, 256>), dim3(unsigned(ng)), dim3(256), rc_lds, st, set, gbits, goff,
+                           rec, pb, pb0, cap, rc0, rc1);
       else
-        hipLaunchKernelGGL((k_adj_rc<KeyT, 64>), dim3(unsigned(nb)), dim3(64), rc_lds, st, set, nbits, goff,
-                           rec, pb, cap, rc0, rc1);
+        hipLaunchKernelGGL((k_adj_rc<KeyT, 64>), dim3(unsigned(ng)), dim3(64), rc_lds, st, set, gbits, goff,
+                           rec, pb, pb0, cap, rc0, rc1);
       static const bool fwd_probe = [] {
         const char* e = getenv("KSH_FWD");
         return e && std::string(e) == "probe";
@@ -3060,21 +2973,9 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
         int64_t* bounds = reinterpret_cast<int64_t*>(p->info);  // kFwdBounds * 8 bytes per 512 k-mers
         KSH_BOUND(size_t(n_chunks + 1) * kFwdBounds * 8 <= al(size_t(2 * n) * 8));
         hipLaunchKernelGGL((k_fwd_bounds<KeyT>), dim3(nblk(n_chunks + 1)), dim3(256), 0, st, set, n_chunks, bounds);
-        // KSH_FWD=pipe: persistent workgroups that prefetch the next chunk's windows under this chunk's search
-        static const bool fwd_pipe = [] {
-          const char* e = getenv("KSH_FWD");
-          return e && std::string(e) == "pipe";
-        }();
-        if (fwd_pipe) {
-          static const int n_cus = [] {
-            int dev = 0, cus = 256;
-            if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-            return cus;
-          }();
-          const int64_t groups = std::min<int64_t>(n_chunks, int64_t(n_cus) * kFwdPipeGroupsPerCu);
-          hipLaunchKernelGGL((k_adj_fwd_pipe<KeyT>), dim3(unsigned(groups)), dim3(kFwdChunk), 0, st, set, bounds, n_chunks,
-                             rc0, rc1, p->nbr, self_rc_flag);
-        } else
+        // (measured and dropped, round 3: a Next window for twice the range, 6144 keys, still four workgroups per
+        // CU: 3 % of the k-mers instead of 15 % fall back to probes in global memory, and the kernel takes
+        // 1.88 ms per 10^8 against 1.87 -- the fall-backs are not what it waits for.  profiles/r03_probe_stage_ab.txt)
         hipLaunchKernelGGL((k_adj_fwd_staged<KeyT>), dim3(unsigned(n_chunks)), dim3(kFwdChunk), 0, st, set, bounds,
                            rc0, rc1, p->nbr, self_rc_flag);
 #ifdef KSH_FWD_DEBUG

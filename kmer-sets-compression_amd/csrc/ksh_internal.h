@@ -67,7 +67,7 @@ struct ksh_ctx {
   size_t slot_bytes[3] = {0, 0, 0};
 
   // decode plan state
-  int64_t dec_words = 0, dec_groups = 0, dec_kmers = 0;
+  int64_t dec_words = 0, dec_groups = 0, dec_kmers = 0, dec_max_bucket = 0;
   const void* dec_src = nullptr;
 
   // encode plan state (ksh_encode.hip)

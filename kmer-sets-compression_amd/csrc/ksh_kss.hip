@@ -310,6 +310,47 @@ static int pair_weights(ksh_kss* k, const std::vector<int32_t>& ids,
 
 static std::string serialize_children(const std::map<int, std::vector<int>>& a);
 
+// The weights that a merge of (j, k) into the new node n changes.  The reference weighs all three families
+// again -- (j, l), (k, l) and (l, n) for every l (kmer_set_set.h:385-425) -- 3 n sampled intersections per
+// iteration, which is 4 x the bytes of the iteration's full merge.  Only the last family is weighed here:
+// j has become j \ n and k has become k \ n with n = j & k a subset of both, and a sampled weight is a sum
+// of per-bucket intersection sizes, so |(j \ n) & l| = |j & l| - |n & l| and the same for k: the integers
+// the reference counts, by subtraction from the table; j', k' and n are pairwise disjoint, weight 0.
+// KSH_REWEIGH=full: all three families weighed, as the reference does (A/B runs; the tests run both).
+template <typename WeighFn>
+static int reweigh_after_merge(int j, int kk, int n, std::map<std::pair<int, int>, int64_t>* weights, WeighFn weigh) {
+  static const bool full = [] {
+    const char* e = getenv("KSH_REWEIGH");
+    return e && std::string(e) == "full";
+  }();
+  std::vector<std::pair<int, int>> pairs;
+  std::vector<int64_t> w;
+  if (full) {
+    for (int l = 0; l < n; l++)
+      if (j != l) pairs.emplace_back(std::min(j, l), std::max(j, l));
+    for (int l = 0; l < n; l++)
+      if (kk != l) pairs.emplace_back(std::min(kk, l), std::max(kk, l));
+    for (int l = 0; l < n; l++) pairs.emplace_back(l, n);
+    KSH_TRY(weigh(pairs, &w));
+    for (size_t q = 0; q < pairs.size(); q++) (*weights)[pairs[q]] = w[q];
+    return KSH_OK;
+  }
+  for (int l = 0; l < n; l++)
+    if (l != j && l != kk) pairs.emplace_back(l, n);
+  KSH_TRY(weigh(pairs, &w));
+  for (size_t q = 0; q < pairs.size(); q++) {
+    const int l = pairs[q].first;
+    (*weights)[pairs[q]] = w[q];
+    (*weights)[{std::min(j, l), std::max(j, l)}] -= w[q];
+    (*weights)[{std::min(kk, l), std::max(kk, l)}] -= w[q];
+  }
+  (*weights)[{std::min(j, kk), std::max(j, kk)}] = 0;
+  (*weights)[{j, n}] = 0;
+  (*weights)[{kk, n}] = 0;
+  return KSH_OK;
+}
+
+
 // Weight() of the node's SPSS without the SPSS: the encode's plan (unitigs, path cover, string layout)
 // gives n_strings and n_bases; the bases are not emitted.  For nodes the loop will merge again before it
 // ends: their strings would be thrown away (the convergence checks only read Weight(), kmer_set_set.h:287).
@@ -343,8 +384,13 @@ __global__ __launch_bounds__(256) void k_sample_copy(const int64_t* __restrict__
   const int64_t bytes = (off[b + 1] - off[b]) * key_bytes;
   const char* src = keys + off[b] * key_bytes;
   char* dst = keys_s + off_s[b] * key_bytes;
-  for (int64_t i = int64_t(threadIdx.x) * 4; i < bytes; i += 256 * 4)
-    *reinterpret_cast<uint32_t*>(dst + i) = *reinterpret_cast<const uint32_t*>(src + i);
+  if (key_bytes >= 4) {
+    for (int64_t i = int64_t(threadIdx.x) * 4; i < bytes; i += 256 * 4)
+      *reinterpret_cast<uint32_t*>(dst + i) = *reinterpret_cast<const uint32_t*>(src + i);
+  } else {  // 2-byte keys: a bucket's bytes need not be a multiple of four, nor its start four-byte aligned
+    for (int64_t i = int64_t(threadIdx.x) * 2; i < bytes; i += 256 * 2)
+      *reinterpret_cast<uint16_t*>(dst + i) = *reinterpret_cast<const uint16_t*>(src + i);
+  }
 }
 
 static size_t a16(size_t x) { return (x + 15) & ~size_t(15); }
@@ -1207,22 +1253,8 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
     k->children[kk].push_back(n);
 
     {
-      std::vector<std::pair<int, int>> pairs;
-      for (int l = 0; l < n; l++) {
-        if (j == l) continue;
-        pairs.emplace_back(std::min(j, l), std::max(j, l));
-      }
-      for (int l = 0; l < n; l++) {
-        if (kk == l) continue;
-        pairs.emplace_back(std::min(kk, l), std::max(kk, l));
-      }
-      for (int l = 0; l < n; l++) pairs.emplace_back(l, n);
-      std::vector<int64_t> w;
-      {
-        PhaseTimer pt(k, 1);
-        KSH_TRY(weigh(pairs, &w));
-      }
-      for (size_t q = 0; q < pairs.size(); q++) weights[pairs[q]] = w[q];
+      PhaseTimer pt(k, 1);
+      KSH_TRY(reweigh_after_merge(j, kk, n, &weights, weigh));
     }
   }
   if (pend.active) {  // the loop ended between checks (max_iterations, no common k-mers left): the last check still decides
@@ -1383,22 +1415,10 @@ static int build(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs,
     k->trace.insert(k->trace.end(), {int64_t(j), int64_t(kk), weight, original_size, size_diff});
 
     {
-      std::vector<std::pair<int, int>> pairs;
-      for (int l = 0; l < n; l++) {
-        if (j == l) continue;
-        pairs.emplace_back(std::min(j, l), std::max(j, l));
-      }
-      for (int l = 0; l < n; l++) {
-        if (kk == l) continue;
-        pairs.emplace_back(std::min(kk, l), std::max(kk, l));
-      }
-      for (int l = 0; l < n; l++) pairs.emplace_back(l, n);
-      std::vector<int64_t> w;
-      {
-        PhaseTimer pt(k, 1);
-        KSH_TRY(pair_weights(k, ids, pairs, &w));
-      }
-      for (size_t q = 0; q < pairs.size(); q++) weights[pairs[q]] = w[q];
+      PhaseTimer pt(k, 1);
+      KSH_TRY(reweigh_after_merge(j, kk, n, &weights, [&](const std::vector<std::pair<int, int>>& pairs, std::vector<int64_t>* w) {
+        return pair_weights(k, ids, pairs, w);
+      }));
     }
   }
   k->final_total_size = total_size;
@@ -1514,15 +1534,9 @@ static int build_single(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_input
       k->sample_pooled[size_t(j)] = k->sample_pooled[size_t(kk)] = true;
       k->samples.push_back(sn);
       k->sample_pooled.push_back(true);
-      std::vector<std::pair<int, int>> pairs;
-      for (int l = 0; l < n; l++)
-        if (j != l) pairs.emplace_back(std::min(j, l), std::max(j, l));
-      for (int l = 0; l < n; l++)
-        if (kk != l) pairs.emplace_back(std::min(kk, l), std::max(kk, l));
-      for (int l = 0; l < n; l++) pairs.emplace_back(l, n);
-      std::vector<int64_t> w;
-      KSH_TRY(sample_weights(k, ids, pairs, &w));
-      for (size_t q = 0; q < pairs.size(); q++) weights[pairs[q]] = w[q];
+      KSH_TRY(reweigh_after_merge(j, kk, n, &weights, [&](const std::vector<std::pair<int, int>>& pairs, std::vector<int64_t>* w) {
+        return sample_weights(k, ids, pairs, w);
+      }));
     }
     return KSH_OK;
   };

@@ -324,3 +324,37 @@ def test_loop_control_ahead(gpu):
     env = dict(os.environ, KSH_KSS_LOOP="ahead")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "control ahead ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
+def test_loop_reweigh_full(gpu):
+    """KSH_REWEIGH=full: all three weight families of an iteration weighed again, as the reference does
+    (kmer_set_set.h:385-425), instead of the default (the new node's family weighed, the two remainders'
+    by subtraction: |(j \\ n) & l| = |j & l| - |n & l|) -- the same trace, checkpoints and nodes as the oracle
+    either way; the default route is what every other test of this file runs."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import oracle_lib as ol\n"
+        "from kmersets import capi, synth\n"
+        "ctx = capi.Context(0)\n"
+        "for (k, n, kb, n_sets, size, seed) in ((15, 14, 2, 10, 6000, 3), (23, 14, 4, 12, 20000, 5)):\n"
+        "    g = capi.geom(k, n)\n"
+        "    sets = synth.phylogeny_sets(k, n_sets, size, seed=seed); ids = synth.sample_bucket_ids(n, seed=seed + 1)\n"
+        "    oc = [ol.Set.from_kmers(k, n, kb, s).compact() for s in sets]\n"
+        "    o = ol.KmerSetSet(oc, ids)\n"
+        "    d = capi.DeviceKmerSetSet(ctx, [capi.DeviceSpss.from_strings(g, c.strings(), ctx.device) for c in oc], ids)\n"
+        "    it, cp, imp = d.trace(); ocp, oimp = o.checkpoints()\n"
+        "    assert np.array_equal(it, o.iterations()) and np.array_equal(cp, ocp) and np.array_equal(imp, oimp)\n"
+        "    assert d.meta() == o.meta() and d.size() == o.size()\n"
+        "    assert all(d.node_strings(i) == o.node(i).strings() for i in range(o.size()))\n"
+        "    d.close()\n"
+        "print('reweigh full ok')\n"
+    ) % (os.path.join(here, "..", "kmer-sets-compression_amd"), here)
+    env = dict(os.environ, KSH_REWEIGH="full")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "reweigh full ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]

@@ -334,7 +334,7 @@ def test_encode_branching_sets(ctx):
             assert st["unitigs"] > 700 and st["strings"] < st["unitigs"]
 
 
-@pytest.mark.parametrize("knob", ["KSH_RANK=stamp", "KSH_EMIT=walk", "KSH_L2_MIN=4096", "KSH_ADJACENCY=probe", "KSH_FWD=probe", "KSH_RC_SCATTER=direct"])
+@pytest.mark.parametrize("knob", ["KSH_RANK=stamp", "KSH_EMIT=walk", "KSH_L2_MIN=4096", "KSH_ADJACENCY=probe", "KSH_FWD=probe", "KSH_RC_SCATTER=direct", "KSH_RC_GROUPS=half"])
 def test_encode_alternative_paths(gpu, knob):
     """The encoder's other routes give the oracle's strings too: the stamping ranking walks with
     k_choose / k_emit per k-mer (what a set with a non-branching loop falls back to), the strings

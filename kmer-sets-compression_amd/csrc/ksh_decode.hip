@@ -24,6 +24,8 @@
 #include "ksh_kmer.h"
 
 #include <algorithm>
+#include <cstdlib>
+#include <string>
 #include <vector>
 
 namespace ksh {
@@ -123,6 +125,193 @@ __global__ __launch_bounds__(kDecThreads) void k_decode(
   if (!kScatter) {
     __syncthreads();
     for (int b = threadIdx.x; b < n_buckets; b += kDecThreads) my_row[b] = lds_hist[b];
+  }
+}
+
+// ---- the scatter in two levels, for large inputs ---------------------------------------------------
+// k_decode<true> writes every key to a random one of 2^N buckets: 10^8 scattered 4-byte stores, the slowest
+// thing the memory system does (1.29 ms per 10^8).  Here every store instruction writes runs, as the SPSS
+// encode's record scatter does (ksh_encode.hip, k_rc_scatter_l1 / l2).  Level 1 (k_decode_l1, the same
+// groups of words and histogram rows as the counting pass): a group takes its words tile by tile
+// (256 words, 8192 positions: a thread rolls a quarter of a word), sorts the tile's keys by SUPER-BUCKET
+// (the top kDecSgBits bucket bits) in LDS and appends each super-bucket's run to the group's share of
+// it -- known exactly from the histogram rows: no atomics in global memory.  Level 2 (k_decode_l2): a
+// tile of the intermediate array lies in one super-bucket (two at a seam), is sorted by bucket in LDS,
+// and a bucket's run goes where one atomicAdd per (tile, bucket) says.  k_bucket_sort orders the buckets.
+constexpr int kDecSgBits = 7;
+constexpr int kDecL1Threads = 1024;
+constexpr int kDecL1Per = 8;                               // positions per thread and tile
+constexpr int kDecL1Tile = kDecL1Threads * kDecL1Per;      // positions per tile: 256 words
+constexpr int kDecL2Threads = 256;
+constexpr int kDecL2Per = 8;
+constexpr int kDecL2Tile = kDecL2Threads * kDecL2Per;
+
+template <typename KeyT>
+__global__ __launch_bounds__(kDecL1Threads) void k_decode_l1(
+    const uint64_t* __restrict__ words, int64_t n_words, int64_t n_bases,
+    const unsigned long long* __restrict__ end_bits, int64_t n_end_words, int k, int key_bits, int n_bucket_bits,
+    int canonical_flag, int64_t words_per_group, const uint32_t* __restrict__ hist_matrix,
+    const int64_t* __restrict__ offsets, KeyT* __restrict__ tmp_keys, uint16_t* __restrict__ tmp_b) {
+  constexpr int kSg = 1 << kDecSgBits;
+  __shared__ KeyT s_key[kDecL1Tile];
+  __shared__ uint16_t s_bkt[kDecL1Tile];
+  __shared__ uint32_t s_cur[kSg], s_cnt[kSg], s_lbase[kSg + 1];
+  const int tid = threadIdx.x;
+  const int nb = 1 << n_bucket_bits, lo_bits = n_bucket_bits - kDecSgBits;
+  const uint32_t* my_row = hist_matrix + int64_t(blockIdx.x) * nb;
+  if (tid < kSg) {
+    // where this group's share of super-bucket tid starts: the super-bucket's start, plus what the groups
+    // before this one put into each of its buckets (the intermediate layout is [super-bucket][group][tile order])
+    uint32_t at = uint32_t(offsets[int64_t(tid) << lo_bits]);
+    for (int bi = 0; bi < (1 << lo_bits); bi++) at += my_row[(tid << lo_bits) + bi];
+    s_cur[tid] = at;
+    s_cnt[tid] = 0;
+  }
+  const int64_t w_begin = int64_t(blockIdx.x) * words_per_group;
+  const int64_t w_end = min(w_begin + words_per_group, n_words);
+  const uint64_t mask = kmer_mask(k);
+  const uint64_t key_mask = (uint64_t(1) << key_bits) - 1;
+  const uint64_t no_end_mask = (uint64_t(1) << (k - 1)) - 1;  // bits p .. p+K-2 must be clear
+  __syncthreads();
+  for (int64_t w0i = w_begin; w0i < w_end; w0i += kDecL1Tile / 32) {
+    const int64_t w = w0i + (tid >> 2);
+    const int j0 = (tid & 3) * kDecL1Per;
+    KeyT key[kDecL1Per];
+    uint32_t bkt[kDecL1Per], rank[kDecL1Per];
+#pragma unroll
+    for (int j = 0; j < kDecL1Per; j++) bkt[j] = 0xFFFFFFFFu;
+    if (w < w_end) {
+      const uint64_t w0 = words[w];
+      const uint64_t w1 = (w + 1 < n_words) ? words[w + 1] : 0;
+      const int64_t p0 = w << 5;
+      const int64_t ew = p0 >> 6;
+      const int esh = int(p0 & 63);
+      uint64_t eb = end_bits[ew] >> esh;
+      if (esh && ew + 1 < n_end_words) eb |= end_bits[ew + 1] << (64 - esh);
+      // the k-mer at position j0 of the word: bases j0 .. j0 + K - 1 of the window w0:w1 (j0 + K <= 55)
+      const int top = 2 * (j0 + k);  // bits of the window up to and including the k-mer's last base
+      uint64_t fw = (top <= 64 ? (w0 >> (64 - top)) : ((w0 << (top - 64)) | (w1 >> (128 - top)))) & mask;
+      uint64_t rc = revcomp(fw, k);
+#pragma unroll
+      for (int j = 0; j < kDecL1Per; j++) {
+        const int jj = j0 + j;
+        const int64_t p = p0 + jj;
+        const bool valid = (p + k <= n_bases) && (((eb >> jj) & no_end_mask) == 0);
+        if (valid) {
+          const uint64_t cn = (canonical_flag && rc < fw) ? rc : fw;
+          bkt[j] = uint32_t(cn >> key_bits);
+          key[j] = KeyT(cn & key_mask);
+          rank[j] = atomicAdd(&s_cnt[bkt[j] >> lo_bits], 1u);
+        }
+        const int q = jj + k;  // position inside the 64-base window of the base that enters
+        const uint64_t nbase = q < 32 ? (w0 >> (62 - 2 * q)) & 3 : (w1 >> (62 - 2 * (q - 32))) & 3;
+        fw = ((fw << 2) & mask) | nbase;
+        rc = (rc >> 2) | ((3 - nbase) << (2 * (k - 1)));
+      }
+    }
+    __syncthreads();
+    if (tid < kSg) {
+      uint32_t before = 0;
+      for (int b = 0; b < tid; b++) before += s_cnt[b];
+      s_lbase[tid] = before;
+      if (tid == kSg - 1) s_lbase[kSg] = before + s_cnt[tid];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < kDecL1Per; j++) {
+      if (bkt[j] == 0xFFFFFFFFu) continue;
+      const uint32_t pos = s_lbase[bkt[j] >> lo_bits] + rank[j];
+      s_key[pos] = key[j];
+      s_bkt[pos] = uint16_t(bkt[j]);
+    }
+    __syncthreads();
+    const int tile_n = int(s_lbase[kSg]);
+    for (int i = tid; i < tile_n; i += kDecL1Threads) {
+      const uint32_t sg = uint32_t(s_bkt[i]) >> lo_bits;
+      const uint32_t dst = s_cur[sg] + (uint32_t(i) - s_lbase[sg]);
+      tmp_keys[dst] = s_key[i];
+      tmp_b[dst] = s_bkt[i];
+    }
+    __syncthreads();
+    if (tid < kSg) {
+      s_cur[tid] += s_cnt[tid];
+      s_cnt[tid] = 0;
+    }
+    __syncthreads();
+  }
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(kDecL2Threads) void k_decode_l2(int64_t n, int n_bucket_bits,
+                                                             const int64_t* __restrict__ offsets,
+                                                             const KeyT* __restrict__ tmp_keys,
+                                                             const uint16_t* __restrict__ tmp_b,
+                                                             uint32_t* __restrict__ cursor, KeyT* __restrict__ keys) {
+  constexpr int kBins = 2 * kDecL2Threads;  // two super-buckets' worth of buckets (a super-bucket has at most 256)
+  __shared__ KeyT s_key[kDecL2Tile];
+  __shared__ uint16_t s_bin[kDecL2Tile];
+  __shared__ uint32_t s_cnt[kBins], s_lbase[kBins], s_gbase[kBins];
+  __shared__ uint32_t s_wave[kDecL2Threads / 64];
+  __shared__ uint32_t s_first;
+  const int tid = threadIdx.x;
+  const int lo_bits = n_bucket_bits - kDecSgBits;
+  const int64_t p0 = int64_t(blockIdx.x) * kDecL2Tile;
+  const int tile_n = int(min<int64_t>(kDecL2Tile, n - p0));
+  s_cnt[2 * tid] = 0;
+  s_cnt[2 * tid + 1] = 0;
+  if (tid == 0) s_first = (uint32_t(tmp_b[p0]) >> lo_bits) << lo_bits;  // first bucket of the tile's first super-bucket
+  __syncthreads();
+  const uint32_t base_b = s_first;
+  const uint32_t n_bins = min<uint32_t>(uint32_t(kBins), (2u << lo_bits));
+  KeyT mine[kDecL2Per];
+  uint32_t bin[kDecL2Per], rank[kDecL2Per];
+#pragma unroll
+  for (int j = 0; j < kDecL2Per; j++) {
+    const int i = tid + j * kDecL2Threads;
+    bin[j] = 0xFFFFFFFFu;
+    if (i >= tile_n) continue;
+    mine[j] = tmp_keys[p0 + i];
+    const uint32_t b = tmp_b[p0 + i];
+    if (b - base_b < n_bins) {
+      bin[j] = b - base_b;
+      rank[j] = atomicAdd(&s_cnt[bin[j]], 1u);
+    } else {
+      // a tile over three or more super-buckets (tiny or very skewed inputs): one key at a time
+      keys[uint32_t(offsets[b]) + atomicAdd(&cursor[b], 1u)] = mine[j];
+    }
+  }
+  __syncthreads();
+  {
+    const uint32_t c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
+    uint32_t inc = c0 + c1;
+    const int lane = tid & 63, wv = tid >> 6;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t o = __shfl_up(inc, d, 64);
+      if (lane >= d) inc += o;
+    }
+    if (lane == 63) s_wave[wv] = inc;
+    __syncthreads();
+    uint32_t before = inc - (c0 + c1);
+    for (int w = 0; w < wv; w++) before += s_wave[w];
+    s_lbase[2 * tid] = before;
+    s_lbase[2 * tid + 1] = before + c0;
+    s_gbase[2 * tid] = c0 ? uint32_t(offsets[base_b + 2 * tid]) + atomicAdd(&cursor[base_b + 2 * tid], c0) : 0u;
+    s_gbase[2 * tid + 1] = c1 ? uint32_t(offsets[base_b + 2 * tid + 1]) + atomicAdd(&cursor[base_b + 2 * tid + 1], c1) : 0u;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < kDecL2Per; j++) {
+    if (bin[j] == 0xFFFFFFFFu) continue;
+    const uint32_t pos = s_lbase[bin[j]] + rank[j];
+    s_key[pos] = mine[j];
+    s_bin[pos] = uint16_t(bin[j]);
+  }
+  __syncthreads();
+  const uint32_t staged = s_lbase[kBins - 1] + s_cnt[kBins - 1];  // (uniform; the far keys were written directly)
+  for (uint32_t i = tid; i < staged; i += kDecL2Threads) {
+    const uint32_t b = s_bin[i];
+    keys[s_gbase[b] + (i - s_lbase[b])] = s_key[i];
   }
 }
 
@@ -596,10 +785,37 @@ int decode_write_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int 
   DecodeState st;
   decode_carve(ctx, groups, nb, n_end_words, s->n_strings, &st);
   KeyT* keys = static_cast<KeyT*>(d_keys);
-  hipLaunchKernelGGL((k_decode<KeyT, true>), dim3(unsigned(groups)), dim3(kDecThreads),
-                     size_t(nb) * 4, ctx->stream, s->d_words, n_words, s->n_bases, st.end_bits,
-                     n_end_words, g->k, key_bits(g), int(nb), canonical_flag, wpg, st.hist, d_offsets,
-                     keys);
+  // KSH_DECODE_SCATTER=direct: one scattered store per k-mer (k_decode<true>), for A/B runs and small inputs
+  static const bool direct = [] {
+    const char* e = getenv("KSH_DECODE_SCATTER");
+    return e && std::string(e) == "direct";
+  }();
+  static const int64_t two_level_min = [] {
+    const char* e = getenv("KSH_DECODE_L2_MIN");  // (tests set it low)
+    return e ? std::max<int64_t>(1024, atoll(e)) : int64_t(1) << 20;
+  }();
+  if (!direct && ctx->dec_kmers >= two_level_min && g->n_bucket_bits > kDecSgBits && g->n_bucket_bits <= 15 &&
+      ctx->dec_kmers < int64_t(0xFFFFFFF0)) {
+    void* tmp = nullptr;
+    const size_t tk = (size_t(ctx->dec_kmers) * sizeof(KeyT) + 255) & ~size_t(255);
+    KSH_TRY(pool_alloc(ctx, tk + size_t(ctx->dec_kmers) * 2 + size_t(nb) * 4 + 256, &tmp));
+    KeyT* tmp_keys = static_cast<KeyT*>(tmp);
+    uint16_t* tmp_b = reinterpret_cast<uint16_t*>(static_cast<char*>(tmp) + tk);
+    uint32_t* cursor = reinterpret_cast<uint32_t*>(static_cast<char*>(tmp) + tk + ((size_t(ctx->dec_kmers) * 2 + 255) & ~size_t(255)));
+    KSH_HIP(hipMemsetAsync(cursor, 0, size_t(nb) * 4, ctx->stream));
+    hipLaunchKernelGGL((k_decode_l1<KeyT>), dim3(unsigned(groups)), dim3(kDecL1Threads), 0, ctx->stream, s->d_words,
+                       n_words, s->n_bases, st.end_bits, n_end_words, g->k, key_bits(g), g->n_bucket_bits,
+                       canonical_flag, wpg, st.hist, d_offsets, tmp_keys, tmp_b);
+    hipLaunchKernelGGL((k_decode_l2<KeyT>), dim3(unsigned((ctx->dec_kmers + kDecL2Tile - 1) / kDecL2Tile)),
+                       dim3(kDecL2Threads), 0, ctx->stream, ctx->dec_kmers, g->n_bucket_bits, d_offsets, tmp_keys, tmp_b,
+                       cursor, keys);
+    pool_free(ctx, tmp);  // (single stream: the block is reused only behind these launches)
+  } else {
+    hipLaunchKernelGGL((k_decode<KeyT, true>), dim3(unsigned(groups)), dim3(kDecThreads),
+                       size_t(nb) * 4, ctx->stream, s->d_words, n_words, s->n_bases, st.end_bits,
+                       n_end_words, g->k, key_bits(g), int(nb), canonical_flag, wpg, st.hist, d_offsets,
+                       keys);
+  }
   // per-bucket sort + duplicate removal; uniq counts reuse st.totals.  Buckets larger than the
   // LDS capacity are partitioned through a scratch copy first; whether any exists is read off
   // the bucket offsets (128 KiB to the host).

@@ -83,6 +83,48 @@ def test_decode_empty_and_tiny(ctx):
     assert int(got.kmers()[0]) == int(ol.lib().ko_canonical(ol.kmer(one), k))
 
 
+def test_decode_two_level_scatter(gpu):
+    """The decode's two-level run-wise scatter (k_decode_l1 / k_decode_l2: what inputs of 2^20 k-mers and
+    more take) on small inputs (KSH_DECODE_L2_MIN=1024), against the oracle: SPSS of phylogeny sets at the
+    three key widths, arbitrary lines with repeated k-mers and string ends at every offset of a word,
+    a k-mer count with a cutoff; and the direct scatter (KSH_DECODE_SCATTER=direct) on the same."""
+    import os
+    import subprocess
+    import sys
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import oracle_lib as ol\n"
+        "from kmersets import capi, synth\n"
+        "ctx = capi.Context(0)\n"
+        "for (k, n, kb) in ((15, 14, 2), (23, 14, 4), (31, 14, 8), (23, 10, 8)):\n"
+        "    for kmers in synth.phylogeny_sets(k, 2, 50000, seed=k) + [synth.random_read_kmers(k, 3000, seed=k, canonical=True)]:\n"
+        "        o = ol.Set.from_kmers(k, n, kb, kmers)\n"
+        "        sp = capi.DeviceSpss.from_strings(capi.geom(k, n, kb), o.spss(), ctx.device)\n"
+        "        got = ctx.spss_decode(sp)\n"
+        "        assert got.n_keys == o.size() and np.array_equal(got.kmers(), o.kmers()), (k, n)\n"
+        "k, n, kb = 23, 14, 4\n"
+        "text = synth.string_of_bases(synth.random_genome(60000, 5))\n"
+        "lines, at = [], 0\n"
+        "for i in range(900):\n"
+        "    ln = k + (i * 7) %% 90\n"
+        "    lines.append(text[at:at + ln]); at += ln - (i %% 5)\n"
+        "want = ol.Set.from_spss(lines, k, n, kb)\n"
+        "got = ctx.spss_decode(capi.DeviceSpss.from_strings(capi.geom(k, n), lines, ctx.device))\n"
+        "assert got.n_keys == want.size() and np.array_equal(got.kmers(), want.kmers())\n"
+        "c = ol.Counter(k, n, kb); c.from_reads(lines + lines[:300]); wset, w_cut = c.to_set(2)\n"
+        "gset, n_cut = ctx.kmer_count(capi.DeviceSpss.from_strings(capi.geom(k, n), lines + lines[:300], ctx.device), 2)\n"
+        "assert np.array_equal(gset.kmers(), wset.kmers()) and n_cut == w_cut\n"
+        "print('decode routes ok')\n"
+    ) % (os.path.join(here, "..", "kmer-sets-compression_amd"), here)
+    for env_add in ({"KSH_DECODE_L2_MIN": "1024"}, {"KSH_DECODE_SCATTER": "direct"}):
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, **env_add), capture_output=True, text=True,
+                           timeout=600)
+        assert r.returncode == 0 and "decode routes ok" in r.stdout, str(env_add) + r.stdout[-2000:] + r.stderr[-4000:]
+
+
 # ------------------------------------------------------------------------------ encode
 def check_encode(ctx, k, n, kb, kmers):
     oset = ol.Set.from_kmers(k, n, kb, kmers)

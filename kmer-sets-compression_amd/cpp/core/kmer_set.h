@@ -94,7 +94,14 @@ class KmerSet {
     host_valid_ = false;
   }
 
-  bool Contains(const Kmer<K>& kmer) const { return Contains(std::vector<Kmer<K>>{kmer})[0]; }
+  // One k-mer: a binary search in the host copy (the one Find keeps; fetched here for sets of up to 2^24
+  // k-mers, 128 MB: a loop of single queries then costs one download instead of an allocation, a launch
+  // and two copies per k-mer); a larger set without a host copy answers on the device.
+  bool Contains(const Kmer<K>& kmer) const {
+    if (!host_valid_ && Size() > (std::int64_t(1) << 24)) return Contains(std::vector<Kmer<K>>{kmer})[0];
+    const std::vector<std::uint64_t>& bits = HostBits();
+    return std::binary_search(bits.begin(), bits.end(), kmer.Bits());
+  }
 
   // Batched membership: one launch for all queries, nothing of the set leaves the device.
   std::vector<bool> Contains(const std::vector<Kmer<K>>& kmers) const {

@@ -59,6 +59,20 @@ constexpr uint32_t kRulerEvery = 1u << kRulerShift;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kMulti = 0xFFFFFFFEu;
 
+// Build with -DKSH_TRACE (make BUILD=build_trace OUT=libkmersets_hip_trace.so EXTRA=-DKSH_TRACE) to record
+// s_memtime at the phases of the two probe kernels' workgroups (tools/probe_trace.py); compiled out otherwise.
+#ifdef KSH_TRACE
+__device__ unsigned long long* g_probe_trace = nullptr;  // [which kernel][workgroup][16]
+__device__ long long g_probe_trace_rows = 0;
+#define KSH_PMARK(which, m)                                                                              \
+  do {                                                                                                   \
+    if (g_probe_trace && threadIdx.x == 0 && int64_t(blockIdx.x) < g_probe_trace_rows)                    \
+      g_probe_trace[((which) * g_probe_trace_rows + blockIdx.x) * 16 + (m)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define KSH_PMARK(which, m) do { } while (0)
+#endif
+
 // ---------------------------------------------------------------------------------- E1
 // Fine index of a set: one workgroup per bucket walks its sorted keys once and records
 // where the top fine_bits key bits change.
@@ -604,6 +618,7 @@ __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 512 ? 8 : (kRcThreads >=
   // the bits of a bucket key that a pass-0 target of this group starts with (the group bits below the bucket's)
   const uint64_t gkey_top = extra > 0 ? (uint64_t(grp) & ((uint64_t(1) << extra) - 1)) << (set.key_bits - extra) : 0;
   if (tid < 2 * kRcSegs) prev_bounds[tid] = pb[2 * kRcSegs * grp + tid];
+  KSH_PMARK(1, 0);
   for (int pass = 0; pass < 2; pass++) {
     const int n_seg = pass == 0 ? 1 : kRcSegs;
     // key bits that vary inside a range: all below the group's in its own range, four fewer in [c][tb][G]
@@ -698,6 +713,7 @@ __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 512 ? 8 : (kRcThreads >=
     }
     while (true) {
       __syncthreads();
+      KSH_PMARK(1, 1 + 7 * pass);  // planned (the group's record range and the bounds have arrived)
       if (bt.used == 0) break;  // an empty pass
       // who stages what: pass 0, the whole workgroup its one range; pass 1, team w range w
       const int my_seg = pass == 0 ? 0 : wave;
@@ -705,8 +721,11 @@ __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 512 ? 8 : (kRcThreads >=
       const int64_t my_lo = bt.win_lo[my_seg];
       const int my_len = bt.win_len[my_seg], my_off = bt.win_off[my_seg];
       const bool last_batch = bt.next_seg >= n_seg;
-      // the first record of this thread is requested ahead of the staging loads (it used to follow the slice
-      // index: one more exposed round trip per batch); the next one ahead of each record's look-ups
+      // the first record of this thread is requested ahead of the staging loads, the next one ahead of each
+      // record's look-ups.  (Three turns ahead measured the same look-up phase -- 18.6 k against 18.2 k cycles
+      // for a thread's six records in pass 0, tools/probe_trace.py -- and a slower kernel, 1.73 against 1.62 ms:
+      // the look-ups do not wait for their records but for the LDS, which 32 waves per CU keep busy with
+      // reads at random addresses, some 500 cycles per LDS instruction and wave.)
       RcRecord<KeyT> nxt;
       nxt.t = kNone;
       if (r0 + tid < r1) nxt = rec[r0 + tid];
@@ -726,7 +745,9 @@ __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 512 ? 8 : (kRcThreads >=
           }
         }
       }
+      KSH_PMARK(1, 2 + 7 * pass);  // this wave's staging loads are in LDS
       __syncthreads();
+      KSH_PMARK(1, 3 + 7 * pass);
       // slice index: sidx[idx_off + j] = first position of the window whose slice is >= j
       if (my_len > 0) {
         const int ioff = bt.idx_off[my_seg], sh = bt.idx_shift[my_seg];
@@ -740,6 +761,7 @@ __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 512 ? 8 : (kRcThreads >=
         }
       }
       __syncthreads();
+      KSH_PMARK(1, 4 + 7 * pass);  // slice index built
 #pragma unroll 1
       for (int64_t r = r0 + tid; r < r1; r += kRcThreads) {
         const RcRecord<KeyT> rr = nxt;
@@ -772,8 +794,11 @@ __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 512 ? 8 : (kRcThreads >=
           }
         }
       }
+      KSH_PMARK(1, 5 + 7 * pass);  // this wave's records looked up
       __syncthreads();
+      KSH_PMARK(1, 6 + 7 * pass);  // everybody's
       for (int i = my_id; i < my_len; i += my_step) out[my_lo + i] = slots[my_off + i];
+      KSH_PMARK(1, 7 + 7 * pass);  // marks stored
       if (last_batch) break;  // (the usual case: the pass was one batch)
       __syncthreads();
       if (tid == 0) plan_serial();
@@ -854,6 +879,7 @@ __device__ __forceinline__ int lds_lower_bound(const KeyT* a, int lo, int hi, Ke
 // KSH_FWD_DEBUG=1: how often the staged forward probe falls back to global probes (per k-mer and cause)
 __device__ unsigned long long g_fwd_dbg[8];
 
+
 template <typename KeyT, int kFwdCapNext = FwdCfg<KeyT>::kCapNext>
 __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_fwd_staged(DevSet<KeyT> set, const int64_t* __restrict__ bounds,
                                                               const uint32_t* __restrict__ rc0,
@@ -870,6 +896,7 @@ __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_
   const int64_t chunk = blockIdx.x;
   const int64_t t = chunk * kFwdChunk + tid;
   const int k = set.k;
+  KSH_PMARK(0, 0);
   if (tid < 2 * kFwdBounds) s_b[tid] = bounds[kFwdBounds * chunk + tid];
   KeyT my_key = 0;
   uint2 rc = make_uint2(kNone, kNone);
@@ -878,6 +905,7 @@ __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_
     rc = make_uint2(rc0[t], rc1[t]);
   }
   __syncthreads();
+  KSH_PMARK(0, 1);  // the bound record has arrived
   const uint64_t x_first = uint64_t(s_b[10]), x_last = uint64_t(s_b[kFwdBounds + 11]);
   // first bucket of: the five ranges, the chunk itself
   int64_t fb[6];
@@ -925,8 +953,10 @@ __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_
 #pragma unroll
       for (int u = 0; u < kPerPrev; u++)
         if (tid + u * kFwdChunk < len[1 + cc]) s_prev[cc][tid + u * kFwdChunk] = vp[cc][u];
+    KSH_PMARK(0, 2);  // this wave's window loads have arrived and are in LDS
   }
   __syncthreads();
+  KSH_PMARK(0, 3);    // everybody's are
   if (t >= set.n) return;
   // my bucket: the chunk's first bucket, or one of the next few
   int64_t my_b = fb[5];
@@ -982,6 +1012,7 @@ __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_
       });
     }
   }
+  KSH_PMARK(0, 4);    // Next side done
   // side 0: Prev(x, c), neighbour as is
 #pragma unroll
   for (int c = 0; c < 4; c++) {
@@ -1010,6 +1041,7 @@ __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_
     cnt[0]++;
     single[0] = uint32_t(idx) << 1;
   }
+  KSH_PMARK(0, 5);    // Prev side done
   const uint32_t r[2] = {rc.x, rc.y};
   uint32_t out[2];
 #pragma unroll
@@ -1018,8 +1050,14 @@ __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_
     out[side] = total == 0 ? kNone : (total > 1 ? kMulti : (cnt[side] == 1 ? single[side] : r[side]));
   }
   reinterpret_cast<uint2*>(nbr)[t] = make_uint2(out[0], out[1]);
+  KSH_PMARK(0, 6);    // searched and stored (the first wave)
 }
 
+// (Measured and dropped, round 3: ranges longer than their windows staged and searched in PARTS, one after
+// the other, instead of their k-mers probing in global memory -- no lane of a wavefront waits for global
+// round trips any more, a T-led chunk takes up to five staging rounds: 2.01 ms per 10^8 against 1.87, 197 us
+// against 176 on a 9 x 10^6 difference set.  The fall-back probes are not what this kernel waits for
+// either way.  profiles/r03_probe_stage_ab.txt)
 // (Measured and dropped, round 3: the same kernel software-pipelined -- persistent workgroups that take
 // chunks blockIdx.x, + gridDim.x, ..., with the windows, keys and marks of the next chunk on their way into
 // registers and the bound record of the one after it behind them while this chunk is searched, and a Next
@@ -2533,6 +2571,9 @@ __device__ __forceinline__ void emit_logged(const DevSet<KeyT>& set, const uint3
     emit(u, 0, x_u);
     if (steps == 0) return;
     const int n_passed = int((steps - 1) / uint32_t(k));
+    // (measured and dropped, round 3: the logged k-mers four at a time, level by level -- their states, then
+    // keys and coarse bucket entries, then the offsets -- instead of one by one: 941 us per 10^8 against 874;
+    // with 7 waves per SIMD in flight the reads of different walkers already overlap)
     for (int j = 0; j < n_passed; j++) {
       const uint32_t st = log.mid[int64_t(j) * log.n_walkers + w];
       emit(st, uint32_t(j + 1) * uint32_t(k), set.kmer(st >> 1));
@@ -3377,6 +3418,14 @@ int ksh_spss_encode_stats(ksh_ctx* ctx, int64_t stats[4]) {
   stats[3] = p->n_bases;
   return KSH_OK;
 }
+
+#ifdef KSH_TRACE
+int ksh_debug_set_probe_trace(void* d_buf, long long rows) {
+  unsigned long long* p = static_cast<unsigned long long*>(d_buf);
+  if (hipMemcpyToSymbol(HIP_SYMBOL(ksh::g_probe_trace), &p, sizeof(p)) != hipSuccess) return 13;
+  return hipMemcpyToSymbol(HIP_SYMBOL(ksh::g_probe_trace_rows), &rows, sizeof(rows)) == hipSuccess ? 0 : 13;
+}
+#endif
 
 int ksh_spss_encode_release(ksh_ctx* ctx) {
   if (ctx) free_plan(ctx);

@@ -76,15 +76,16 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("KSH_LIB") or LIB_PATH   # KSH_LIB: another build of the same sources (tools/probe_trace.py)
+    if not os.path.exists(path):
         raise RuntimeError(
             "%s is missing: run __graft_entry__.build() (make -C %s). "
-            "The k-mer set hot path has no CPU fallback." % (LIB_PATH, CSRC_DIR))
+            "The k-mer set hot path has no CPU fallback." % (path, CSRC_DIR))
     # torch ships its own libamdhip64; load it first so that this library binds to the
     # same HIP runtime (two runtimes in one process cannot both open the device).
     import torch  # noqa: F401
 
-    L = C.CDLL(LIB_PATH)
+    L = C.CDLL(path)
     vp, i32, i64 = C.c_void_p, C.c_int32, C.c_int64
     GP, SP = C.POINTER(Geom), C.POINTER(SetView)
     sig = {

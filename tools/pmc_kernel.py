@@ -37,9 +37,14 @@ def rows(path, names, counter):
 def main():
     args = [a for a in sys.argv[1:]]
     units_from = None
+    units_scale = 1
     if "--units-from" in args:
         i = args.index("--units-from")
         units_from = args[i + 1]
+        del args[i:i + 2]
+    if "--units-scale" in args:      # k-mers per thread of the --units-from kernel (k_decode_l2: 8 keys per thread)
+        i = args.index("--units-scale")
+        units_scale = int(args[i + 1])
         del args[i:i + 2]
     fetch_csv, write_csv, names = args[0], args[1], args[2].split(",")
     out_path = args[3] if len(args) > 3 else None
@@ -49,8 +54,8 @@ def main():
     extra = [] if units_from in names else [units_from]
     f = rows(fetch_csv, names + extra, "FETCH_SIZE")
     w = rows(write_csv, names + extra, "WRITE_SIZE")
-    units_f = sum(x[0] for x in f.get(units_from, []))
-    units_w = sum(x[0] for x in w.get(units_from, []))
+    units_f = sum(x[0] for x in f.get(units_from, [])) * units_scale
+    units_w = sum(x[0] for x in w.get(units_from, [])) * units_scale
     for nm in extra:
         f.pop(nm, None)
         w.pop(nm, None)

@@ -69,18 +69,29 @@ __device__ long long g_probe_trace_rows = 0;
     if (g_probe_trace && threadIdx.x == 0 && int64_t(blockIdx.x) < g_probe_trace_rows)                    \
       g_probe_trace[((which) * g_probe_trace_rows + blockIdx.x) * 16 + (m)] = __builtin_amdgcn_s_memtime(); \
   } while (0)
+// the same by the first lane of every wave: slot = the wave's number
+#define KSH_PMARK_WAVE(which)                                                                            \
+  do {                                                                                                   \
+    if (g_probe_trace && threadIdx.x % 64 == 0 && threadIdx.x / 64 < 16 && int64_t(blockIdx.x) < g_probe_trace_rows) \
+      g_probe_trace[((which) * g_probe_trace_rows + blockIdx.x) * 16 + threadIdx.x / 64] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
 #else
 #define KSH_PMARK(which, m) do { } while (0)
+#define KSH_PMARK_WAVE(which) do { } while (0)
 #endif
 
 // ---------------------------------------------------------------------------------- E1
 // Fine index of a set: one workgroup per bucket walks its sorted keys once and records
-// where the top fine_bits key bits change.
+// where the top fine_bits key bits change.  The bucket's row of the index (2^fine_bits entries, about
+// two thirds of an entry per key) is put together in LDS and written out in whole lines: written from
+// the key loop, a wave's stores fell a line and a half apart and the kernel ran at a third of the
+// memory rate (0.25 ms for the 0.67 GB of a 10^8-k-mer set).
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_fine_index(const int64_t* __restrict__ off,
                                                      const KeyT* __restrict__ keys, int key_bits,
                                                      int fine_bits, uint32_t* __restrict__ fine,
                                                      int64_t n_buckets) {
+  extern __shared__ uint32_t s_fine[];  // 2^fine_bits
   const int64_t b = blockIdx.x;
   const int64_t lo = off[b], hi = off[b + 1];
   const int kSlices = 1 << fine_bits;
@@ -89,13 +100,32 @@ __global__ __launch_bounds__(256) void k_fine_index(const int64_t* __restrict__ 
   if (lo == hi) {
     for (int sub = threadIdx.x; sub < kSlices; sub += 256) f[sub] = uint32_t(lo);
   } else {
-    for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
-      const int cur = int(uint64_t(keys[i]) >> sh);
-      const int prev = i > lo ? int(uint64_t(keys[i - 1]) >> sh) : -1;
-      for (int sub = prev + 1; sub <= cur; sub++) f[sub] = uint32_t(i);
+    // four rounds of loads in flight per thread
+    constexpr int kAhead = 4;
+    for (int64_t base = lo; base < hi; base += 256 * kAhead) {
+      KeyT cur_key[kAhead], prev_key[kAhead];
+#pragma unroll
+      for (int u = 0; u < kAhead; u++) {
+        const int64_t i = base + u * 256 + threadIdx.x;
+        if (i < hi) {
+          cur_key[u] = keys[i];
+          prev_key[u] = i > lo ? keys[i - 1] : KeyT(0);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < kAhead; u++) {
+        const int64_t i = base + u * 256 + threadIdx.x;
+        if (i < hi) {
+          const int cur = int(uint64_t(cur_key[u]) >> sh);
+          const int prev = i > lo ? int(uint64_t(prev_key[u]) >> sh) : -1;
+          for (int sub = prev + 1; sub <= cur; sub++) s_fine[sub] = uint32_t(i);
+        }
+      }
     }
     const int last = int(uint64_t(keys[hi - 1]) >> sh);
-    for (int sub = last + 1 + int(threadIdx.x); sub < kSlices; sub += 256) f[sub] = uint32_t(hi);
+    for (int sub = last + 1 + int(threadIdx.x); sub < kSlices; sub += 256) s_fine[sub] = uint32_t(hi);
+    __syncthreads();
+    for (int sub = threadIdx.x; sub < kSlices; sub += 256) f[sub] = s_fine[sub];
   }
   if (b == n_buckets - 1 && threadIdx.x == 0) fine[n_buckets << fine_bits] = uint32_t(hi);
 }
@@ -617,6 +647,7 @@ __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 512 ? 8 : (kRcThreads >=
   const int64_t p0_lo = pb0 ? pb0[2 * grp] : set.off[grp], p0_hi = pb0 ? pb0[2 * grp + 1] : set.off[grp + 1];
   // the bits of a bucket key that a pass-0 target of this group starts with (the group bits below the bucket's)
   const uint64_t gkey_top = extra > 0 ? (uint64_t(grp) & ((uint64_t(1) << extra) - 1)) << (set.key_bits - extra) : 0;
+  KSH_PMARK_WAVE(2);  // when each wave of the workgroup started
   if (tid < 2 * kRcSegs) prev_bounds[tid] = pb[2 * kRcSegs * grp + tid];
   KSH_PMARK(1, 0);
   for (int pass = 0; pass < 2; pass++) {
@@ -712,6 +743,7 @@ __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 512 ? 8 : (kRcThreads >=
       if (total > cap && s2 == 0) plan_serial();
     }
     while (true) {
+      if (pass == 0) KSH_PMARK_WAVE(3);  // when each wave reached the barrier behind the planner (its last visit)
       __syncthreads();
       KSH_PMARK(1, 1 + 7 * pass);  // planned (the group's record range and the bounds have arrived)
       if (bt.used == 0) break;  // an empty pass
@@ -1254,6 +1286,18 @@ __global__ __launch_bounds__(256) void k_ruler_heads(const uint32_t* __restrict_
 // starts (by a hash bit) in the first, and in the second only those whose record no mirror image
 // has filled in -- three walks for two stretches on average instead of four.
 //   Records start unset (all ones: no record looks like that).  Equal values may be written twice.
+//   Within a phase a walk that starts after its mirror image has arrived finds its record filled in and
+//   does not start (round 3): the walkers of a phase start over the kernel's whole duration, a walk lasts
+//   a few tens of microseconds, so of two mirror images in the same phase the later one nearly always
+//   sees the earlier one's record -- one walk per stretch and a few per cent, not three for two.  The
+//   records of mirror images are stored and looked at with device scope (another XCD's L2 may hold the
+//   line from before the store); a stale look costs a walk, not a wrong record.
+__device__ __forceinline__ unsigned long long rec_look(const unsigned long long* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void rec_post(unsigned long long* p, unsigned long long v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 __device__ __forceinline__ bool first_phase(uint32_t s) {
   return (((s >> 1) * 0x9E3779B1u) >> 13 ^ s) & 1u;
 }
@@ -1300,7 +1344,8 @@ __global__ __launch_bounds__(256) void k_rank_walk(const uint32_t* __restrict__ 
     return;
   }
   const uint32_t r = uint32_t(s64);
-  if (kPhase == 1 ? !first_phase(r) : rinfo[i] != kRecUnset) return;
+  if (kPhase == 1 && !first_phase(r)) return;
+  if (rec_look(rinfo + i) != kRecUnset) return;
   const uint2 own = link_pair(link, r);
   uint32_t lk = leave_link(own, r);
   if (lk == kNone) {
@@ -1315,7 +1360,7 @@ __global__ __launch_bounds__(256) void k_rank_walk(const uint32_t* __restrict__ 
     steps++;
     if (sampled_ruler(cur) || steps >= 0x3FFFFFFFu) {
       rinfo[i] = make_rinfo(false, steps, cur);
-      rinfo[dense_index(cur ^ 1)] = make_rinfo(false, steps, r ^ 1);
+      rec_post(rinfo + dense_index(cur ^ 1), make_rinfo(false, steps, r ^ 1));
       log.arrived(i, steps, cur);
       return;
     }
@@ -1327,7 +1372,7 @@ __global__ __launch_bounds__(256) void k_rank_walk(const uint32_t* __restrict__ 
     if (lk == kNone) {
       rinfo[i] = make_rinfo(true, steps, cur);
       // the chain that starts at cur ^ 1 (an unsampled k-mer) has ruler r ^ 1 ahead of it
-      chain_info[cur >> 1] = make_chain_info(true, steps, dense_index(r ^ 1));
+      rec_post(chain_info + (cur >> 1), make_chain_info(true, steps, dense_index(r ^ 1)));
       log.arrived(i, steps, cur);
       return;
     }
@@ -1351,10 +1396,11 @@ __global__ __launch_bounds__(256) void k_rank_heads(const uint32_t* __restrict__
   } else if (own.y == kNone && own.x != kNone) {
     s0 = 2 * t + 1;
   } else {
-    if (kPhase == 1) log.arrived(e, 0, 2 * t);  // a k-mer on its own: no walk arrives at it
+    log.arrived(e, 0, 2 * t);  // a k-mer on its own: no walk arrives at it (either phase: the first may be left out)
     return;
   }
-  if (kPhase == 1 ? !first_phase(s0) : chain_info[t] != kRecUnset) return;
+  if (kPhase == 1 && !first_phase(s0)) return;
+  if (rec_look(chain_info + t) != kRecUnset) return;
   uint32_t lk = leave_link(own, s0);
   uint32_t cur = s0, off = 0;
   int since = 0, n_passed = 0;
@@ -1363,7 +1409,7 @@ __global__ __launch_bounds__(256) void k_rank_heads(const uint32_t* __restrict__
     off++;
     if (sampled_ruler(cur)) {
       chain_info[t] = make_chain_info(true, off, dense_index(cur));
-      rinfo[dense_index(cur ^ 1)] = make_rinfo(true, off, s0 ^ 1);  // its walk ends at the chain end s0 ^ 1
+      rec_post(rinfo + dense_index(cur ^ 1), make_rinfo(true, off, s0 ^ 1));  // its walk ends at the chain end s0 ^ 1
       log.arrived(e, off, cur);
       return;
     }
@@ -1374,7 +1420,7 @@ __global__ __launch_bounds__(256) void k_rank_heads(const uint32_t* __restrict__
     lk = leave_link(link_pair(link, cur), cur);
     if (lk == kNone || off >= 0x3FFFFFFFu) {
       chain_info[t] = make_chain_info(false, off, cur);
-      chain_info[cur >> 1] = make_chain_info(false, off, s0 ^ 1);  // the mirror chain, from cur ^ 1 to s0 ^ 1
+      rec_post(chain_info + (cur >> 1), make_chain_info(false, off, s0 ^ 1));  // the mirror chain, from cur ^ 1 to s0 ^ 1
       log.arrived(e, off, cur);
       return;
     }
@@ -2884,7 +2930,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   DevSet<KeyT> set{sv->d_offsets, static_cast<const KeyT*>(sv->d_keys), nb, n, g->k, key_bits(g)};
   hipStream_t st = ctx->stream;
   if (use_fine) {
-    hipLaunchKernelGGL((k_fine_index<KeyT>), dim3(unsigned(nb)), dim3(256), 0, st, sv->d_offsets,
+    hipLaunchKernelGGL((k_fine_index<KeyT>), dim3(unsigned(nb)), dim3(256), size_t(4) << fine_bits, st, sv->d_offsets,
                        static_cast<const KeyT*>(sv->d_keys), key_bits(g), fine_bits, p->fine, nb);
     set.fine = p->fine;
     set.fine_bits = fine_bits;
@@ -3111,8 +3157,21 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
         p->log_heads = lh;
         KSH_HIP(hipMemsetAsync(rinfo, 0xFF, size_t(n_dense) * 8, st));
         hipLaunchKernelGGL(k_rank_unset, dim3(nblk(n_ends)), dim3(256), 0, st, ends, n_ends, chain_info);
-        hipLaunchKernelGGL(k_rank_walk<1>, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, chain_info, lr);
-        hipLaunchKernelGGL(k_rank_heads<1>, dim3(nblk(n_ends)), dim3(256), 0, st, link, ends, n_ends, rinfo, chain_info, lh);
+        // Enough walkers to start over many rounds of the grid (the GPU holds half a million at a time): all of
+        // them in one launch, the later of two mirror images finds its record filled in (one walk per stretch
+        // and 1 / rounds; the second phase of the split, a quarter of its lanes walking, is bound by how long a
+        // wave lives, not by the reads: 1e8 k-mers, k_rank_walk 2.20 + 1.01 ms split, 1.81 + 0.99 split with the
+        // look at the start).  Fewer: mirror images would start together, so the split by hash bit
+        // stays (KSH_RANK_PHASES=2 forces it, =1 the single launch).
+        static const int64_t race_min = [] {
+          const char* e = getenv("KSH_RANK_PHASES");
+          if (e && std::string(e) == "1") return int64_t(0);  // one launch at any size (tests)
+          return e && std::string(e) == "2" ? (int64_t(1) << 60) : int64_t(3) << 19;
+        }();
+        if (n_dense < race_min)
+          hipLaunchKernelGGL(k_rank_walk<1>, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, chain_info, lr);
+        if (n_ends < race_min)
+          hipLaunchKernelGGL(k_rank_heads<1>, dim3(nblk(n_ends)), dim3(256), 0, st, link, ends, n_ends, rinfo, chain_info, lh);
         hipLaunchKernelGGL(k_rank_walk<2>, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, chain_info, lr);
         hipLaunchKernelGGL(k_rank_heads<2>, dim3(nblk(n_ends)), dim3(256), 0, st, link, ends, n_ends, rinfo, chain_info, lh);
       }

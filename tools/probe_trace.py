@@ -1,6 +1,10 @@
 """Per-phase cycle breakdown of the two probe kernels' workgroups (k_adj_fwd_staged, k_adj_rc) on one
 1e8-k-mer k=23 genome set: s_memtime marks of the first thread of every workgroup (debugging aid).
 
+A pass of k_adj_rc that takes several batches (a group denser than its window: the A... buckets and the
+densest C... ones of a canonical set, 35 % of the workgroups at 10^8) overwrites its marks batch by batch: the
+phases printed are those of its LAST batch, and "plan" holds the batches before it.
+
 Needs the trace build: make -C kmer-sets-compression_amd/csrc BUILD=build_trace OUT=libkmersets_hip_trace.so EXTRA=-DKSH_TRACE
 and KSH_LIB pointing at it.  Not part of the product path or of the test suite.
 """
@@ -25,12 +29,12 @@ def main():
     for _ in range(2):
         ctx.spss_encode(a, mode=0)
     rows = max((a.n_keys + 511) // 512, 1 << 14) + 8
-    buf = torch.zeros(2 * rows * 16, dtype=torch.int64, device=ctx.device)
+    buf = torch.zeros(4 * rows * 16, dtype=torch.int64, device=ctx.device)
     assert lib.ksh_debug_set_probe_trace(C.c_void_p(buf.data_ptr()), rows) == 0
     ctx.spss_encode(a, mode=0)
     torch.cuda.synchronize()
     assert lib.ksh_debug_set_probe_trace(C.c_void_p(0), 0) == 0
-    t = buf.cpu().view(2, rows, 16)
+    t = buf.cpu().view(4, rows, 16)
     fwd_names = ["bound record arrives (1st round trip)", "window loads arrive, LDS stores (2nd round trip)",
                  "barrier", "Next search", "Prev searches", "verdict + store"]
     rc_names = ["plan (record range + bounds arrive)", "stage: loads -> LDS", "barrier", "slice index + barrier",
@@ -50,6 +54,31 @@ def main():
             d = (cur - prev).double()
             prev = cur
             print("   %-50s mean %8.0f  p50 %8.0f  p90 %8.0f" % (rc_names[ph], d.mean(), d.median(), d.quantile(0.9)))
+    waves(t)
+
+
+def waves(t):
+    """k_adj_rc: when the waves of a workgroup started, and when they reached the planner's barrier (pass 0)."""
+    ok = (t[1][:, 7] != 0) & (t[1][:, 14] != 0) & (t[2][:, 15] != 0)
+    r, st, ar = t[1][ok], t[2][ok], t[3][ok]
+    plan = (r[:, 1] - r[:, 0]).double()
+    spread = (st.max(dim=1).values - st.min(dim=1).values).double()
+    first_to_barrier = (ar.max(dim=1).values - st.min(dim=1).values).double()
+    w0 = (ar[:, 0] - st[:, 0]).double()
+    print("k_adj_rc waves (16-wave workgroups only): start spread mean %.0f p50 %.0f p90 %.0f; planner wave start -> barrier "
+          "mean %.0f p90 %.0f; first start -> last arrival mean %.0f p90 %.0f" % (
+              spread.mean(), spread.median(), spread.quantile(0.9), w0.mean(), w0.quantile(0.9),
+              first_to_barrier.mean(), first_to_barrier.quantile(0.9)))
+    slow = plan > 20000
+    print("   workgroups with plan > 20k cycles: %d of %d; their start spread mean %.0f, planner wave mean %.0f; the others' %.0f, %.0f"
+          % (int(slow.sum()), plan.numel(), spread[slow].mean(), w0[slow].mean(), spread[~slow].mean(), w0[~slow].mean()))
+    last_wave = (ar - ar.min(dim=1, keepdim=True).values).double()
+    print("   arrival at the barrier after the first arrival, by wave number (mean over slow workgroups):",
+          [int(x) for x in last_wave[slow].mean(dim=0).tolist()])
+    start_by_wave = (st - st.min(dim=1, keepdim=True).values).double()
+    print("   start after the first start, by wave number (slow workgroups):", [int(x) for x in start_by_wave[slow].mean(dim=0).tolist()])
+    idx = torch.nonzero(ok).flatten()
+    print("   slow workgroups by index decile:", torch.histc(idx[slow].double(), bins=10, min=0, max=float(idx.max())).int().tolist())
 
 
 if __name__ == "__main__":

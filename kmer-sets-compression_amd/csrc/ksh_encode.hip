@@ -1368,6 +1368,8 @@ __global__ __launch_bounds__(256) void k_rank_walk(const uint32_t* __restrict__ 
       since = 0;
       log.passed(i, n_passed++, cur);
     }
+    // (measured and dropped: another look at the own record every eighth step, to give up a walk whose mirror
+    // image arrives while it is under way -- 2.40 against 2.41 ms)
     lk = leave_link(link_pair(link, cur), cur);
     if (lk == kNone) {
       rinfo[i] = make_rinfo(true, steps, cur);
@@ -1379,6 +1381,12 @@ __global__ __launch_bounds__(256) void k_rank_walk(const uint32_t* __restrict__ 
   }
 }
 
+// (Measured and dropped, round 3: the one-launch walk by waves that stay -- a wave owns a contiguous slice of the
+// walkers and a lane that has arrived takes the slice's next one, so that a wave's reads per round trip stay 64
+// instead of falling off towards its longest walker: 3.02 ms per 10^8 k-mers against 2.41 for a thread per
+// walker, 2.72 with a quarter of the waves; the emit after it took 0.83 against 0.71 ms, i.e. more mirror
+// images had both walked: a turn of a full wave waits for the slowest of 64 random reads, every walk takes
+// longer, and more of them overlap their mirror image.)
 template <int kPhase>
 __global__ __launch_bounds__(256) void k_rank_heads(const uint32_t* __restrict__ link,
                                                      const uint32_t* __restrict__ ends, int64_t n_ends,
@@ -3157,16 +3165,21 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
         p->log_heads = lh;
         KSH_HIP(hipMemsetAsync(rinfo, 0xFF, size_t(n_dense) * 8, st));
         hipLaunchKernelGGL(k_rank_unset, dim3(nblk(n_ends)), dim3(256), 0, st, ends, n_ends, chain_info);
-        // Enough walkers to start over many rounds of the grid (the GPU holds half a million at a time): all of
-        // them in one launch, the later of two mirror images finds its record filled in (one walk per stretch
-        // and 1 / rounds; the second phase of the split, a quarter of its lanes walking, is bound by how long a
-        // wave lives, not by the reads: 1e8 k-mers, k_rank_walk 2.20 + 1.01 ms split, 1.81 + 0.99 split with the
-        // look at the start).  Fewer: mirror images would start together, so the split by hash bit
-        // stays (KSH_RANK_PHASES=2 forces it, =1 the single launch).
+        // Enough walkers for the launch to take a while (2^18: half a grid-full): all of them in one launch,
+        // the later of two mirror images finds its record filled in -- one walk per stretch and a fifth
+        // (by the emit's time: 1.2 logs per stretch) instead of three for two.  The second phase of the split,
+        // an eighth of its lanes walking, is bound by how long a wave lives, not by the reads: 10^8 k-mers,
+        // k_rank_walk 2.20 + 1.01 ms split, 1.81 + 0.99 split with the look at the start, 2.41 in one
+        // launch.  Over the 64 x 10^8 build (ms per build, ranking walks of its timed region halved): from
+        // 3 x 2^20 walkers 922 / 356, from 2^20 922 / 342, from 2^19 917 / 329, from 2^18 906 / 329, below that the
+        // same.  Fewer walkers start together, mirror images too: the split by hash bit stays
+        // (KSH_RANK_PHASES=2 forces it, =1 the single launch).
         static const int64_t race_min = [] {
           const char* e = getenv("KSH_RANK_PHASES");
           if (e && std::string(e) == "1") return int64_t(0);  // one launch at any size (tests)
-          return e && std::string(e) == "2" ? (int64_t(1) << 60) : int64_t(3) << 19;
+          if (e && std::string(e) == "2") return int64_t(1) << 60;
+          const char* m = getenv("KSH_RANK_RACE_MIN");  // walkers from which one launch takes them all (A/B runs)
+          return m ? int64_t(atoll(m)) : int64_t(1) << 18;
         }();
         if (n_dense < race_min)
           hipLaunchKernelGGL(k_rank_walk<1>, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, chain_info, lr);

@@ -1085,6 +1085,13 @@ __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_
   KSH_PMARK(0, 6);    // searched and stored (the first wave)
 }
 
+// (Measured and dropped, round 3: SLICE INDEXES over the five windows, as k_adj_rc has them -- extended keys
+// (bucket within the range << key bits | key) cut into about one slice per key over the interval the chunk's
+// queries can take, a query reads its slice's two bounds and a key or two instead of searching 9 .. 12 steps:
+// a third of the LDS reads at random addresses, the strings the oracle's -- and 2.86 ms per 10^8 against 1.86.
+// Putting the index together costs more than the searches it saves: every position fills the slices between
+// its predecessor's and its own, a loop whose trip count is the longest gap among 64 lanes, ten times per
+// thread, and a second barrier.)
 // (Measured and dropped, round 3: ranges longer than their windows staged and searched in PARTS, one after
 // the other, instead of their k-mers probing in global memory -- no lane of a wavefront waits for global
 // round trips any more, a T-led chunk takes up to five staging rounds: 2.01 ms per 10^8 against 1.87, 197 us

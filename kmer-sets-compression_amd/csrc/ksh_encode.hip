@@ -59,6 +59,14 @@ constexpr uint32_t kRulerEvery = 1u << kRulerShift;
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint32_t kMulti = 0xFFFFFFFEu;
 
+// Hops per launch of the pointer-jumping rounds (k_ruler_jump, k_l2_jump, k_walk_jump): a record's reach
+// grows (kJumpHops + 1)-fold per launch whatever snapshots of its successors it reads, so that many fewer
+// launches end every chain; the rounds are launch-bound on all but the largest sets.
+#ifndef KSH_JUMP_HOPS
+#define KSH_JUMP_HOPS 4
+#endif
+constexpr int kJumpHops = KSH_JUMP_HOPS;
+
 // Build with -DKSH_TRACE (make BUILD=build_trace OUT=libkmersets_hip_trace.so EXTRA=-DKSH_TRACE) to record
 // s_memtime at the phases of the two probe kernels' workgroups (tools/probe_trace.py); compiled out otherwise.
 #ifdef KSH_TRACE
@@ -1462,10 +1470,11 @@ __global__ __launch_bounds__(256) void k_ruler_jump(int64_t n_dense,
   if (i >= n_dense) return;
   uint64_t mine = rinfo[i];
   if (mine & kEndFlag) return;
-  // two hops per launch (the rounds are launch-bound: a record's reach at least triples per launch, so
-  // log3 instead of log2 of the longest chain many launches); any snapshot of a record keeps the invariant
+  // kJumpHops hops per launch (the rounds are launch-bound: a record's reach grows at least (kJumpHops + 1)-fold
+  // per launch, so log5 instead of log2 of the longest chain many launches); any snapshot of a record keeps
+  // the invariant
 #pragma unroll
-  for (int hop = 0; hop < 2 && !(mine & kEndFlag); hop++) {
+  for (int hop = 0; hop < kJumpHops && !(mine & kEndFlag); hop++) {
     const uint64_t theirs = rinfo[dense_index(uint32_t(mine))];
     const uint32_t dist = uint32_t((mine >> 32) & 0x7FFFFFFFu) + uint32_t((theirs >> 32) & 0x7FFFFFFFu);
     mine = (theirs & kEndFlag) | (uint64_t(dist & 0x7FFFFFFFu) << 32) | uint32_t(theirs);
@@ -1533,7 +1542,7 @@ __global__ __launch_bounds__(256) void k_l2_jump(int64_t n_l2, unsigned long lon
   uint64_t mine = r2[j];
   if (mine & kEndFlag) return;
 #pragma unroll
-  for (int hop = 0; hop < 2 && !(mine & kEndFlag); hop++) {  // (two hops per launch, see k_ruler_jump)
+  for (int hop = 0; hop < kJumpHops && !(mine & kEndFlag); hop++) {  // (kJumpHops hops per launch, see k_ruler_jump)
     const uint64_t theirs = r2[level2_index(int64_t(uint32_t(mine)))];
     const uint32_t dist = uint32_t((mine >> 32) & 0x7FFFFFFFu) + uint32_t((theirs >> 32) & 0x7FFFFFFFu);
     mine = (theirs & kEndFlag) | (uint64_t(dist & 0x7FFFFFFFu) << 32) | uint32_t(theirs);
@@ -2285,7 +2294,7 @@ __global__ __launch_bounds__(256) void k_walk_jump(int64_t n_states, unsigned lo
   unsigned long long mine = walk[s];
   if (mine & kWalkDone) return;
 #pragma unroll
-  for (int hop = 0; hop < 2 && !(mine & kWalkDone); hop++) {  // (two hops per launch, see k_ruler_jump)
+  for (int hop = 0; hop < kJumpHops && !(mine & kWalkDone); hop++) {  // (kJumpHops hops per launch, see k_ruler_jump)
     const unsigned long long theirs =
         __hip_atomic_load(&walk[walk_next(mine)], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     mine = make_walk((theirs & kWalkDone) != 0, walk_next(theirs), walk_weight(mine) + walk_weight(theirs));
@@ -3210,10 +3219,10 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       hipLaunchKernelGGL(k_l2_walk<true>, dim3(nblk(n_jump)), dim3(256), 0, st, rinfo, n_dense, r2, l2_head, l2_stamp);
       hipLaunchKernelGGL(k_l2_walk<false>, dim3(nblk(n_dense)), dim3(256), 0, st, rinfo, n_dense, r2, l2_head, l2_stamp);
     }
-    // log3(records) + 3 launches end every chain (a loop of rulers never ends: k_rulers_done sees it); all of
+    // log5(records) + 3 launches end every chain (a loop of rulers never ends: k_rulers_done sees it); all of
     // them are enqueued at once, a round after the last one that changed anything returns at its first load
-    int max_rounds = 3;  // a record's reach at least triples per launch (two hops): log3 of the records, and spare
-    for (int64_t x = n_jump; x > 1; x /= 3) max_rounds++;
+    int max_rounds = 3;  // a record's reach grows five-fold per launch (four hops): log5 of the records, and spare
+    for (int64_t x = n_jump; x > 1; x /= (kJumpHops + 1)) max_rounds++;
     max_rounds = std::min(max_rounds, kJumpRoundsMax);
     if (!first_pass) {  // the stamping pass after a loop was found: its flags and sums start over
       KSH_HIP(hipMemsetAsync(ctl->jump_live, 0, sizeof(ctl->jump_live), st));
@@ -3349,10 +3358,10 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     unsigned long long* walk = p->best_prio;
     uint32_t* sid_at = p->best_w;
     hipLaunchKernelGGL(k_walk_init, dim3(nblk(2 * n_u)), dim3(256), 0, st, p->mate, p->u_len, 2 * n_u, walk);
-    // log3(2 n_u) + 3 launches end every walk of a loop-free cover; enqueued at once (a round after the last
+    // log5(2 n_u) + 3 launches end every walk of a loop-free cover; enqueued at once (a round after the last
     // one that changed anything returns at its first load), the last flag is looked at with the sizes below
-    walk_rounds = 3;  // (two hops per launch: log3 of the states, and spare)
-    for (int64_t x = 2 * n_u; x > 1; x /= 3) walk_rounds++;
+    walk_rounds = 3;  // (four hops per launch: log5 of the states, and spare)
+    for (int64_t x = 2 * n_u; x > 1; x /= (kJumpHops + 1)) walk_rounds++;
     walk_rounds = std::min(walk_rounds, kWalkRoundsMax);
     for (int round = 0; round < walk_rounds; round++)
       hipLaunchKernelGGL(k_walk_jump, dim3(nblk(2 * n_u)), dim3(256), 0, st, 2 * n_u, walk,

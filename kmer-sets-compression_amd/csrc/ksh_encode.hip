@@ -44,6 +44,7 @@
 #include "ksh_kmer.h"
 
 #include <algorithm>
+#include <cstddef>
 #include <cstdlib>
 #include <string>
 
@@ -1350,9 +1351,15 @@ constexpr int kLogMidRulers = 7, kLogMidHeads = 7;
 template <int kPhase>
 __global__ __launch_bounds__(256) void k_rank_walk(const uint32_t* __restrict__ link, int64_t n_states,
                                                     int64_t n_dense, unsigned long long* __restrict__ rinfo,
-                                                    unsigned long long* __restrict__ chain_info, WalkLog log) {
+                                                    unsigned long long* __restrict__ chain_info, WalkLog log,
+                                                    unsigned long long* __restrict__ unset_a,
+                                                    unsigned long long* __restrict__ unset_b) {
   const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (i >= n_dense) return;
+  if (unset_a) {  // the two-level jumping's per-ruler arrays start unset (a fill of their own is a launch each)
+    unset_a[i] = ~0ull;
+    unset_b[i] = ~0ull;
+  }
   const int64_t s64 = 2 * int64_t(kRulerEvery) * (i >> 1) + (i & 1);
   if (s64 >= n_states) {
     rinfo[i] = make_rinfo(true, 0, 0);
@@ -1910,9 +1917,16 @@ __global__ __launch_bounds__(256) void k_end_counts(const uint32_t* __restrict__
 
 __global__ __launch_bounds__(256) void k_end_fill(const uint32_t* __restrict__ link, int64_t n,
                                                    const int64_t* __restrict__ before,
-                                                   uint32_t* __restrict__ ends) {
+                                                   uint32_t* __restrict__ ends, uint8_t* __restrict__ hcls) {
   __shared__ uint64_t lds4[4];
   const int64_t t0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * kHeadItems;
+  // no k-mer is a head yet (k_choose_ends marks the heads; the array is this thread's eight k-mers wide here)
+  static_assert(kHeadItems == 8, "one 8-byte store per thread");
+  if (t0 + kHeadItems <= n) {
+    *reinterpret_cast<uint64_t*>(hcls + t0) = ~uint64_t(0);
+  } else {
+    for (int64_t t = t0; t < n; t++) hcls[t] = 0xFF;
+  }
   const uint32_t flags = end_flags8(link, t0, n);
   const uint64_t mine = uint64_t(__popc(flags));
   uint64_t total;
@@ -1981,9 +1995,10 @@ __global__ __launch_bounds__(256) void k_edges(DevSet<KeyT> set, int64_t n_verti
                                                 const uint32_t* __restrict__ u_last,
                                                 const uint32_t* __restrict__ head,
                                                 const uint32_t* __restrict__ uid,
-                                                uint32_t* __restrict__ edges) {
+                                                uint32_t* __restrict__ edges, uint32_t* __restrict__ mate) {
   const int64_t v = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (v >= n_vertices) return;
+  mate[v] = kNone;  // nobody is matched yet
   const uint32_t u = uint32_t(v >> 1), side = uint32_t(v & 1);
   const uint32_t st = side ? u_last[u] : u_first[u];
   const int k = set.k;
@@ -2114,9 +2129,14 @@ __global__ __launch_bounds__(64) void k_match_slow(const uint32_t* __restrict__ 
 // ParallelDisjointSet, a component with no node that misses an edge is a loop.  (Round 1 walked
 // every open path from its ends with one thread per path; a set with bubbles stitches 10^5..10^6
 // unitigs into one path.)
-__global__ __launch_bounds__(256) void k_dsu_init(unsigned long long* __restrict__ a, int64_t n_u) {
+// (the fills of small arrays ride on kernels that have a thread per entry anyway: every fill is a launch)
+__global__ __launch_bounds__(256) void k_dsu_init(unsigned long long* __restrict__ a, int64_t n_u,
+                                                   uint8_t* __restrict__ has_terminal) {
   const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-  if (u < n_u) a[u] = (unsigned long long)u;
+  if (u < n_u) {
+    a[u] = (unsigned long long)u;
+    has_terminal[u] = 0;
+  }
 }
 
 // One thread per vertex v = 2u + side with an edge; the edge {v, mate[v]} is united once, by its
@@ -2312,9 +2332,13 @@ __global__ __launch_bounds__(256) void k_string_starts(const uint32_t* __restric
                                                         const unsigned long long* __restrict__ walk,
                                                         int64_t n_u, bool directed,
                                                         uint8_t* __restrict__ scls,
-                                                        int64_t* __restrict__ s_nk) {
+                                                        int64_t* __restrict__ s_nk,
+                                                        int64_t* __restrict__ str_start) {
   const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (u >= n_u) return;
+  // the strings' base counts land at their ids later (k_string_ids): n_strings <= n_u entries, the rest stay zero
+  str_start[u] = 0;
+  if (u == 0) str_start[n_u] = 0;
   const bool hl = mate[2 * u] != kNone, hr = mate[2 * u + 1] != kNone;
   uint8_t cls = 0xFF;
   int64_t nk = 0;
@@ -3134,7 +3158,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   uint32_t* ends = p->pos;  // (k_choose writes pos after the last kernel that reads the list)
   hipLaunchKernelGGL(k_end_counts, dim3(unsigned(n_hblocks)), dim3(256), 0, st, link, n, end_before);
   KSH_TRY(scan_exclusive_i64(ctx, end_before, end_before, n_hblocks, end_before + n_hblocks));
-  hipLaunchKernelGGL(k_end_fill, dim3(unsigned(n_hblocks)), dim3(256), 0, st, link, n, end_before, ends);
+  hipLaunchKernelGGL(k_end_fill, dim3(unsigned(n_hblocks)), dim3(256), 0, st, link, n, end_before, ends, p->hcls);
   p->directed = directed;
   p->ends = ends;
   KSH_HIP(hipMemcpyAsync(ctx->h_pinned, end_before + n_hblocks, 8, hipMemcpyDeviceToHost, st));
@@ -3198,10 +3222,15 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
           return m ? int64_t(atoll(m)) : int64_t(1) << 18;
         }();
         if (n_dense < race_min)
-          hipLaunchKernelGGL(k_rank_walk<1>, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, chain_info, lr);
+          hipLaunchKernelGGL(k_rank_walk<1>, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, chain_info, lr,
+                             static_cast<unsigned long long*>(nullptr), static_cast<unsigned long long*>(nullptr));
         if (n_ends < race_min)
           hipLaunchKernelGGL(k_rank_heads<1>, dim3(nblk(n_ends)), dim3(256), 0, st, link, ends, n_ends, rinfo, chain_info, lh);
-        hipLaunchKernelGGL(k_rank_walk<2>, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, chain_info, lr);
+        // (hlen / hlast are k_choose_ends' to fill afterwards: until then they hold the two-level jumping's arrays)
+        const bool l2_after = n_dense >= l2_threshold();
+        hipLaunchKernelGGL(k_rank_walk<2>, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, chain_info, lr,
+                           l2_after ? reinterpret_cast<unsigned long long*>(p->hlen) : nullptr,
+                           l2_after ? reinterpret_cast<unsigned long long*>(p->hlast) : nullptr);
         hipLaunchKernelGGL(k_rank_heads<2>, dim3(nblk(n_ends)), dim3(256), 0, st, link, ends, n_ends, rinfo, chain_info, lh);
       }
     }
@@ -3213,9 +3242,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     unsigned long long* r2 = reinterpret_cast<unsigned long long*>(p->uid);        // n_jump * 8 <= 4n
     unsigned long long* l2_head = reinterpret_cast<unsigned long long*>(p->hlen);  // n_dense * 8 <= 4n
     unsigned long long* l2_stamp = reinterpret_cast<unsigned long long*>(p->hlast);
-    if (two_levels) {
-      KSH_HIP(hipMemsetAsync(l2_head, 0xFF, size_t(n_dense) * 8, st));
-      KSH_HIP(hipMemsetAsync(l2_stamp, 0xFF, size_t(n_dense) * 8, st));
+    if (two_levels) {  // (l2_head / l2_stamp were set to unset by k_rank_walk<2>)
       hipLaunchKernelGGL(k_l2_walk<true>, dim3(nblk(n_jump)), dim3(256), 0, st, rinfo, n_dense, r2, l2_head, l2_stamp);
       hipLaunchKernelGGL(k_l2_walk<false>, dim3(nblk(n_dense)), dim3(256), 0, st, rinfo, n_dense, r2, l2_head, l2_stamp);
     }
@@ -3246,7 +3273,6 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       hipLaunchKernelGGL(k_loops, dim3(nblk(n)), dim3(256), 0, st, link, n, p->head, p->pos, p->ori,
                          p->hcls, p->hlen, p->hlast);
     } else {
-      KSH_HIP(hipMemsetAsync(p->hcls, 0xFF, size_t(n), st));
       hipLaunchKernelGGL(k_choose_ends, dim3(nblk(n_ends)), dim3(256), 0, st, link, ends, n_ends, rinfo, chain_info,
                          directed, p->head, p->ori, p->hcls, p->hlen, p->hlast,
                          reinterpret_cast<unsigned long long*>(d_tot + 2), loop_flag);
@@ -3316,8 +3342,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
                        p->u_sid, p->u_koff, p->u_flip, p->lens, p->str_start);
   } else {
     hipLaunchKernelGGL((k_edges<KeyT>), dim3(nblk(2 * n_u)), dim3(256), 0, st, set, 2 * n_u, directed,
-                       p->u_first, p->u_last, p->head, p->uid, p->edges);
-    KSH_HIP(hipMemsetAsync(p->mate, 0xFF, size_t(2 * n_u) * 4, st));
+                       p->u_first, p->u_last, p->head, p->uid, p->edges, p->mate);
     p->rounds = 0;
     const bool slow = mode == 2;
     if (slow) {
@@ -3345,9 +3370,8 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       // components of the chosen edges (parallel union-find), the ones without a terminal are loops
       DevDsu dsu{reinterpret_cast<unsigned long long*>(p->sc01)};  // sc01 is only filled by k_string_counts
       uint8_t* has_terminal = p->scls;                             // scls only by k_string_starts
-      hipLaunchKernelGGL(k_dsu_init, dim3(nblk(n_u)), dim3(256), 0, st, dsu.a, n_u);
+      hipLaunchKernelGGL(k_dsu_init, dim3(nblk(n_u)), dim3(256), 0, st, dsu.a, n_u, has_terminal);
       hipLaunchKernelGGL(k_dsu_unite_mates, dim3(nblk(2 * n_u)), dim3(256), 0, st, dsu, p->mate, 2 * n_u);
-      KSH_HIP(hipMemsetAsync(has_terminal, 0, size_t(n_u), st));
       hipLaunchKernelGGL(k_dsu_mark_terminals, dim3(nblk(n_u)), dim3(256), 0, st, dsu, p->mate, n_u, has_terminal);
       hipLaunchKernelGGL(k_dsu_open_paths, dim3(nblk(n_u)), dim3(256), 0, st, dsu, has_terminal, n_u, p->visited);
       hipLaunchKernelGGL(k_loop_cut, dim3(unsigned((n_u + 63) / 64)), dim3(64), 0, st, p->mate, n_u,
@@ -3367,15 +3391,13 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       hipLaunchKernelGGL(k_walk_jump, dim3(nblk(2 * n_u)), dim3(256), 0, st, 2 * n_u, walk,
                          round ? &ctl->walk_live[round - 1] : nullptr, &ctl->walk_live[round]);
     hipLaunchKernelGGL(k_string_starts, dim3(nblk(n_u)), dim3(256), 0, st, p->mate, p->u_len, walk, n_u,
-                       directed, p->scls, p->s_nk);
+                       directed, p->scls, p->s_nk, p->str_start);
     hipLaunchKernelGGL(k_string_counts, dim3(nblk(n_u)), dim3(256), 0, st, p->scls, n_u, slow, p->sc01,
                        p->sc2);
     arena_reset(ctx);
     int64_t* d_t2 = ctl->t2;
     KSH_TRY(scan_exclusive_i64(ctx, p->sc01, p->sc01, n_u, d_t2));
     KSH_TRY(scan_exclusive_i64(ctx, p->sc2, p->sc2, n_u, d_t2 + 1));
-    // the strings' base counts land at their ids: n_strings <= n_u entries, the rest stay zero
-    KSH_HIP(hipMemsetAsync(p->str_start, 0, size_t(n_u + 1) * 8, st));
     hipLaunchKernelGGL(k_string_ids, dim3(nblk(n_u)), dim3(256), 0, st, n_u, p->scls, p->sc01, p->sc2, p->s_nk, d_t2,
                        slow, g->k, sid_at, p->lens, p->str_start);
     hipLaunchKernelGGL(k_string_assign, dim3(nblk(n_u)), dim3(256), 0, st, p->u_len, walk, n_u, p->scls, sid_at,
@@ -3388,11 +3410,14 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
                      p->u_flip, p->str_start, p->lens, p->u_head, n_u, reinterpret_cast<UnitigPlace*>(p->c01));
   KSH_HIP(hipGetLastError());
   // one look at everything the unitig level left behind: strings by class, bases, the last walk round's flag
-  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, ctl->t2, 3 * 8, hipMemcpyDeviceToHost, st));
-  KSH_HIP(hipMemcpyAsync(ctx->h_pinned + 3, &ctl->walk_live[walk_rounds > 0 ? walk_rounds - 1 : 0], sizeof(int),
-                         hipMemcpyDeviceToHost, st));
+  // (one copy: the block from t2 to its end, 436 bytes of the 512 pinned ones)
+  constexpr size_t kTail = sizeof(EncCtl) - offsetof(EncCtl, t2);
+  static_assert(kTail <= 64 * sizeof(int64_t) && offsetof(EncCtl, n_bases) == offsetof(EncCtl, t2) + 16, "pinned read-back");
+  KSH_HIP(hipMemcpyAsync(ctx->h_pinned, ctl->t2, kTail, hipMemcpyDeviceToHost, st));
   KSH_HIP(hipStreamSynchronize(st));
-  if (walk_rounds > 0 && *reinterpret_cast<int*>(ctx->h_pinned + 3))
+  const int* walk_live_host = reinterpret_cast<const int*>(reinterpret_cast<const char*>(ctx->h_pinned) +
+                                                           (offsetof(EncCtl, walk_live) - offsetof(EncCtl, t2)));
+  if (walk_rounds > 0 && walk_live_host[walk_rounds - 1])
     return fail(KSH_INTERNAL, "the path cover still holds a loop");
   if (mode != 1) ns = (ctx->h_pinned[0] & 0xFFFFFFFF) + (ctx->h_pinned[0] >> 32) + ctx->h_pinned[1];
   p->n_strings = ns;

@@ -466,7 +466,10 @@ static int make_sample(ksh_kss* k, const KssSet& full, const uint8_t* d_flag, co
 }
 
 // A set goes to `peer`: its offsets, then its keys.  A rank that does not have the set (it failed to build
-// it) sends an empty one in its place.
+// it) sends an empty one in its place.  (Two operations, not one ncclGroupStart / End group: the receiver
+// learns the number of keys from the offsets and cannot post the second receive before the first has
+// arrived; a step of this protocol moves data one way between two ranks -- a rank either sends or
+// receives in it -- so ungrouped operations cannot wait for each other crosswise.)
 static int send_set_on(ksh_kss* k, const KssSet& s, int peer, bool side) {
   const int64_t nb = n_buckets(&k->g);
   const int64_t* off = s.off ? s.off : k->zero_off;

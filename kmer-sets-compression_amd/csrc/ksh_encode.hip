@@ -1094,6 +1094,14 @@ __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_
   KSH_PMARK(0, 6);    // searched and stored (the first wave)
 }
 
+// (Measured and dropped, round 3: a RUN of consecutive k-mers per thread -- their queries ascend in every window,
+// so only a thread's first k-mer searches and the following ones step on from where the one before ended: a
+// third of the LDS reads per k-mer with runs of four, half with runs of two.  The windows' LDS per k-mer stays
+// what it is, so the threads per CU fall with the run: runs of four (128 threads per chunk, 14 waves per CU)
+// 3.53 ms per 10^8 against 1.86, runs of two (28 waves) 2.33.  And the other way round, THREE PIVOTS per step
+// read together -- half the dependent steps of a binary search for 1.5 x the reads: 2.04 ms.  One k-mer per
+// thread, binary searches, four workgroups per CU is where this kernel's minimum is: neither the count of its
+// LDS reads nor the length of their dependency chains alone is what it waits for.)
 // (Measured and dropped, round 3: SLICE INDEXES over the five windows, as k_adj_rc has them -- extended keys
 // (bucket within the range << key bits | key) cut into about one slice per key over the interval the chunk's
 // queries can take, a query reads its slice's two bounds and a key or two instead of searching 9 .. 12 steps:

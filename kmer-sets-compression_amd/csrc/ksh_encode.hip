@@ -1094,6 +1094,10 @@ __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_
   KSH_PMARK(0, 6);    // searched and stored (the first wave)
 }
 
+// (Measured and dropped, round 3: workgroups that STAY and take chunks in turn with only the next chunk's bound
+// record on its way -- the light form of the software pipeline below, to take the first of a chunk's two
+// round trips off its path: the loop's state does not fit the 64 vector registers that four workgroups per
+// CU allow (168 bytes of scratch per lane), 5.1 ms per 10^8 against 1.86.)
 // (Measured and dropped, round 3: a RUN of consecutive k-mers per thread -- their queries ascend in every window,
 // so only a thread's first k-mer searches and the following ones step on from where the one before ended: a
 // third of the LDS reads per k-mer with runs of four, half with runs of two.  The windows' LDS per k-mer stays

@@ -3097,11 +3097,13 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       // LDS window: a group's range with some to spare (larger ranges are staged in batches).  Half-bucket
       // groups: 15 % to spare, so that four workgroups (window + 1 KB of static LDS each) share a CU's 160 KB.
       const int64_t per_group = n / ng;
+      // (a multiple of 8 keys: the 4-byte marks behind the keys are compared-and-swapped in LDS and have to sit on
+      // 4-byte boundaries whatever the key width -- an odd window of 2-byte keys faulted the kernel, round 3)
       const int cap = int(std::min<int64_t>((kRcWindowBytes - 4 * kRcSegs) / int64_t(sizeof(KeyT) + 6),
-                                            std::max<int64_t>(1024, extra ? per_group * 23 / 20 + 256 : per_group * 5 / 4 + 256)));
+                                            std::max<int64_t>(1024, extra ? per_group * 23 / 20 + 256 : per_group * 5 / 4 + 256))) & ~7;
       const size_t rc_lds = size_t(cap) * (sizeof(KeyT) + 4) + size_t(cap + 2 * kRcSegs) * 2;
       // k_adj_rc keeps window positions, lengths and slice-index offsets in 16 bits (sidx, RcBatch::packed)
-      KSH_BOUND(cap >= 1 && cap + 2 * kRcSegs < 65536);
+      KSH_BOUND(cap >= 8 && cap % 8 == 0 && cap + 2 * kRcSegs < 65536);
       KSH_BOUND(rc_lds + 2048 <= size_t(kRcWindowBytes) + 2048 && rc_lds <= size_t(kRcWindowBytes));
       int64_t* pb = static_cast<int64_t*>(arena_alloc(ctx, size_t(ng) * 2 * kRcSegs * 8));
       int64_t* pb0 = extra ? static_cast<int64_t*>(arena_alloc(ctx, size_t(ng) * 2 * 8)) : nullptr;

@@ -376,6 +376,31 @@ def test_encode_branching_sets(ctx):
             assert st["unitigs"] > 700 and st["strings"] < st["unitigs"]
 
 
+def test_u16_keys_medium_and_large_sets(ctx):
+    """(15, 14, uint16_t) beyond the sizes of the small parity cases: the 256-thread and 512-thread variants of
+    k_adj_rc with 2-byte keys (a window of an odd number of 2-byte keys put the 4-byte marks behind it on a
+    2-byte boundary and faulted the kernel's compare-and-swap: `bench_loop.py --k 15 --sets 8 --size 3e7`, round
+    3).  One set against the oracle string for string; larger ones, odd window sizes among them, through
+    encode -> decode == the set."""
+    from kmersets import synth_torch
+
+    k, n, kb = 15, 14, 2
+    g = capi.geom(k, n)
+    kmers = synth.phylogeny_sets(k, 1, 4_400_001, seed=11)[0]
+    d = capi.DeviceSet.from_kmers(g, kmers, ctx.device)
+    assert ctx.spss_encode(d, mode=0).to_strings() == ol.Set.from_kmers(k, n, kb, kmers).spss()
+    odd = 0
+    for i, size in enumerate((10_000_001, 13_333_337, 17_000_003, 23_456_789, 30_000_001)):
+        ks = synth_torch.phylogeny_sets(k, 1, size, 20 + i, ctx.device)[0]
+        d = synth_torch.device_set(g, ks)
+        window = (d.n_keys // (1 << n)) * 5 // 4 + 256  # what the host asks for before it rounds to 8 keys
+        odd += window % 2
+        back = ctx.spss_decode(ctx.spss_encode(d, mode=0))
+        assert back.n_keys == d.n_keys and ctx.set_hash(back) == ctx.set_hash(d), size
+        del ks, d, back
+    assert odd >= 1  # (the sizes above are chosen so that the case that faulted is among them)
+
+
 @pytest.mark.parametrize("knob", ["KSH_RANK=stamp", "KSH_EMIT=walk", "KSH_L2_MIN=4096", "KSH_ADJACENCY=probe", "KSH_FWD=probe", "KSH_RC_SCATTER=direct", "KSH_RC_GROUPS=half", "KSH_RANK_PHASES=1"])
 def test_encode_alternative_paths(gpu, knob):
     """The encoder's other routes give the oracle's strings too: the stamping ranking walks with

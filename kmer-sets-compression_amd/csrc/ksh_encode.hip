@@ -2016,33 +2016,56 @@ __global__ __launch_bounds__(256) void k_edges(DevSet<KeyT> set, int64_t n_verti
   const int k = set.k;
   const uint64_t x = set.kmer(st >> 1);
   const uint64_t o = (st & 1) ? revcomp(x, k) : x;
-#pragma unroll
-  for (int c = 0; c < 4; c++) {
-    const uint64_t y = side ? kmer_next(o, k, c) : kmer_prev(o, k, c);
-    uint32_t out = kNone;
+  // The four candidates of an end in two families: the ones that are consecutive values -- Next(o, .) as they
+  // are, or the reverse complements of Prev(o, .), which are Next(rc(o), .) -- are found by ONE bounded search
+  // (DevSet::for_group4); the others sit in four different buckets and are probed one by one, and in a
+  // canonical set only where that form is the canonical one.  (Four probes per end before; about three now.)
+  uint32_t out[4] = {kNone, kNone, kNone, kNone};
+  const auto take = [&](int c, int64_t i, bool as_is) {
+    const uint32_t u2 = uid[head[i]];
+    if (u2 == u) return;
     if (directed) {
-      const int64_t i = set.find(y);
-      if (i >= 0) {
-        const uint32_t u2 = uid[head[i]];
-        if (u2 != u) out = 2 * u2 + (side ? 0u : 1u);
-      }
-    } else {
-      const uint64_t r = revcomp(y, k);
-      const uint64_t z = y < r ? y : r;
-      const int64_t i = set.find(z);
-      if (i >= 0) {
-        const uint32_t u2 = uid[head[i]];
-        if (u2 != u) {
-          // side of k-mer z this edge touches
-          const uint32_t f = side ? (y == z ? 0u : 1u) : (y == z ? 1u : 0u);
-          const uint32_t fs = u_first[u2];
-          const uint32_t side2 = ((fs >> 1) == uint32_t(i) && (fs & 1) == f) ? 0u : 1u;
-          out = 2 * u2 + side2;
+      out[c] = 2 * u2 + (side ? 0u : 1u);
+      return;
+    }
+    // side of the k-mer found that this edge touches
+    const uint32_t f = side ? (as_is ? 0u : 1u) : (as_is ? 1u : 0u);
+    const uint32_t fs = u_first[u2];
+    const uint32_t side2 = ((fs >> 1) == uint32_t(i) && (fs & 1) == f) ? 0u : 1u;
+    out[c] = 2 * u2 + side2;
+  };
+  if (side) {
+    set.for_group4(kmer_next(o, k, 0), [&](int64_t i) { take(int(uint64_t(set.keys[i]) & 3), i, true); });
+    if (!directed) {
+#pragma unroll
+      for (int c = 0; c < 4; c++) {
+        const uint64_t y = kmer_next(o, k, c), r = revcomp(y, k);
+        if (r < y) {
+          const int64_t i = set.find(r);
+          if (i >= 0) take(c, i, false);
         }
       }
     }
-    edges[4 * v + c] = out;
+  } else {
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const uint64_t y = kmer_prev(o, k, c);
+      if (directed || y <= revcomp(y, k)) {
+        const int64_t i = set.find(y);
+        if (i >= 0) take(c, i, true);
+      }
+    }
+    if (!directed) {
+      // rc(Prev(o, c)) = Next(rc(o), 3 - c); a member is the canonical form of its candidate only when it is the smaller
+      const uint64_t ro = revcomp(o, k);
+      set.for_group4(kmer_next(ro, k, 0), [&](int64_t i) {
+        const int c = 3 - int(uint64_t(set.keys[i]) & 3);
+        const uint64_t y = kmer_prev(o, k, c);
+        if (revcomp(y, k) < y) take(c, i, false);
+      });
+    }
   }
+  *reinterpret_cast<uint4*>(edges + 4 * v) = make_uint4(out[0], out[1], out[2], out[3]);
 }
 
 // ---------------------------------------------------------------------------------- E5

@@ -50,7 +50,9 @@
 
 namespace ksh {
 
-// Sampled rulers: both states of every kRulerEvery-th k-mer (E2).
+// Sampled rulers: both states of every kRulerEvery-th k-mer (E2).  (Every 32nd, measured again with the one-launch
+// ranking walks of round 3: every 16th, an encode of 10^8 k-mers 10.0 ms and the build 0.94 s; every 64th, 11.8 ms
+// -- the emit from the logs triples, its stretches outgrow the logged k-mers -- and 0.91 s; every 32nd 9.7 ms, 0.89 s.)
 #ifndef KSH_RULER_SHIFT
 #define KSH_RULER_SHIFT 5
 #endif

@@ -558,10 +558,6 @@ int ksh_ctx_create(int device, void* stream, ksh_ctx** out) {
   KSH_HIP(hipSetDevice(device));
   ksh_ctx* ctx = new ksh_ctx;
   ctx->device = device;
-  {
-    int cu = 0;
-    if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) ctx->n_cu = cu;
-  }
   if (stream) {
     ctx->stream = static_cast<hipStream_t>(stream);
   } else {

@@ -76,7 +76,6 @@ struct ksh_ctx {
   // kernels of this context's device that have been granted more than 64 KB of dynamic LDS
   // (hipFuncSetAttribute acts on the current device: once per context, not once per process)
   uint32_t lds_opt_in = 0;
-  int n_cu = 256;  // compute units of the device (grids of persistent waves)
 
   // text -> SPSS plan state (ksh_text.hip), FASTA -> fragments plan state (ksh_fasta.hip);
   // both use slot kSlotText, so a plan of one kind invalidates a pending plan of the other

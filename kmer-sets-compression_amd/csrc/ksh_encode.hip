@@ -1920,16 +1920,20 @@ __device__ __forceinline__ uint32_t end_flags8(const uint32_t* __restrict__ link
   return flags;
 }
 
+// (the flags of a thread's eight k-mers are kept, a byte per thread, for k_end_fill: it reads n / 8 bytes
+// instead of the link table once more)
 __global__ __launch_bounds__(256) void k_end_counts(const uint32_t* __restrict__ link, int64_t n,
-                                                     int64_t* __restrict__ counts) {
+                                                     int64_t* __restrict__ counts, uint8_t* __restrict__ flags8) {
   __shared__ uint64_t lds4[4];
   const int64_t t0 = (int64_t(blockIdx.x) * 256 + threadIdx.x) * kHeadItems;
+  const uint32_t flags = end_flags8(link, t0, n);
+  flags8[int64_t(blockIdx.x) * 256 + threadIdx.x] = uint8_t(flags);
   uint64_t total;
-  (void)block_scan_packed(uint64_t(__popc(end_flags8(link, t0, n))), lds4, &total);
+  (void)block_scan_packed(uint64_t(__popc(flags)), lds4, &total);
   if (threadIdx.x == 0) counts[blockIdx.x] = int64_t(total);
 }
 
-__global__ __launch_bounds__(256) void k_end_fill(const uint32_t* __restrict__ link, int64_t n,
+__global__ __launch_bounds__(256) void k_end_fill(const uint8_t* __restrict__ flags8, int64_t n,
                                                    const int64_t* __restrict__ before,
                                                    uint32_t* __restrict__ ends, uint8_t* __restrict__ hcls) {
   __shared__ uint64_t lds4[4];
@@ -1941,7 +1945,7 @@ __global__ __launch_bounds__(256) void k_end_fill(const uint32_t* __restrict__ l
   } else {
     for (int64_t t = t0; t < n; t++) hcls[t] = 0xFF;
   }
-  const uint32_t flags = end_flags8(link, t0, n);
+  const uint32_t flags = flags8[int64_t(blockIdx.x) * 256 + threadIdx.x];
   const uint64_t mine = uint64_t(__popc(flags));
   uint64_t total;
   int64_t at = before[blockIdx.x] + int64_t(block_scan_packed(mine, lds4, &total) - mine);
@@ -3195,9 +3199,11 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   int64_t* end_before = static_cast<int64_t*>(arena_alloc(ctx, size_t(n_hblocks + 1) * 8));
   if (!end_before) return fail(KSH_INTERNAL, "scratch arena too small");
   uint32_t* ends = p->pos;  // (k_choose writes pos after the last kernel that reads the list)
-  hipLaunchKernelGGL(k_end_counts, dim3(unsigned(n_hblocks)), dim3(256), 0, st, link, n, end_before);
+  uint8_t* end_flags = p->ori;  // (the orientations are k_choose_ends' to fill later; a byte per eight k-mers until then)
+  KSH_BOUND(size_t(n_hblocks) * 256 <= al(size_t(n)));
+  hipLaunchKernelGGL(k_end_counts, dim3(unsigned(n_hblocks)), dim3(256), 0, st, link, n, end_before, end_flags);
   KSH_TRY(scan_exclusive_i64(ctx, end_before, end_before, n_hblocks, end_before + n_hblocks));
-  hipLaunchKernelGGL(k_end_fill, dim3(unsigned(n_hblocks)), dim3(256), 0, st, link, n, end_before, ends, p->hcls);
+  hipLaunchKernelGGL(k_end_fill, dim3(unsigned(n_hblocks)), dim3(256), 0, st, end_flags, n, end_before, ends, p->hcls);
   p->directed = directed;
   p->ends = ends;
   KSH_HIP(hipMemcpyAsync(ctx->h_pinned, end_before + n_hblocks, 8, hipMemcpyDeviceToHost, st));

@@ -889,24 +889,25 @@ constexpr int kFwdBounds = 12;
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_fwd_bounds(DevSet<KeyT> set, int64_t n_chunks,
                                                      int64_t* __restrict__ bounds) {
-  const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  // a thread per search (ten per boundary): the searches are chains of dependent reads, and a thread per
+  // boundary put two hundred thousand of them on a GPU that holds half a million threads
+  const int64_t id = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t c = id / 10;
+  const int j = int(id - c * 10);
   if (c > n_chunks) return;
   const int k = set.k;
   const int64_t t = c * kFwdChunk;
   int64_t* out = bounds + kFwdBounds * c;
-  if (t < set.n) {
-    const uint64_t x = set.kmer(t);
-    out[0] = lower_bound_kmer(set, kmer_next(x, k, 0));
-#pragma unroll
-    for (int cc = 0; cc < 4; cc++) out[1 + cc] = lower_bound_kmer(set, kmer_prev(x, k, cc));
-    out[10] = int64_t(x);
-  }
-  if (t > 0) {
+  if (j < 5) {
+    if (t < set.n) {
+      const uint64_t x = set.kmer(t);
+      out[j] = lower_bound_kmer(set, j == 0 ? kmer_next(x, k, 0) : kmer_prev(x, k, j - 1));
+      if (j == 0) out[10] = int64_t(x);
+    }
+  } else if (t > 0) {
     const uint64_t y = set.kmer((t < set.n ? t : set.n) - 1);
-    out[5] = lower_bound_kmer(set, kmer_next(y, k, 3) + 1);
-#pragma unroll
-    for (int cc = 0; cc < 4; cc++) out[6 + cc] = lower_bound_kmer(set, kmer_prev(y, k, cc) + 1);
-    out[11] = int64_t(y);
+    out[j] = lower_bound_kmer(set, (j == 5 ? kmer_next(y, k, 3) : kmer_prev(y, k, j - 6)) + 1);
+    if (j == 5) out[11] = int64_t(y);
   }
 }
 
@@ -3162,7 +3163,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
         const int64_t n_chunks = (n + kFwdChunk - 1) / kFwdChunk;
         int64_t* bounds = reinterpret_cast<int64_t*>(p->info);  // kFwdBounds * 8 bytes per 512 k-mers
         KSH_BOUND(size_t(n_chunks + 1) * kFwdBounds * 8 <= al(size_t(2 * n) * 8));
-        hipLaunchKernelGGL((k_fwd_bounds<KeyT>), dim3(nblk(n_chunks + 1)), dim3(256), 0, st, set, n_chunks, bounds);
+        hipLaunchKernelGGL((k_fwd_bounds<KeyT>), dim3(nblk((n_chunks + 1) * 10)), dim3(256), 0, st, set, n_chunks, bounds);
         // (measured and dropped, round 3: a Next window for twice the range, 6144 keys, still four workgroups per
         // CU: 3 % of the k-mers instead of 15 % fall back to probes in global memory, and the kernel takes
         // 1.88 ms per 10^8 against 1.87 -- the fall-backs are not what it waits for.  profiles/r03_probe_stage_ab.txt)

@@ -2714,7 +2714,9 @@ __device__ __forceinline__ void emit_logged(const DevSet<KeyT>& set, const uint3
       const uint32_t st = log.mid[int64_t(j) * log.n_walkers + w];
       emit(st, uint32_t(j + 1) * uint32_t(k), set.kmer(st >> 1));
     }
-    emit(arrival, steps, set.kmer(arrival >> 1));
+    // a sampled k-mer the walk arrived at writes itself (emit_ruler_walker: every one of them does, from its own
+    // thread, whose k-mer comes with the block's keys): only the end of a chain costs a k-mer's reads here
+    if (!sampled_ruler(arrival)) emit(arrival, steps, set.kmer(arrival >> 1));
   } else {
     emit(u, 0, x_u);
     uint32_t cur = u, step = 0;
@@ -2739,12 +2741,25 @@ __device__ __forceinline__ void emit_ruler_walker(const DevSet<KeyT>& set, const
                                                   const UnitigPlace* __restrict__ place_at_head,
                                                   uint8_t* __restrict__ bytes) {
   const uint64_t hdr = log.hdr[i];
-  if (hdr == kRecUnset) return;
+  bool self_only = false;
+  if (hdr == kRecUnset) {
+    // Neither state of this sampled k-mer walked (both stretches beside it were walked from their other ends): the
+    // walks that arrived here left the k-mer to itself; the thread of its even state writes it.
+    if (kLongPass || (i & 1) || log.hdr[i ^ 1] != kRecUnset) return;
+    self_only = true;
+  }
   const int64_t t = (i >> 1) << kRulerShift;
   // both states of a sampled k-mer have reached their ends (there is no loop on this path)
   const ulonglong2 ri = reinterpret_cast<const ulonglong2*>(rinfo)[i >> 1];
   const Chosen c = choose_from_ends(uint32_t(ri.x), uint32_t((ri.x >> 32) & 0x7FFFFFFFu), uint32_t(ri.y),
                                     uint32_t((ri.y >> 32) & 0x7FFFFFFFu), directed);
+  if (self_only) {
+    const UnitigPlace pl = place_at_head[c.head_state >> 1];
+    const uint32_t flip = pl.flags & 1;
+    const uint32_t q = flip ? (c.len - 1 - c.p) : c.p;
+    if (q < pl.len) store_kmer<kRun>(bytes + pl.base + q, ((c.d ^ flip) & 1) ? revcomp(x_t, set.k) : x_t, set.k);
+    return;
+  }
   emit_logged<KeyT, kRun, kLongPass>(set, link, log, i, hdr, uint32_t(2 * t + (i & 1)), x_t, c,
                                      place_at_head[c.head_state >> 1], bytes);
 }

@@ -2859,7 +2859,9 @@ __global__ __launch_bounds__(256) void k_pack(const uint8_t* __restrict__ bytes,
 // ONE fill when the plan starts (they used to be a dozen memsets of 4..16 bytes, each a launch), and
 // read back in three copies (after the end list, after the unitig counts, at the end).
 constexpr int kJumpRoundsMax = 48;  // pointer-jumping rounds over the rulers: 2 + log2(n) <= 34
-constexpr int kMatchBatch = 8;      // matching rounds enqueued between two looks at their flags (4..6 observed)
+constexpr int kMatchBatch = 8;      // matching rounds enqueued between two looks at their flags
+constexpr int kMatchFirst = 4;      // ... in the first batch: genomes and their intersections / differences take 1..3
+                                    // rounds (a round that finds nothing ends them); graphs with tips and bubbles 4..6
 constexpr int kWalkRoundsMax = 40;  // jumping rounds over the path cover: 2 + log2(2 n_u)
 struct EncCtl {
   int64_t tot[3 + kLenSums];  // [0..1] unitig counts by class, [2 .. 2 + kLenSums) k-mers the unitigs account
@@ -3409,22 +3411,24 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     if (slow) {
       hipLaunchKernelGGL(k_match_slow, dim3(1), dim3(64), 0, st, p->edges, p->mate, n_u);
     } else {
-      // rounds in batches of kMatchBatch, one look at the flags per batch (4..6 rounds observed: one look)
+      // rounds in batches, one look at the flags per batch: four rounds first (every round past the last one that
+      // found something is two launches that return at once, some 9 us each), then eight at a time
       for (bool more = true; more;) {
         if (p->rounds) KSH_HIP(hipMemsetAsync(ctl->match_live, 0, sizeof(ctl->match_live), st));
-        for (int r = 0; r < kMatchBatch; r++) {
+        const int batch = p->rounds ? kMatchBatch : kMatchFirst;
+        for (int r = 0; r < batch; r++) {
           hipLaunchKernelGGL(k_match_best, dim3(nblk(2 * n_u)), dim3(256), 0, st, p->edges, p->mate, 2 * n_u, directed,
                              p->best_prio, p->best_w, r ? &ctl->match_live[r - 1] : nullptr, &ctl->match_live[r]);
           hipLaunchKernelGGL(k_match_commit, dim3(nblk(2 * n_u)), dim3(256), 0, st, p->best_prio, p->best_w, 2 * n_u,
                              &ctl->match_live[r], p->mate);
         }
-        KSH_HIP(hipMemcpyAsync(ctx->h_pinned, ctl->match_live, kMatchBatch * sizeof(int), hipMemcpyDeviceToHost, st));
+        KSH_HIP(hipMemcpyAsync(ctx->h_pinned, ctl->match_live, batch * sizeof(int), hipMemcpyDeviceToHost, st));
         KSH_HIP(hipStreamSynchronize(st));
         const int* live = reinterpret_cast<const int*>(ctx->h_pinned);
         int ran = 0;
-        while (ran < kMatchBatch && live[ran]) ran++;
-        more = ran == kMatchBatch;
-        p->rounds += more ? kMatchBatch : ran + 1;  // (the round that found nothing counts, as before)
+        while (ran < batch && live[ran]) ran++;
+        more = ran == batch;
+        p->rounds += more ? batch : ran + 1;  // (the round that found nothing counts, as before)
         if (p->rounds > 100000) return fail(KSH_INTERNAL, "matching did not converge");
       }
       // the path extension of fast = false never closes a loop; the greedy matching can:

@@ -570,7 +570,7 @@ int ksh_ctx_create(int device, void* stream, ksh_ctx** out) {
     }
     ctx->own_stream = true;
   }
-  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pinned), kPinnedWords * sizeof(int64_t));
+  hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&ctx->h_pinned), 64 * sizeof(int64_t));
   if (e != hipSuccess) {
     delete ctx;
     return fail(KSH_INTERNAL, "hipHostMalloc failed: %s", hipGetErrorString(e));

@@ -3319,22 +3319,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       KSH_HIP(hipMemsetAsync(d_tot, 0, (3 + kLenSums) * 8, st));
       KSH_HIP(hipMemsetAsync(ctl->long_count, 0, sizeof(ctl->long_count), st));
     }
-    // The bound is for one chain through all the records; the chains of a genome's unitigs end within three
-    // to five launches, and every launch past the last one that changed anything is one that returns at
-    // once, some 9 us each.  So a first batch only; its last flag comes back with the unitig counts below,
-    // and should it say that the batch was not enough, the rest of the rounds and the kernels after them run
-    // once more (KSH_JUMP_FIRST=n sets the batch: tests run with 1).
-    static const int jump_first = [] {
-      const char* e = getenv("KSH_JUMP_FIRST");
-      return e ? std::max(1, atoi(e)) : 0;
-    }();
-    // (not in two levels: k_choose_ends writes the arrays that hold the level-2 walkers' records, so nothing could
-    // run again after it -- and a set that large does not notice seven empty launches)
-    const int first_rounds = (stamped || two_levels) ? max_rounds : std::min(max_rounds, jump_first ? jump_first : 6);
-    int rounds_done = 0;
-   for (;;) {  // (until the jumping has ended every chain: once, or twice)
-    const int upto = rounds_done == 0 ? first_rounds : max_rounds;
-    for (int round = rounds_done; round < upto; round++) {
+    for (int round = 0; round < max_rounds; round++) {
       const int* prev = round ? &ctl->jump_live[round - 1] : nullptr;
       if (two_levels)
         hipLaunchKernelGGL(k_l2_jump, dim3(nblk(n_jump)), dim3(256), 0, st, n_jump, r2, prev, &ctl->jump_live[round]);
@@ -3342,7 +3327,6 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
         hipLaunchKernelGGL(k_ruler_jump, dim3(nblk(n_dense)), dim3(256), 0, st, n_dense, rinfo, prev,
                            &ctl->jump_live[round]);
     }
-    rounds_done = upto;
     if (two_levels)
       hipLaunchKernelGGL(k_l2_resolve, dim3(nblk(n_dense)), dim3(256), 0, st, n_dense, r2, l2_head, l2_stamp, rinfo);
     int* loop_flag = reinterpret_cast<int*>(d_tot + 2 + kLenSums);
@@ -3361,24 +3345,12 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     KSH_TRY(scan_exclusive_i64(ctx, b01, b01, n_hblocks, d_tot));
     KSH_TRY(scan_exclusive_i64(ctx, b23, b23, n_hblocks, d_tot + 1));
     KSH_HIP(hipGetLastError());
-    // one copy: the sums, the self-reverse-complement flag, and on to the jump rounds' flags
-    static_assert(offsetof(EncCtl, self_rc) == (3 + kLenSums) * 8 && offsetof(EncCtl, tot) == 0 &&
-                      offsetof(EncCtl, match_live) <= kPinnedWords * sizeof(int64_t), "one copy: tot + self_rc + jump_live");
-    KSH_HIP(hipMemcpyAsync(ctx->h_pinned, ctl, offsetof(EncCtl, match_live), hipMemcpyDeviceToHost, st));
+    static_assert(offsetof(EncCtl, self_rc) == (3 + kLenSums) * 8 && (4 + kLenSums) <= 64, "one copy: tot + self_rc");
+    KSH_HIP(hipMemcpyAsync(ctx->h_pinned, d_tot, (4 + kLenSums) * 8, hipMemcpyDeviceToHost, st));
     KSH_HIP(hipStreamSynchronize(st));
     if (*reinterpret_cast<int*>(ctx->h_pinned + 3 + kLenSums))
       return fail(KSH_INVALID_ARGUMENT, "the canonical set holds a k-mer that is its own reverse "
                                         "complement (even k): not supported");
-    const int* jump_live_host = reinterpret_cast<const int*>(reinterpret_cast<const char*>(ctx->h_pinned) +
-                                                            offsetof(EncCtl, jump_live));
-    if (rounds_done < max_rounds && jump_live_host[rounds_done - 1]) {
-      // the first batch's last round still moved records: the sums of k_choose_ends and its head marks start over
-      KSH_HIP(hipMemsetAsync(d_tot + 2, 0, (1 + kLenSums) * 8, st));
-      KSH_HIP(hipMemsetAsync(p->hcls, 0xFF, size_t(n), st));
-      continue;
-    }
-    break;
-   }
     p->stamped = stamped;
     p->rinfo = rinfo;
     p->chain_info = chain_info;

@@ -47,8 +47,6 @@ constexpr int kNumTimers = 8;
 // Scratch arena: one growing device buffer, carved by bump allocation and reset
 // at the start of every public call that needs scratch.  The pair plan keeps its
 // own buffers (they must survive until ksh_pair_write).
-constexpr int kPinnedWords = 128;  // ksh_ctx::h_pinned: the small read-backs (the encode's control block is the largest)
-
 struct ksh_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -59,7 +57,7 @@ struct ksh_ctx {
   size_t arena_used = 0;
 
   // pinned host staging for small read-backs
-  int64_t* h_pinned = nullptr;  // kPinnedWords int64
+  int64_t* h_pinned = nullptr;  // 64 int64
   int64_t* h_batch = nullptr;   // pinned, grown on demand (ksh_pair_algebra_batch totals)
   size_t h_batch_count = 0;
 

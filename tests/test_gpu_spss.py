@@ -401,15 +401,14 @@ def test_u16_keys_medium_and_large_sets(ctx):
     assert odd >= 1  # (the sizes above are chosen so that the case that faulted is among them)
 
 
-@pytest.mark.parametrize("knob", ["KSH_RANK=stamp", "KSH_EMIT=walk", "KSH_L2_MIN=4096", "KSH_ADJACENCY=probe", "KSH_FWD=probe", "KSH_RC_SCATTER=direct", "KSH_RC_GROUPS=half", "KSH_RANK_PHASES=1", "KSH_JUMP_FIRST=1"])
+@pytest.mark.parametrize("knob", ["KSH_RANK=stamp", "KSH_EMIT=walk", "KSH_L2_MIN=4096", "KSH_ADJACENCY=probe", "KSH_FWD=probe", "KSH_RC_SCATTER=direct", "KSH_RC_GROUPS=half", "KSH_RANK_PHASES=1"])
 def test_encode_alternative_paths(gpu, knob):
     """The encoder's other routes give the oracle's strings too: the stamping ranking walks with
     k_choose / k_emit per k-mer (what a set with a non-branching loop falls back to), the strings
     written by a second walk instead of from the ranking walks' logs, the two-level pointer jumping on
     sets of any size (by default it starts at 2^20 ruler records), the in-place
     neighbour probe, the in-place forward half, the one-pass record scatter, half-bucket groups, the
-    ranking walks of large sets (all walkers in one launch) on small ones, a first batch of one jump round (so that
-    the rest of the rounds and the kernels after them run a second time).  The switches are read
+    ranking walks of large sets (all walkers in one launch) on small ones.  The switches are read
     once per process, so each runs in a process of its own."""
     import os
     import subprocess

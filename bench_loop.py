@@ -29,6 +29,7 @@ def main():
     ap.add_argument("--size", type=float, default=1e7)
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--max-iterations", type=int, default=-1)
+    ap.add_argument("--lanes", type=int, default=0, help="ksh_ctx_set_lanes (0 = default, 1 = one stream)")
     ap.add_argument("--cpu-iterations", type=int, default=0,
                     help="also time the oracle on the first I iterations (0 = skip)")
     ap.add_argument("--cpu-size", type=float, default=0, help="set size for the CPU leg (default: --size)")
@@ -73,6 +74,7 @@ def main():
     k, nbits, n_sets, size = args.k, args.bucket_bits, args.sets, int(args.size)
     g = capi.geom(k, nbits)
     ctx = capi.Context(local_rank)
+    ctx.set_lanes(args.lanes)
     dev = ctx.device
     t0 = time.perf_counter()
     kmers = synth_torch.phylogeny_sets(k, n_sets, size, args.seed, dev)

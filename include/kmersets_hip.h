@@ -108,6 +108,19 @@ int ksh_ctx_enable_timing(ksh_ctx* ctx, int enable);
 int ksh_ctx_timing_reset(ksh_ctx* ctx);
 int ksh_ctx_timing_read(ksh_ctx* ctx, int kind, float* total_ms, int64_t* launches);
 int ksh_ctx_timing_units(ksh_ctx* ctx, int kind, int64_t* units);
+/* Lanes.  Calls that hold independent jobs -- the SPSS encodes of the stale nodes at a convergence check and at
+ * the end of ksh_kss_build (lib/core/kmer_set_set.h:287,345-360), the decodes of its inputs (:138-153, which the
+ * reference runs on its thread pool too) -- run them on up to n_lanes HIP streams of the context's GPU at once,
+ * each from a host thread of its own with scratch of its own (one job's LDS-bound probe kernels then overlap
+ * another's walks, which wait on HBM, and nobody's host round trips leave the GPU idle); results are the same,
+ * node ids being fixed before the jobs start.  The helper lanes live inside the context (created on first use,
+ * mapped scratch kept, freed by ksh_ctx_destroy) and are left out when their scratch does not fit the free
+ * memory.  n_lanes = 1: everything on the context's stream, as before; 0: the default (KSH_LANES, else 3).
+ * With lanes, ksh_ctx_timing_read / _units sum over the lanes (stream time: spans of different lanes overlap);
+ * ksh_ctx_timing_wall is the length of the UNION of a kind's timed spans over all lanes, i.e. the wall time
+ * during which at least one launch of the kind was running. */
+int ksh_ctx_set_lanes(ksh_ctx* ctx, int n_lanes);
+int ksh_ctx_timing_wall(ksh_ctx* ctx, int kind, float* wall_ms);
 
 /* ---- KmerSet::Size / Hash  (lib/core/kmer_set.h:65-71, :224-244) --------------------- */
 /* XOR of all k-mer bit patterns in the set. */
@@ -280,6 +293,26 @@ int ksh_spss_encode_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* se
 int ksh_spss_encode_write(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens);
 /* stats = { unitigs, matching rounds, strings, bases } of the current plan. */
 int ksh_spss_encode_stats(ksh_ctx* ctx, int64_t stats[4]);
+/* Which variants of the encode's kernels the current plan ran (they are chosen by set size and geometry;
+ * the parity tests assert the route so that a case cannot silently take another one): a mask of KSH_ROUTE_*. */
+enum {
+  KSH_ROUTE_PROBE_STAGED = 1 << 0,       /* neighbour probe staged in LDS (k_rc_*, k_adj_rc), not k_adjacency */
+  KSH_ROUTE_RC_1024 = 1 << 1,            /* k_adj_rc with 1024 / 512 / 256 / 64 threads per group */
+  KSH_ROUTE_RC_512 = 1 << 2,
+  KSH_ROUTE_RC_256 = 1 << 3,
+  KSH_ROUTE_RC_64 = 1 << 4,
+  KSH_ROUTE_RC_BATCHED = 1 << 5,         /* some group's ranges took several batches of its LDS window */
+  KSH_ROUTE_SCATTER_TWO_LEVEL = 1 << 6,  /* k_rc_scatter_l1 / _l2 instead of k_rc_scatter */
+  KSH_ROUTE_FWD_STAGED = 1 << 7,         /* k_adj_fwd_staged instead of k_adj_fwd */
+  KSH_ROUTE_RANK_ONE_LAUNCH = 1 << 8,    /* all ruler walkers in one launch (mirror images racing) */
+  KSH_ROUTE_HEADS_ONE_LAUNCH = 1 << 9,   /* the same for the chain-start walkers */
+  KSH_ROUTE_JUMP_TWO_LEVEL = 1 << 10,    /* pointer jumping over the level-2 rulers (k_l2_*) */
+  KSH_ROUTE_RANK_STAMPED = 1 << 11,      /* the stamping walks (sets with a non-branching loop, KSH_RANK=stamp) */
+  KSH_ROUTE_EMIT_LOGS = 1 << 12,         /* strings written from the ranking walks' logs */
+  KSH_ROUTE_LONG_STRETCHES = 1 << 13,    /* ... and some stretch outgrew its log (the long list) */
+  KSH_ROUTE_MATCH_MORE_ROUNDS = 1 << 14  /* the matching needed more than its first batch of rounds */
+};
+int ksh_spss_encode_routes(ksh_ctx* ctx, int64_t* routes);
 /* Frees the current plan's device memory (also done by the next plan / ctx_destroy). */
 int ksh_spss_encode_release(ksh_ctx* ctx);
 

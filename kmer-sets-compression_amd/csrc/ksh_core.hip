@@ -6,8 +6,10 @@
 #include "ksh_scan.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cstring>
 #include <iterator>
+#include <thread>
 #include <type_traits>
 
 namespace ksh {
@@ -86,7 +88,11 @@ static size_t pool_round(size_t bytes) {
   return (bytes + gran - 1) / gran * gran;
 }
 
+static void pool_trim_locked(ksh_ctx* ctx);
+static void lanes_release_scratch(ksh_ctx* ctx);
+
 int pool_alloc(ksh_ctx* ctx, size_t bytes, void** out) {
+  std::lock_guard<std::mutex> lock(ctx->pool_mu);
   if (ctx->inject_skip >= 0 && bytes >= ctx->inject_min_bytes) {
     if (ctx->inject_skip == 0) {
       *out = nullptr;
@@ -104,8 +110,12 @@ int pool_alloc(ksh_ctx* ctx, size_t bytes, void** out) {
   }
   hipError_t e = hipMalloc(out, want);
   if (e != hipSuccess) {
-    pool_trim(ctx);  // give the cached blocks back and retry once
+    pool_trim_locked(ctx);  // give the cached blocks back and retry once
     e = hipMalloc(out, want);
+    if (e != hipSuccess && !ctx->lanes.empty() && !ctx->lanes_busy) {
+      lanes_release_scratch(ctx);  // ... and the idle lanes' scratch (mapped again when they are next used)
+      e = hipMalloc(out, want);
+    }
     if (e != hipSuccess)
       return fail(KSH_INTERNAL, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
   }
@@ -115,6 +125,7 @@ int pool_alloc(ksh_ctx* ctx, size_t bytes, void** out) {
 
 void pool_free(ksh_ctx* ctx, void* p) {
   if (!p) return;
+  std::lock_guard<std::mutex> lock(ctx->pool_mu);
   auto it = ctx->pool_sizes.find(p);
   if (it == ctx->pool_sizes.end()) {
     (void)hipFree(p);
@@ -133,6 +144,11 @@ void pool_free(ksh_ctx* ctx, void* p) {
 }
 
 void pool_trim(ksh_ctx* ctx) {
+  std::lock_guard<std::mutex> lock(ctx->pool_mu);
+  pool_trim_locked(ctx);
+}
+
+static void pool_trim_locked(ksh_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   for (auto& kv : ctx->pool_free_blocks) {
     ctx->pool_sizes.erase(kv.second);
@@ -140,6 +156,97 @@ void pool_trim(ksh_ctx* ctx) {
   }
   ctx->pool_free_blocks.clear();
   ctx->pool_cached_bytes = 0;
+}
+
+// ---- lanes
+static void lanes_release_scratch(ksh_ctx* ctx) {
+  for (ksh_ctx* lane : ctx->lanes) {
+    (void)hipStreamSynchronize(lane->stream);
+    free_plan(lane);
+    pool_trim(lane);
+    for (int i = 0; i < 3; i++) {
+      if (lane->slot[i]) (void)hipFree(lane->slot[i]);
+      lane->slot[i] = nullptr;
+      lane->slot_bytes[i] = 0;
+    }
+    if (lane->arena) (void)hipFree(lane->arena);
+    lane->arena = nullptr;
+    lane->arena_bytes = lane->arena_used = 0;
+  }
+}
+
+static int lanes_default() {
+  static const int v = [] {
+    const char* e = getenv("KSH_LANES");
+    const int n = e ? atoi(e) : 3;
+    return n < 1 ? 1 : (n > 8 ? 8 : n);
+  }();
+  return v;
+}
+
+int run_on_lanes(ksh_ctx* ctx, const std::vector<size_t>& order, size_t need_bytes,
+                 const std::function<int(ksh_ctx*)>& prepare, const std::function<int(ksh_ctx*, size_t)>& job) {
+  if (order.empty()) return KSH_OK;
+  const int wanted = ctx->lane_parent ? 1 : (ctx->lanes_wanted > 0 ? ctx->lanes_wanted : lanes_default());
+  const size_t n_lanes = std::min<size_t>(size_t(wanted), order.size());
+  KSH_HIP(hipStreamSynchronize(ctx->stream));  // what the jobs read was written on this stream
+  std::vector<ksh_ctx*> use{ctx};
+  for (size_t l = 1; l < n_lanes; l++) {
+    if (ctx->lanes.size() < l) {
+      ksh_ctx* lane = nullptr;
+      if (ksh_ctx_create(ctx->device, nullptr, &lane) != KSH_OK) break;  // (no stream, no pinned page: go on with fewer)
+      lane->lane_parent = ctx;
+      ctx->lanes.push_back(lane);
+    }
+    ksh_ctx* lane = ctx->lanes[l - 1];
+    // scratch for the largest job, mapped here, on one thread, before anything runs -- and only when it fits with
+    // room to spare: a lane is an optimisation, the memory may be owed to the sets (config 5: 215 of 288 GB)
+    size_t free_b = 0, total_b = 0;
+    const size_t have = lane->slot_bytes[kSlotEncode] + lane->slot_bytes[kSlotDecode] + lane->arena_bytes;
+    if (have < need_bytes) {
+      if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) break;
+      if (free_b < (need_bytes - have) + need_bytes / 4 + (size_t(4) << 30)) break;
+    }
+    if (prepare(lane) != KSH_OK) {
+      (void)hipGetLastError();
+      break;
+    }
+    lane->timing = ctx->timing;
+    lane->timing_stride = ctx->timing_stride;
+    use.push_back(lane);
+  }
+  if (use.size() == 1) {
+    for (size_t q : order) KSH_TRY(job(ctx, q));
+    return KSH_OK;
+  }
+  std::atomic<size_t> next{0};
+  std::atomic<int> first_rc{KSH_OK};
+  std::mutex msg_mu;
+  std::string first_msg;
+  const auto work = [&](ksh_ctx* lane) {
+    (void)hipSetDevice(lane->device);
+    while (first_rc.load() == KSH_OK) {
+      const size_t at = next.fetch_add(1);
+      if (at >= order.size()) break;
+      const int rc = job(lane, order[at]);
+      if (rc != KSH_OK) {
+        std::lock_guard<std::mutex> lock(msg_mu);
+        if (first_rc.load() == KSH_OK) {
+          first_msg = g_last_error;  // (this thread's)
+          first_rc.store(rc);
+        }
+      }
+    }
+    (void)hipStreamSynchronize(lane->stream);  // what the job wrote is read on the parent's stream afterwards
+  };
+  ctx->lanes_busy = true;
+  std::vector<std::thread> threads;
+  for (size_t l = 1; l < use.size(); l++) threads.emplace_back(work, use[l]);
+  work(ctx);
+  for (std::thread& t : threads) t.join();
+  ctx->lanes_busy = false;
+  if (first_rc.load() != KSH_OK) return fail(first_rc.load(), "%s", first_msg.c_str());
+  return KSH_OK;
 }
 
 hipEvent_t timer_event(ksh_ctx* ctx, size_t* index) {
@@ -594,6 +701,8 @@ int ksh_ctx_destroy(ksh_ctx* ctx) {
   if (!ctx) return KSH_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  for (ksh_ctx* lane : ctx->lanes) ksh_ctx_destroy(lane);
+  ctx->lanes.clear();
   free_plan(ctx);
   pool_trim(ctx);
   if (ctx->arena) (void)hipFree(ctx->arena);
@@ -628,6 +737,13 @@ int ksh_ctx_enable_timing(ksh_ctx* ctx, int enable) {
   if (!ctx) return fail(KSH_INVALID_ARGUMENT, "ctx is NULL");
   ctx->timing = enable > 0;
   ctx->timing_stride = enable > 0 ? enable : 1;
+  return KSH_OK;  // (the lanes take the setting over whenever they are used)
+}
+
+int ksh_ctx_set_lanes(ksh_ctx* ctx, int n_lanes) {
+  if (!ctx) return fail(KSH_INVALID_ARGUMENT, "ctx is NULL");
+  if (n_lanes > 8) return fail(KSH_INVALID_ARGUMENT, "at most 8 lanes");
+  ctx->lanes_wanted = n_lanes < 1 ? -1 : n_lanes;
   return KSH_OK;
 }
 
@@ -640,6 +756,7 @@ int ksh_ctx_timing_reset(ksh_ctx* ctx) {
     ctx->timing_seen[i] = 0;
     ctx->timing_units[i] = 0;
   }
+  for (ksh_ctx* lane : ctx->lanes) KSH_TRY(ksh_ctx_timing_reset(lane));
   return KSH_OK;
 }
 
@@ -655,6 +772,50 @@ int ksh_ctx_timing_read(ksh_ctx* ctx, int kind, float* total_ms, int64_t* launch
   }
   *total_ms = float(sum);
   *launches = int64_t(ctx->ev_spans[kind].size());
+  for (ksh_ctx* lane : ctx->lanes) {  // (stream time: spans of different lanes overlap; ksh_ctx_timing_wall for the union)
+    float ms = 0;
+    int64_t n = 0;
+    KSH_TRY(ksh_ctx_timing_read(lane, kind, &ms, &n));
+    *total_ms += ms;
+    *launches += n;
+  }
+  return KSH_OK;
+}
+
+int ksh_ctx_timing_wall(ksh_ctx* ctx, int kind, float* wall_ms) {
+  if (!ctx || !wall_ms) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  if (kind < 0 || kind >= kNumTimers) return fail(KSH_INVALID_ARGUMENT, "no timer kind %d", kind);
+  std::vector<ksh_ctx*> all{ctx};
+  all.insert(all.end(), ctx->lanes.begin(), ctx->lanes.end());
+  hipEvent_t ref = nullptr;
+  std::vector<std::pair<float, float>> iv;
+  for (ksh_ctx* c : all) {
+    KSH_HIP(hipStreamSynchronize(c->stream));
+    for (const auto& span : c->ev_spans[kind]) {
+      if (!ref) ref = c->ev_pool[span.first];
+      float t0 = 0, t1 = 0;
+      // (all on one device: the events share a clock; a span that began before the reference has t0 < 0)
+      KSH_HIP(hipEventElapsedTime(&t0, ref, c->ev_pool[span.first]));
+      KSH_HIP(hipEventElapsedTime(&t1, ref, c->ev_pool[span.second]));
+      iv.emplace_back(t0, t1);
+    }
+  }
+  std::sort(iv.begin(), iv.end());
+  double sum = 0;
+  float lo = 0, hi = 0;
+  bool open = false;
+  for (const auto& x : iv) {
+    if (open && x.first <= hi) {
+      hi = std::max(hi, x.second);
+    } else {
+      if (open) sum += hi - lo;
+      lo = x.first;
+      hi = x.second;
+      open = true;
+    }
+  }
+  if (open) sum += hi - lo;
+  *wall_ms = float(sum);
   return KSH_OK;
 }
 
@@ -708,6 +869,7 @@ int ksh_ctx_timing_units(ksh_ctx* ctx, int kind, int64_t* units) {
   if (!ctx || !units) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
   if (kind < 0 || kind >= kNumTimers) return fail(KSH_INVALID_ARGUMENT, "no timer kind %d", kind);
   *units = ctx->timing_units[kind];
+  for (ksh_ctx* lane : ctx->lanes) *units += lane->timing_units[kind];
   return KSH_OK;
 }
 

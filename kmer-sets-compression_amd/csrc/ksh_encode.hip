@@ -638,7 +638,7 @@ template <typename KeyT, int kRcThreads>
 __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 512 ? 8 : (kRcThreads >= 128 ? kRcThreads / 128 : 1))) void k_adj_rc(
     DevSet<KeyT> set, int gbits, const int64_t* __restrict__ goff, const RcRecord<KeyT>* __restrict__ rec,
     const int64_t* __restrict__ pb, const int64_t* __restrict__ pb0, int cap, uint32_t* __restrict__ rc0,
-    uint32_t* __restrict__ rc1) {
+    uint32_t* __restrict__ rc1, int* __restrict__ batched) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   KeyT* skeys = reinterpret_cast<KeyT*>(lds_raw);
   uint32_t* slots = reinterpret_cast<uint32_t*>(lds_raw + size_t(cap) * sizeof(KeyT));
@@ -746,6 +746,7 @@ __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 512 ? 8 : (kRcThreads >=
       } else if (s2 == 0) {
         bt.next_seg = 0;
         bt.next_pos = lo;
+        *batched = 1;  // (ksh_spss_encode_routes: some group's ranges did not fit the window together)
       }
       // (the serial planner reads seg_lo / seg_hi written by the other lanes of this wave: same wave, in order)
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -2872,6 +2873,8 @@ struct EncCtl {
   int64_t n_bases;            // total of the string lengths in bases
   unsigned long long sc_used; // k_loop_cut's scratch cursor
   unsigned int long_count[2]; // WalkLog::long_count
+  int rc_batched;             // k_adj_rc: a group's ranges took more than one batch of its LDS window
+  int pad2;
   int jump_live[kJumpRoundsMax + 1];
   int match_live[kMatchBatch + 1];
   int walk_live[kWalkRoundsMax + 1];
@@ -2902,6 +2905,7 @@ struct EncPlan {
   int64_t *s_nk = nullptr, *sc01 = nullptr, *sc2 = nullptr, *str_start = nullptr;
   EncCtl* ctl = nullptr;
   int rounds = 0;
+  int64_t routes = 0;  // KSH_ROUTE_* bits: which variants this plan ran (ksh_spss_encode_routes)
   // ranking without stamps (k_choose_ends): the ruler and chain-start records live on in `info`
   // until the strings are written (k_emit_rulers / k_emit_heads)
   bool stamped = true;
@@ -2983,6 +2987,37 @@ void free_plan(ksh_ctx* ctx) {
   ctx->enc_state = nullptr;
 }
 
+// slices of about 1.5 keys (measured on 10^7- and 10^8-key sets: 9 and 12 bits are the
+// fastest there; fewer bits mean longer slices, more bits a bigger index to build)
+// (at least four values per slice: the four consecutive candidates of a group probe share one)
+static int enc_fine_bits(const ksh_geom* g, int64_t n) {
+  const int64_t nb = n_buckets(g);
+  int fine_bits = 0;
+  while (fine_bits < 13 && fine_bits + 2 < key_bits(g) && (int64_t(3) << fine_bits) < 2 * (n / nb + 1)) fine_bits++;
+  return fine_bits;
+}
+static size_t enc_slot_bytes(const ksh_geom* g, int64_t n) {
+  const int64_t nb = n_buckets(g);
+  const int fine_bits = enc_fine_bits(g, n);
+  const size_t fine_entries = fine_bits >= 2 ? (size_t(nb) << fine_bits) + 1 : 0;
+  return 2 * al(size_t(2 * n) * 4) + al(size_t(2 * n) * 8) + 5 * al(size_t(n) * 4) + 2 * al(size_t(n)) +
+         2 * al(size_t(n) * 8) + al(fine_entries * 4) + al(size_t((n >> kCoarseShift) + 2) * 4) +
+         al(sizeof(EncCtl) + size_t(2 * nb) * 4) + 4096;
+}
+static size_t enc_arena_bytes(const ksh_geom* g, int64_t n) {
+  const int64_t nb = n_buckets(g);
+  return size_t(n / 256 + 4096) * 8 * 2 + (1u << 16) + size_t(n / kHeadSpan + 64) * 8 +
+         (nb <= (1 << 14) ? size_t(kRcRowsMax) * 2 * nb * 4 + size_t(2 * nb + 1) * 16 + size_t(2 * nb) * 280 + 8192 : 0);
+}
+size_t encode_scratch_bytes(const ksh_geom* g, int64_t n) {
+  const size_t slot = enc_slot_bytes(g, n), arena = enc_arena_bytes(g, n);
+  return slot + (slot >> 3) + arena + (arena >> 2) + (size_t(2) << 20);  // (with slot_reserve's and arena_reserve's spare)
+}
+int encode_reserve(ksh_ctx* ctx, const ksh_geom* g, int64_t n) {
+  KSH_TRY(slot_reserve(ctx, kSlotEncode, enc_slot_bytes(g, n)));
+  return arena_reserve(ctx, enc_arena_bytes(g, n));
+}
+
 template <typename KeyT>
 int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool directed, int mode,
                   int64_t* n_strings, int64_t* n_bases) {
@@ -3001,19 +3036,10 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
   }
   if (n >= int64_t(0x7FFFFFF0)) return fail(KSH_INVALID_ARGUMENT, "set too large for 32-bit indices");
   const int64_t nb = n_buckets(g);
-  // slices of about 1.5 keys (measured on 10^7- and 10^8-key sets: 9 and 12 bits are the
-  // fastest there; fewer bits mean longer slices, more bits a bigger index to build)
-  int fine_bits = 0;
-  // (at least four values per slice: the four consecutive candidates of a group probe share one)
-  while (fine_bits < 13 && fine_bits + 2 < key_bits(g) && (int64_t(3) << fine_bits) < 2 * (n / nb + 1)) fine_bits++;
+  const int fine_bits = enc_fine_bits(g, n);
   const bool use_fine = fine_bits >= 2;
   const size_t fine_entries = use_fine ? (size_t(nb) << fine_bits) + 1 : 0;
-  const size_t bytes = 2 * al(size_t(2 * n) * 4) + al(size_t(2 * n) * 8) + 5 * al(size_t(n) * 4) +
-                       2 * al(size_t(n)) + 2 * al(size_t(n) * 8) + al(fine_entries * 4) +
-                       al(size_t((n >> kCoarseShift) + 2) * 4) + al(sizeof(EncCtl) + size_t(2 * nb) * 4) + 4096;
-  KSH_TRY(slot_reserve(ctx, kSlotEncode, bytes));
-  KSH_TRY(arena_reserve(ctx, size_t(n / 256 + 4096) * 8 * 2 + (1u << 16) + size_t(n / kHeadSpan + 64) * 8 +
-                                 (nb <= (1 << 14) ? size_t(kRcRowsMax) * 2 * nb * 4 + size_t(2 * nb + 1) * 16 + size_t(2 * nb) * 280 + 8192 : 0)));
+  KSH_TRY(encode_reserve(ctx, g, n));
   arena_reset(ctx);
   char* at = ctx->slot[kSlotEncode];
   p->nbr = carve<uint32_t>(at, size_t(2 * n));
@@ -3118,6 +3144,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       hipLaunchKernelGGL(k_rc_columns, dim3(unsigned((ng + 63) / 64)), dim3(64 * kColTeams), 0, st, hist, rows, int(ng),
                          totals);
       KSH_TRY(scan_exclusive_i64(ctx, totals, goff, ng, goff + ng));
+      p->routes |= KSH_ROUTE_PROBE_STAGED | (two_level ? KSH_ROUTE_SCATTER_TWO_LEVEL : 0);
       if (two_level) {
         // two levels of run-wise writes; the intermediate records borrow arrays that are written
         // later: u32 keys: the upper half of the chain-rank records; u64 keys (16-byte records): the
@@ -3157,18 +3184,20 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       if (!pb || (extra && !pb0)) return fail(KSH_INTERNAL, "scratch arena too small");
       hipLaunchKernelGGL((k_rc_bounds<KeyT>), dim3(nblk(ng * 2 * kRcSegs + (extra ? ng * 2 : 0))), dim3(256), 0, st, set,
                          gbits, pb, pb0);
+      p->routes |= per_group > 4096 ? KSH_ROUTE_RC_1024 : per_group > 1024 ? KSH_ROUTE_RC_512
+                   : per_group > 256 ? KSH_ROUTE_RC_256 : KSH_ROUTE_RC_64;
       if (per_group > 4096)
         hipLaunchKernelGGL((k_adj_rc<KeyT, 1024>), dim3(unsigned(ng)), dim3(1024), rc_lds, st, set, gbits, goff,
-                           rec, pb, pb0, cap, rc0, rc1);
+                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched);
       else if (per_group > 1024)
         hipLaunchKernelGGL((k_adj_rc<KeyT, 512>), dim3(unsigned(ng)), dim3(512), rc_lds, st, set, gbits, goff,
-                           rec, pb, pb0, cap, rc0, rc1);
+                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched);
       else if (per_group > 256)
         hipLaunchKernelGGL((k_adj_rc<KeyT, 256>), dim3(unsigned(ng)), dim3(256), rc_lds, st, set, gbits, goff,
-                           rec, pb, pb0, cap, rc0, rc1);
+                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched);
       else
         hipLaunchKernelGGL((k_adj_rc<KeyT, 64>), dim3(unsigned(ng)), dim3(64), rc_lds, st, set, gbits, goff,
-                           rec, pb, pb0, cap, rc0, rc1);
+                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched);
       static const bool fwd_probe = [] {
         const char* e = getenv("KSH_FWD");
         return e && std::string(e) == "probe";
@@ -3176,6 +3205,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       if (fwd_probe) {
         hipLaunchKernelGGL((k_adj_fwd<KeyT>), dim3(nblk(n)), dim3(256), 0, st, set, rc0, rc1, p->nbr, self_rc_flag);
       } else {
+        p->routes |= KSH_ROUTE_FWD_STAGED;
         // the records are dead by now: the chunk bounds take their place
         const int64_t n_chunks = (n + kFwdChunk - 1) / kFwdChunk;
         int64_t* bounds = reinterpret_cast<int64_t*>(p->info);  // kFwdBounds * 8 bytes per 512 k-mers
@@ -3263,6 +3293,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
           lr.n_mid = kLogMidRulers;
           lh.n_mid = kLogMidHeads;
           KSH_HIP(hipMemsetAsync(at8, 0xFF, size_t(n_dense + n_ends) * 8, st));  // nobody has walked yet
+          p->routes |= KSH_ROUTE_EMIT_LOGS;
         }
         p->log_rulers = lr;
         p->log_heads = lh;
@@ -3284,6 +3315,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
           const char* m = getenv("KSH_RANK_RACE_MIN");  // walkers from which one launch takes them all (A/B runs)
           return m ? int64_t(atoll(m)) : int64_t(1) << 18;
         }();
+        p->routes |= (n_dense >= race_min ? KSH_ROUTE_RANK_ONE_LAUNCH : 0) | (n_ends >= race_min ? KSH_ROUTE_HEADS_ONE_LAUNCH : 0);
         if (n_dense < race_min)
           hipLaunchKernelGGL(k_rank_walk<1>, dim3(nblk(n_dense)), dim3(256), 0, st, link, ns2, n_dense, rinfo, chain_info, lr,
                              static_cast<unsigned long long*>(nullptr), static_cast<unsigned long long*>(nullptr));
@@ -3305,6 +3337,8 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     unsigned long long* r2 = reinterpret_cast<unsigned long long*>(p->uid);        // n_jump * 8 <= 4n
     unsigned long long* l2_head = reinterpret_cast<unsigned long long*>(p->hlen);  // n_dense * 8 <= 4n
     unsigned long long* l2_stamp = reinterpret_cast<unsigned long long*>(p->hlast);
+    if (two_levels) p->routes |= KSH_ROUTE_JUMP_TWO_LEVEL;
+    if (stamped) p->routes = (p->routes | KSH_ROUTE_RANK_STAMPED) & ~int64_t(KSH_ROUTE_EMIT_LOGS | KSH_ROUTE_RANK_ONE_LAUNCH | KSH_ROUTE_HEADS_ONE_LAUNCH | KSH_ROUTE_JUMP_TWO_LEVEL);
     if (two_levels) {  // (l2_head / l2_stamp were set to unset by k_rank_walk<2>)
       hipLaunchKernelGGL(k_l2_walk<true>, dim3(nblk(n_jump)), dim3(256), 0, st, rinfo, n_dense, r2, l2_head, l2_stamp);
       hipLaunchKernelGGL(k_l2_walk<false>, dim3(nblk(n_dense)), dim3(256), 0, st, rinfo, n_dense, r2, l2_head, l2_stamp);
@@ -3484,6 +3518,14 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
                                                            (offsetof(EncCtl, walk_live) - offsetof(EncCtl, t2)));
   if (walk_rounds > 0 && walk_live_host[walk_rounds - 1])
     return fail(KSH_INTERNAL, "the path cover still holds a loop");
+  {
+    const char* tail = reinterpret_cast<const char*>(ctx->h_pinned);
+    const auto at_tail = [&](size_t member_off) { return tail + (member_off - offsetof(EncCtl, t2)); };
+    if (*reinterpret_cast<const int*>(at_tail(offsetof(EncCtl, rc_batched)))) p->routes |= KSH_ROUTE_RC_BATCHED;
+    const unsigned int* lc = reinterpret_cast<const unsigned int*>(at_tail(offsetof(EncCtl, long_count)));
+    if (!p->stamped && (lc[0] || lc[1])) p->routes |= KSH_ROUTE_LONG_STRETCHES;
+    if (p->rounds > kMatchFirst) p->routes |= KSH_ROUTE_MATCH_MORE_ROUNDS;
+  }
   if (mode != 1) ns = (ctx->h_pinned[0] & 0xFFFFFFFF) + (ctx->h_pinned[0] >> 32) + ctx->h_pinned[1];
   p->n_strings = ns;
   p->n_bases = ctx->h_pinned[2];
@@ -3584,6 +3626,14 @@ int ksh_spss_encode_write(ksh_ctx* ctx, uint64_t* d_words, uint32_t* d_lens) {
   if (p->n > 0 && (!d_words || !d_lens)) return fail(KSH_INVALID_ARGUMENT, "NULL output");
   KSH_HIP(hipSetDevice(ctx->device));
   return KSH_BY_KEY(p->g.key_bytes, encode_write_t, ctx, d_words, d_lens);
+}
+
+int ksh_spss_encode_routes(ksh_ctx* ctx, int64_t* routes) {
+  if (!ctx || !routes) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  EncPlan* p = static_cast<EncPlan*>(ctx->enc_state);
+  if (!p) return fail(KSH_FAILED_PRECONDITION, "no encode plan");
+  *routes = p->routes;
+  return KSH_OK;
 }
 
 int ksh_spss_encode_stats(ksh_ctx* ctx, int64_t stats[4]) {

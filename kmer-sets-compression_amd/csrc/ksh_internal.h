@@ -8,7 +8,9 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <functional>
 #include <map>
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -102,6 +104,7 @@ struct ksh_ctx {
   // freed blocks are kept and reused, because hipMalloc / hipFree of 100 MB-scale blocks
   // cost milliseconds and hipFree synchronises the device.  Single stream, so reuse after
   // free is ordered.
+  std::mutex pool_mu;  // (lane jobs allocate their results from their parent's pool: run_on_lanes)
   std::multimap<size_t, void*> pool_free_blocks;
   std::unordered_map<void*, size_t> pool_sizes;
   size_t pool_cached_bytes = 0;
@@ -109,6 +112,15 @@ struct ksh_ctx {
   // inject_min_bytes have succeeded, every further one fails; -1: off
   long long inject_skip = -1;
   size_t inject_min_bytes = 0;
+
+  // Lanes: helper contexts on the same device, each with a stream, scratch slots and arena of its own, on
+  // which independent jobs of one call run side by side with the context's own (ksh::run_on_lanes: the stale
+  // nodes of a convergence check are independent encodes, the inputs of a build independent decodes).
+  // They live as long as the context: their scratch is mapped once.
+  std::vector<ksh_ctx*> lanes;
+  ksh_ctx* lane_parent = nullptr;  // set in a lane: where its jobs' results are allocated
+  int lanes_wanted = -1;           // ksh_ctx_set_lanes; -1: KSH_LANES or the default
+  bool lanes_busy = false;
 
   // kernel timers: when enabled, every launch of a timed kind gets its own event
   // pair from a pool; ksh_ctx_timing_read sums them after a stream sync.
@@ -130,9 +142,25 @@ void* arena_alloc(ksh_ctx* ctx, size_t bytes);
 int plan_reserve(ksh_ctx* ctx, size_t bytes);
 enum { kSlotDecode = 0, kSlotEncode = 1, kSlotText = 2 };
 int slot_reserve(ksh_ctx* ctx, int which, size_t bytes);
+// (thread-safe; a lane's jobs allocate what outlives them from lane->lane_parent's pool)
 int pool_alloc(ksh_ctx* ctx, size_t bytes, void** out);
 void pool_free(ksh_ctx* ctx, void* p);
 void pool_trim(ksh_ctx* ctx);
+
+// Runs job(lane, q) for every q of `order` (most expensive first), on the context's stream and on up to
+// lanes_wanted - 1 helper contexts at once, each from a host thread of its own; the calling thread is lane 0.
+// `prepare(lane)` reserves the scratch the largest job needs and is called for a helper lane before it is
+// used (a lane that cannot get its scratch -- memory -- is left out, that is no error); `need_bytes` is what
+// that reservation takes, checked against the free memory first.  The context's stream is drained before
+// the jobs start and every lane's stream when they end, so callers see ordinary single-stream ordering.
+// Returns the first failure (its message becomes the calling thread's last error).
+int run_on_lanes(ksh_ctx* ctx, const std::vector<size_t>& order, size_t need_bytes,
+                 const std::function<int(ksh_ctx*)>& prepare, const std::function<int(ksh_ctx*, size_t)>& job);
+inline ksh_ctx* result_ctx(ksh_ctx* lane) { return lane->lane_parent ? lane->lane_parent : lane; }
+
+// Scratch of an SPSS encode / decode of n k-mers (slot + arena bytes): what a lane reserves (ksh_encode.hip, ksh_decode.hip)
+size_t encode_scratch_bytes(const ksh_geom* g, int64_t n);
+int encode_reserve(ksh_ctx* ctx, const ksh_geom* g, int64_t n);
 
 int check_geom(const ksh_geom* g);
 int check_view(const ksh_set_view* v, const char* name);  // ksh_pair.hip

@@ -159,32 +159,49 @@ static int alloc_keys(ksh_ctx* ctx, const ksh_geom* g, int64_t n_keys, KssSet* o
   return pool_alloc(ctx, std::max<size_t>(size_t(n_keys) * g->key_bytes, 16), &out->keys);
 }
 
+// (ctx may be a lane: the work runs on its stream with its scratch, the result lives in its parent's pool)
 static int decode_to_set(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* sp, int canonical_flag,
                          KssSet* out) {
-  KSH_TRY(alloc_offsets(ctx, g, out));
+  ksh_ctx* home = result_ctx(ctx);
+  KSH_TRY(alloc_offsets(home, g, out));
   int64_t n = 0;
-  KSH_TRY(ksh_spss_decode_plan(ctx, g, sp, canonical_flag, out->off, &n));
-  KSH_TRY(alloc_keys(ctx, g, n, out));
-  KSH_TRY(ksh_spss_decode_write(ctx, g, sp, canonical_flag, out->off, out->keys, &n));
+  int rc = ksh_spss_decode_plan(ctx, g, sp, canonical_flag, out->off, &n);
+  if (rc == KSH_OK) rc = alloc_keys(home, g, n, out);
+  if (rc == KSH_OK) rc = ksh_spss_decode_write(ctx, g, sp, canonical_flag, out->off, out->keys, &n);
+  if (rc != KSH_OK) {
+    free_set(home, out);
+    return rc;
+  }
   out->n = n;
   return KSH_OK;
 }
 
 static int encode_set(ksh_ctx* ctx, const ksh_geom* g, const KssSet& s, int canonical_flag,
                       KssCompact* out) {
+  ksh_ctx* home = result_ctx(ctx);
   const ksh_set_view v = view_of(s);
   int64_t ns = 0, nbases = 0;
   KSH_TRY(ksh_spss_encode_plan(ctx, g, &v, canonical_flag, 0, &ns, &nbases));
   out->owned = true;
-  KSH_TRY(pool_alloc(ctx, std::max<size_t>(size_t((nbases + 31) / 32) * 8, 16),
-                     reinterpret_cast<void**>(&out->words)));
-  KSH_TRY(pool_alloc(ctx, std::max<size_t>(size_t(ns) * 4, 16), reinterpret_cast<void**>(&out->lens)));
-  KSH_TRY(ksh_spss_encode_write(ctx, out->words, out->lens));
+  int rc = pool_alloc(home, std::max<size_t>(size_t((nbases + 31) / 32) * 8, 16), reinterpret_cast<void**>(&out->words));
+  if (rc == KSH_OK) rc = pool_alloc(home, std::max<size_t>(size_t(ns) * 4, 16), reinterpret_cast<void**>(&out->lens));
+  if (rc == KSH_OK) rc = ksh_spss_encode_write(ctx, out->words, out->lens);
+  if (rc != KSH_OK) {
+    free_compact(home, out);
+    return rc;
+  }
   out->n_strings = ns;
   out->n_bases = nbases;
   out->size = s.n;
   out->valid = true;
   return KSH_OK;
+}
+
+// Independent jobs of one build on the context's lanes (ksh::run_on_lanes): largest first.
+static std::vector<size_t> largest_first(const std::vector<size_t>& items, const std::function<int64_t(size_t)>& cost) {
+  std::vector<size_t> order(items);
+  std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return cost(a) > cost(b); });
+  return order;
 }
 
 // The reference re-encodes the three nodes of every merge at once (kmer_set_set.h:345-360), but
@@ -193,15 +210,30 @@ static int encode_set(ksh_ctx* ctx, const ksh_geom* g, const KssSet& s, int cano
 // encode is deferred to the points where the reference looks: same values, fewer encodes.
 static int ensure_compacts(ksh_kss* k) {
   if (k->world <= 1) {
-    for (size_t i = 0; i < k->compacts.size(); i++) {
-      if (k->compacts[i].valid) continue;
-      KssCompact c;
-      KSH_TRY(encode_set(k->ctx, &k->g, k->sets[i], k->canonical, &c));
-      k->compacts[i] = c;
-      k->n_encodes++;
-      k->n_encoded_kmers += k->sets[i].n;
-    }
-    return KSH_OK;
+    // the stale nodes are independent (kmer_set_set.h:287,345-360; their ids were fixed when they were made): on
+    // the context's lanes, several at once
+    std::vector<size_t> stale;
+    int64_t n_max = 0;
+    for (size_t i = 0; i < k->compacts.size(); i++)
+      if (!k->compacts[i].valid) {
+        stale.push_back(i);
+        n_max = std::max(n_max, k->sets[i].n);
+      }
+    const int rc = run_on_lanes(
+        k->ctx, largest_first(stale, [&](size_t i) { return k->sets[i].n; }), encode_scratch_bytes(&k->g, n_max),
+        [&](ksh_ctx* lane) { return encode_reserve(lane, &k->g, n_max); },
+        [&](ksh_ctx* lane, size_t i) {
+          KssCompact c;
+          KSH_TRY(encode_set(lane, &k->g, k->sets[i], k->canonical, &c));
+          k->compacts[i] = c;  // (distinct nodes: no two jobs write one element)
+          return int(KSH_OK);
+        });
+    for (size_t i : stale)
+      if (k->compacts[i].valid) {
+        k->n_encodes++;
+        k->n_encoded_kmers += k->sets[i].n;
+      }
+    return rc;
   }
   // Sharded: the stale nodes (the same list on every rank, the loop being deterministic) are
   // dealt out; a rank encodes its share and all ranks exchange what the loop reads,
@@ -1301,7 +1333,8 @@ static int build(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs,
                  const std::vector<int32_t>& ids, int32_t max_iterations) {
   ksh_ctx* ctx = k->ctx;
   const ksh_geom* g = &k->g;
-  // inputs: keep the caller's containers as the nodes' compacts, decode each once
+  // inputs: keep the caller's containers as the nodes' compacts, decode each once (the reference decodes and
+  // samples them on its pool, kmer_set_set.h:138-153: independent jobs, on the context's lanes)
   for (int32_t i = 0; i < n_inputs; i++) {
     KssCompact c;
     c.words = const_cast<uint64_t*>(inputs[i].d_words);
@@ -1309,13 +1342,25 @@ static int build(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs,
     c.n_strings = inputs[i].n_strings;
     c.n_bases = inputs[i].n_bases;
     c.owned = false;
-    KSH_TRY(ksh_spss_size(ctx, g, &inputs[i], &c.size));
     k->compacts.push_back(c);
     k->sets.emplace_back();
-    {
-      PhaseTimer pt(k, 0);
-      KSH_TRY(decode_to_set(ctx, g, &inputs[i], k->canonical, &k->sets.back()));
+  }
+  {
+    PhaseTimer pt(k, 0);
+    std::vector<size_t> all;
+    int64_t most_bases = 0;
+    for (int32_t i = 0; i < n_inputs; i++) {
+      all.push_back(size_t(i));
+      most_bases = std::max(most_bases, inputs[i].n_bases);
     }
+    KSH_TRY(run_on_lanes(
+        ctx, largest_first(all, [&](size_t i) { return inputs[i].n_bases; }),
+        size_t(most_bases) * size_t(g->key_bytes + 3) + (size_t(256) << 20),  // intermediate keys + bucket ids, histograms
+        [](ksh_ctx*) { return int(KSH_OK); },  // (the decode's scratch is small and grows on demand)
+        [&](ksh_ctx* lane, size_t i) {
+          KSH_TRY(ksh_spss_size(lane, g, &inputs[i], &k->compacts[i].size));  // KmerSetCompact::Size(): sum of len - K + 1
+          return decode_to_set(lane, g, &inputs[i], k->canonical, &k->sets[i]);
+        }));
   }
 
   std::map<std::pair<int, int>, int64_t> weights;

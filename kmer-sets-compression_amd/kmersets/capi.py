@@ -108,6 +108,8 @@ def lib():
         "ksh_ctx_timing_reset": (C.c_int, [vp]),
         "ksh_ctx_timing_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(i64)]),
         "ksh_ctx_timing_units": (C.c_int, [vp, C.c_int, C.POINTER(i64)]),
+        "ksh_ctx_set_lanes": (C.c_int, [vp, C.c_int]),
+        "ksh_ctx_timing_wall": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float)]),
         "ksh_set_hash": (C.c_int, [vp, GP, SP, C.POINTER(C.c_uint64)]),
         "ksh_dsu_components": (C.c_int, [vp, i64, vp, vp, i64, vp]),
         "ksh_set_contains": (C.c_int, [vp, GP, SP, vp, i64, vp]),
@@ -133,6 +135,7 @@ def lib():
         "ksh_spss_encode_plan": (C.c_int, [vp, GP, SP, C.c_int, C.c_int, C.POINTER(i64), C.POINTER(i64)]),
         "ksh_spss_encode_write": (C.c_int, [vp, vp, vp]),
         "ksh_spss_encode_stats": (C.c_int, [vp, C.POINTER(i64)]),
+        "ksh_spss_encode_routes": (C.c_int, [vp, C.POINTER(i64)]),
         "ksh_spss_encode_release": (C.c_int, [vp]),
         "ksh_set_union_plan": (C.c_int, [vp, GP, SP, SP, vp, C.POINTER(i64)]),
         "ksh_set_union_write": (C.c_int, [vp, GP, SP, SP, vp]),
@@ -389,6 +392,17 @@ class Context:
         check(lib().ksh_ctx_timing_units(self.h, kind, C.byref(n)))
         return n.value
 
+    def timing_wall(self, kind):
+        """ms during which at least one timed launch of the kind was running on any lane (union of the spans)."""
+        ms = C.c_float()
+        check(lib().ksh_ctx_timing_wall(self.h, kind, C.byref(ms)))
+        return ms.value
+
+    def set_lanes(self, n):
+        """Independent jobs of one call (a check's encodes, the inputs' decodes) on up to n streams at once; 1: one
+        stream, 0: the default (KSH_LANES, else 3)."""
+        check(lib().ksh_ctx_set_lanes(self.h, int(n)))
+
     # KmerSet::Hash / Size -------------------------------------------------------
     def set_hash(self, s):
         out = C.c_uint64()
@@ -553,6 +567,16 @@ class Context:
         st = (C.c_int64 * 4)()
         check(lib().ksh_spss_encode_stats(self.h, st))
         return {"unitigs": st[0], "rounds": st[1], "strings": st[2], "bases": st[3]}
+
+    ROUTES = ("probe_staged", "rc_1024", "rc_512", "rc_256", "rc_64", "rc_batched", "scatter_two_level",
+              "fwd_staged", "rank_one_launch", "heads_one_launch", "jump_two_level", "rank_stamped", "emit_logs",
+              "long_stretches", "match_more_rounds")
+
+    def spss_encode_routes(self):
+        """The kernel variants the last encode plan ran (KSH_ROUTE_* of include/kmersets_hip.h), as a set of names."""
+        r = C.c_int64()
+        check(lib().ksh_spss_encode_routes(self.h, C.byref(r)))
+        return {name for bit, name in enumerate(self.ROUTES) if r.value >> bit & 1}
 
     def pair_algebra_onepass(self, a, b):
         """(A & B, A \\ B, B \\ A) by ksh_pair_algebra (count + write passes enqueued back to

@@ -1,0 +1,146 @@
+"""Oracle string equality on inputs that PROVABLY take the kernel variants the headline bench runs
+("What's weak" 1): k_adj_rc<KeyT, 1024> with windows staged in several batches, the
+two-level rc scatter, two-level pointer jumping, the one-launch ranking walks -- each test asserts
+the route through ksh_spss_encode_routes, so a case cannot silently take another variant -- and a
+route differential at 10^8 k-mers: the default staged route against the size-independent in-place
+probe + stamping walks + emit by walking (independent algorithms; the latter oracle-checked at
+small sizes by test_encode_alternative_paths).  Reference: lib/core/spss.h:230-615,1358-1829."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import oracle_lib as ol
+from kmersets import capi, synth
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+@pytest.fixture(scope="module")
+def ctx(gpu):
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def encode_vs_oracle(ctx, k, n, kmers, must, must_not=()):
+    g = capi.geom(k, n)
+    d = capi.DeviceSet.from_kmers(g, kmers, ctx.device)
+    sp = ctx.spss_encode(d, mode=0)
+    routes = ctx.spss_encode_routes()
+    stats = ctx.spss_encode_stats()
+    missing = set(must) - routes
+    assert not missing and not (set(must_not) & routes), (sorted(routes), must, must_not)
+    want = ol.Set.from_kmers(k, n, g.key_bytes, kmers).spss()
+    got = sp.to_strings()
+    assert len(got) == len(want) and got == want
+    assert sp.n_bases == sum(len(x) for x in want)
+    back = ctx.spss_decode(sp)
+    assert back.n_keys == d.n_keys and ctx.set_diff(back, d) == 0
+    return routes, stats
+
+
+def test_u32_1024_threads_batched_windows(ctx):
+    """(19, 8, uint32_t), 5 x 10^6 k-mers: 19 500 k-mers per group > 4096 -> k_adj_rc<u32, 1024>; a window holds
+    7 976 keys, so every group's pass 0 (and pass 1 for most) takes several batches; N = 8 > kSgBits and
+    n >= 2^20 -> the two-level rc scatter; 3 x 10^5 ruler walkers >= 2^18 -> all of them in one launch."""
+    k, n = 19, 8
+    a = synth.phylogeny_sets(k, 1, 5_000_000, seed=41)[0]
+    encode_vs_oracle(ctx, k, n, a, {"probe_staged", "rc_1024", "rc_batched", "scatter_two_level", "fwd_staged",
+                                    "rank_one_launch", "emit_logs"}, {"rank_stamped"})
+
+
+def test_u32_fragmented_heads_one_launch(ctx):
+    """The intersection of two 5 %-diverged genomes of 10^7 bases, (19, 8, uint32_t): 3.8 x 10^6 k-mers in some
+    1.9 x 10^5 unitigs, so the chain-start walkers pass 2^18 and go in one launch too, the matching has work at
+    every junction and the path cover stitches multi-unitig strings -- on the 1024-thread, batched route."""
+    k, n = 19, 8
+    a, b = synth.phylogeny_sets(k, 2, 10_000_000, seed=43, rate=0.025)
+    inter = np.intersect1d(a, b)
+    assert 3_000_000 < inter.size < 4_500_000
+    routes, stats = encode_vs_oracle(ctx, k, n, inter, {"probe_staged", "rc_1024", "rc_batched", "scatter_two_level",
+                                                       "heads_one_launch"}, {"rank_stamped"})
+    assert stats["unitigs"] > 150_000
+
+
+def test_u64_1024_threads_batched_windows(ctx):
+    """(23, 8, uint64_t), 2.5 x 10^6 k-mers: 9 800 k-mers per group -> k_adj_rc<u64, 1024>, a window of 5 700
+    8-byte keys -> several batches; 16-byte records through the two-level scatter (the intermediate records
+    borrow nbr + link)."""
+    k, n = 23, 8
+    a = synth.phylogeny_sets(k, 1, 2_500_000, seed=47)[0]
+    encode_vs_oracle(ctx, k, n, a, {"probe_staged", "rc_1024", "rc_batched", "scatter_two_level", "fwd_staged",
+                                    "emit_logs"}, {"rank_stamped"})
+
+
+def test_bench_geometry_two_level_jumping(ctx):
+    """One (23, 14, uint32_t) set of 1.7 x 10^7 k-mers against the oracle: the bench's geometry with 2^20 ruler
+    records, i.e. two-level pointer jumping, the one-launch ranking, the two-level scatter at N = 14 (128
+    groups per super-group) and the emit from the logs with its long-stretch list."""
+    k, n = 23, 14
+    a = synth.phylogeny_sets(k, 1, 17_000_000, seed=53)[0]
+    encode_vs_oracle(ctx, k, n, a, {"probe_staged", "rc_512", "scatter_two_level", "fwd_staged", "rank_one_launch",
+                                    "jump_two_level", "emit_logs"}, {"rank_stamped"})
+
+
+ROUTE_WORKER = r"""
+import hashlib, json, sys
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import torch
+from kmersets import capi, synth_torch
+k, n, size = 23, 14, int(sys.argv[1])
+ctx = capi.Context(0)
+g = capi.geom(k, n)
+a, b = [synth_torch.device_set(g, x) for x in synth_torch.phylogeny_sets(k, 2, size, 61, ctx.device)]
+inter, amb, _ = ctx.pair_algebra(a, b)
+out = {}
+for name, s in (("genome", a), ("intersection", inter), ("difference", amb)):
+    sp = ctx.spss_encode(s, mode=0)
+    routes = sorted(ctx.spss_encode_routes())
+    torch.cuda.synchronize()
+    n_words = (sp.n_bases + 31) // 32
+    h = hashlib.sha256()
+    h.update(sp.words[:n_words].cpu().numpy().tobytes())
+    h.update(sp.lens[:sp.n_strings].cpu().numpy().tobytes())
+    back = ctx.spss_decode(sp)
+    ok = back.n_keys == s.n_keys and ctx.set_diff(back, s) == 0
+    out[name] = {"n": s.n_keys, "strings": sp.n_strings, "bases": sp.n_bases, "sha256": h.hexdigest(),
+                 "routes": routes, "roundtrip": bool(ok)}
+    del sp, back
+print("ROUTE_RESULT " + json.dumps(out))
+"""
+
+
+def _run_route(env_add, size):
+    env = dict(os.environ)
+    env.update(env_add)
+    code = ROUTE_WORKER % (os.path.join(os.path.dirname(HERE), "kmer-sets-compression_amd"), HERE)
+    r = subprocess.run([sys.executable, "-c", code, str(size)], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    line = [x for x in r.stdout.splitlines() if x.startswith("ROUTE_RESULT ")][-1]
+    return json.loads(line[len("ROUTE_RESULT "):])
+
+
+def test_route_differential_1e8(gpu):
+    """At the bench's size -- a 10^8-k-mer genome set, its intersection with a sibling and the difference set --
+    the default route (k_adj_rc<u32, 1024> with two batches for the dense groups, two-level scatter and jumping,
+    one-launch ranking, strings from the walk logs) and the route of independent, size-independent kernels
+    (k_adjacency probing in global memory, stamping walks + k_choose, k_emit) write the same SPSS words and
+    lengths, byte for byte.  The switches are read once per process: two processes."""
+    size = 100_000_000
+    default = _run_route({}, size)
+    other = _run_route({"KSH_ADJACENCY": "probe", "KSH_RANK": "stamp", "KSH_EMIT": "walk"}, size)
+    r = set(default["genome"]["routes"])
+    assert {"probe_staged", "rc_1024", "rc_batched", "scatter_two_level", "fwd_staged", "rank_one_launch",
+            "jump_two_level", "emit_logs"} <= r, sorted(r)
+    assert "probe_staged" not in other["genome"]["routes"] and "rank_stamped" in other["genome"]["routes"]
+    for name in ("genome", "intersection", "difference"):
+        d, o = default[name], other[name]
+        assert d["roundtrip"] and o["roundtrip"], name
+        assert (d["n"], d["strings"], d["bases"], d["sha256"]) == (o["n"], o["strings"], o["bases"], o["sha256"]), name
+    assert default["difference"]["strings"] > 1000 and default["genome"]["n"] > 99_000_000

@@ -73,6 +73,31 @@ def test_loop_vs_oracle_mid_size(ctx):
     dkss.close()
 
 
+@pytest.mark.parametrize("lanes", [1, 2, 4])
+def test_loop_lanes(gpu, lanes):
+    """The stale nodes of a check and the inputs' decodes on 1, 2 and 4 streams at once (ksh_ctx_set_lanes): the
+    same trace, checkpoints, DAG, node strings and Get(i) as the oracle's whichever lane encoded a node
+    (kmer_set_set.h:138-153,287,345-360: the reference runs these on its pool too), twice on the same context
+    (the helper lanes and their scratch are reused), and the timers add up: the union of the probe stage's
+    spans is no longer than their sum over the lanes."""
+    c = capi.Context(0)
+    c.set_lanes(lanes)
+    try:
+        for rep in range(2):
+            c.enable_timing(1)
+            c.timing_reset()
+            sets, osets, okss, dkss = build_both(c, 23, 14, 4, 12, 60000, 21 + rep)
+            assert compare(sets, osets, okss, dkss) > 0
+            (ms, launches), wall = c.timing_read(3), c.timing_wall(3)
+            assert launches == dkss.stats()["n_encodes"] and 0 < wall <= ms * 1.001 + 0.05
+            if lanes == 1:
+                assert abs(wall - ms) <= 0.02 * ms + 0.05
+            c.enable_timing(False)
+            dkss.close()
+    finally:
+        c.close()
+
+
 def test_loop_truncated_and_no_merge(ctx):
     k, n, kb = 23, 14, 4
     sets, osets, okss, dkss = build_both(ctx, k, n, kb, 6, 20000, 9, max_iterations=2)

@@ -9,17 +9,25 @@
 //   free Add / Sub / Intersection        the same (Intersection is NOT lhs.Sub(Sub(lhs, rhs)):
 //                                        one merge emits it directly)
 // Single-k-mer Add / Remove go through a pending list (flushed by the next bulk call);
-// Contains asks the device (ksh_set_contains; the batched overload takes many k-mers in one
+// Contains(kmer) looks at the pending edits, then at the host copy of the resident part (the one Find
+// keeps) or asks the device (ksh_set_contains; the batched overload takes many k-mers in one
 // launch); Find needs the k-mers on the host for its host predicate: they are expanded on the
 // device (ksh_set_kmers) and downloaded once.  n_workers stays in the signatures and is ignored.
+// Const methods may be called from several host threads at once, as the reference's are from its pool
+// threads (lib/core/kmer_set.h:51-52, spss.h:80-90): what they fill in lazily -- the flush of pending
+// edits, the host copy -- is filled in under a lock, each thread talks to the device through its own
+// context (ksc::Ctx()).  Non-const methods need the set to themselves, as in the reference.
 // KeyType keeps its meaning for the host-side accessors; on the device keys are 2 bytes when
 // 2K - N <= 16 (the reference's (15, 14, uint16_t)), 4 when <= 32, else 8.
 #ifndef KSC_CORE_KMER_SET_H_
 #define KSC_CORE_KMER_SET_H_
 
 #include <algorithm>
+#include <atomic>
 #include <cstdint>
+#include <mutex>
 #include <tuple>
+#include <unordered_set>
 #include <utility>
 #include <vector>
 
@@ -83,24 +91,33 @@ class KmerSet {
 
   void Clear() { *this = KmerSet(); }
 
+  // (the host copy mirrors the RESIDENT part and stays valid while edits are only pending: the reference's
+  // `while (!visited.Contains(cur)) visited.Add(cur)` (spss.h:206-216) then never touches the device)
   void Add(const Kmer<K>& kmer) {
+    if (!pending_remove_.empty()) Flush();  // keeps Remove-then-Add order
     pending_add_.push_back(kmer.Bits());
-    host_valid_ = false;
+    pending_add_index_.insert(kmer.Bits());
   }
 
   void Remove(const Kmer<K>& kmer) {
     Flush();  // keeps Add-then-Remove order
     pending_remove_.push_back(kmer.Bits());
-    host_valid_ = false;
   }
 
-  // One k-mer: a binary search in the host copy (the one Find keeps; fetched here for sets of up to 2^24
-  // k-mers, 128 MB: a loop of single queries then costs one download instead of an allocation, a launch
-  // and two copies per k-mer); a larger set without a host copy answers on the device.
+  // One k-mer: the pending edits first (removes are always younger than adds: Remove flushes), then a binary
+  // search in the host copy of the resident part -- fetched here, under the lock, for sets of up to 2^24 k-mers
+  // (128 MB: a loop of single queries then costs one download instead of an allocation, a launch and two copies
+  // per k-mer) -- and a larger set without a host copy answers on the device.  Nothing else is modified, so
+  // concurrent readers are safe (the reference calls this from its pool threads, spss.h:80-90).
   bool Contains(const Kmer<K>& kmer) const {
-    if (!host_valid_ && Size() > (std::int64_t(1) << 24)) return Contains(std::vector<Kmer<K>>{kmer})[0];
-    const std::vector<std::uint64_t>& bits = HostBits();
-    return std::binary_search(bits.begin(), bits.end(), kmer.Bits());
+    const std::uint64_t b = kmer.Bits();
+    if (!pending_remove_.empty() && std::find(pending_remove_.begin(), pending_remove_.end(), b) != pending_remove_.end())
+      return false;
+    if (pending_add_index_.count(b)) return true;
+    if (!resident_.load(std::memory_order_acquire)) return false;
+    if (!host_valid_.load(std::memory_order_acquire) && n_ > (std::int64_t(1) << 24)) return ResidentContains({b})[0];
+    const std::vector<std::uint64_t>& bits = ResidentHostBits();
+    return std::binary_search(bits.begin(), bits.end(), b);
   }
 
   // Batched membership: one launch for all queries, nothing of the set leaves the device.
@@ -108,15 +125,8 @@ class KmerSet {
     std::vector<std::uint64_t> bits;
     bits.reserve(kmers.size());
     for (const Kmer<K>& kmer : kmers) bits.push_back(kmer.Bits());
-    const ksc::DeviceBuffer d_q = ksc::DeviceBuffer::FromHost(bits);
-    ksc::DeviceBuffer d_f(bits.size());
-    const ksh_geom g = Geom();
-    const ksh_set_view v = View();
-    ksc::Check(ksh_set_contains(ksc::Ctx(), &g, &v, static_cast<const std::uint64_t*>(d_q.get()),
-                                static_cast<std::int64_t>(bits.size()), static_cast<std::uint8_t*>(d_f.get())));
-    ksc::Check(ksh_ctx_sync(ksc::Ctx()));
-    const std::vector<std::uint8_t> f = d_f.ToHost<std::uint8_t>(bits.size());
-    return std::vector<bool>(f.begin(), f.end());
+    Flush();
+    return ResidentContains(bits);
   }
 
   void Reserve(std::int64_t) {}
@@ -214,25 +224,69 @@ class KmerSet {
   // Ascending bit patterns of all k-mers: expanded on the device, downloaded once, cached.
   const std::vector<std::uint64_t>& HostBits() const {
     Flush();
-    if (!host_valid_) {
-      ksc::DeviceBuffer d_bits(static_cast<std::size_t>(n_) * 8);
-      const ksh_geom g = Geom();
-      const ksh_set_view v{static_cast<const std::int64_t*>(offsets_.get()), keys_.get(), n_};
-      ksc::Check(ksh_set_kmers(ksc::Ctx(), &g, &v, static_cast<std::uint64_t*>(d_bits.get())));
-      ksc::Check(ksh_ctx_sync(ksc::Ctx()));
-      host_ = d_bits.ToHost<std::uint64_t>(static_cast<std::size_t>(n_));
-      host_valid_ = true;
+    return ResidentHostBits();
+  }
+
+ private:
+  // A mutex / flag that a copy or a move of the set starts afresh (the set is a value type, lib/core/kmer_set.h:57).
+  struct Lock {
+    std::recursive_mutex m;
+    Lock() = default;
+    Lock(const Lock&) {}
+    Lock& operator=(const Lock&) { return *this; }
+  };
+  struct Flag {
+    std::atomic<bool> v{false};
+    Flag() = default;
+    Flag(const Flag& o) : v(o.v.load()) {}
+    Flag& operator=(const Flag& o) {
+      v.store(o.v.load());
+      return *this;
+    }
+    Flag& operator=(bool b) {
+      v.store(b, std::memory_order_release);
+      return *this;
+    }
+    bool load(std::memory_order mo = std::memory_order_acquire) const { return v.load(mo); }
+    operator bool() const { return load(); }
+  };
+
+  // The host copy of the resident part (pending edits are not in it), filled in once under the lock.
+  const std::vector<std::uint64_t>& ResidentHostBits() const {
+    if (!host_valid_.load()) {
+      std::lock_guard<std::recursive_mutex> lock(mu_.m);
+      if (!host_valid_.load()) {
+        ksc::DeviceBuffer d_bits(static_cast<std::size_t>(n_) * 8);
+        const ksh_geom g = Geom();
+        const ksh_set_view v{static_cast<const std::int64_t*>(offsets_.get()), keys_.get(), n_};
+        ksc::Check(ksh_set_kmers(ksc::Ctx(), &g, &v, static_cast<std::uint64_t*>(d_bits.get())));
+        ksc::Check(ksh_ctx_sync(ksc::Ctx()));
+        host_ = d_bits.ToHost<std::uint64_t>(static_cast<std::size_t>(n_));
+        host_valid_ = true;
+      }
     }
     return host_;
   }
 
- private:
+  // Membership in the resident part, on the device (the calling thread's context; the set is only read).
+  std::vector<bool> ResidentContains(const std::vector<std::uint64_t>& bits) const {
+    const ksc::DeviceBuffer d_q = ksc::DeviceBuffer::FromHost(bits);
+    ksc::DeviceBuffer d_f(bits.size());
+    const ksh_geom g = Geom();
+    const ksh_set_view v{static_cast<const std::int64_t*>(offsets_.get()), keys_.get(), n_};
+    ksc::Check(ksh_set_contains(ksc::Ctx(), &g, &v, static_cast<const std::uint64_t*>(d_q.get()),
+                                static_cast<std::int64_t>(bits.size()), static_cast<std::uint8_t*>(d_f.get())));
+    ksc::Check(ksh_ctx_sync(ksc::Ctx()));
+    const std::vector<std::uint8_t> f = d_f.ToHost<std::uint8_t>(bits.size());
+    return std::vector<bool>(f.begin(), f.end());
+  }
+
   void Adopt(ksc::DeviceBuffer off, ksc::DeviceBuffer keys, std::int64_t n) const {
     offsets_ = std::move(off);
     keys_ = std::move(keys);
     n_ = n;
-    resident_ = true;
     host_valid_ = false;
+    resident_ = true;
   }
 
   void Upload(std::vector<std::uint64_t> bits) const {
@@ -260,16 +314,17 @@ class KmerSet {
     host_valid_ = true;
   }
 
-  // Applies pending single-k-mer edits: set = (set | adds) \ removes.
+  // Applies pending single-k-mer edits: set = (set | adds) \ removes.  Under the lock: two const calls that both
+  // find edits pending apply them once.
   void Flush() const {
-    if (!resident_) {
-      resident_ = true;
-      Upload({});
-    }
+    if (resident_.load() && pending_add_.empty() && pending_remove_.empty()) return;
+    std::lock_guard<std::recursive_mutex> lock(mu_.m);
+    if (!resident_.load()) Upload({});
     if (pending_add_.empty() && pending_remove_.empty()) return;
     std::vector<std::uint64_t> adds, removes;
     adds.swap(pending_add_);
     removes.swap(pending_remove_);
+    pending_add_index_.clear();
     if (!adds.empty()) {
       std::sort(adds.begin(), adds.end());
       adds.erase(std::unique(adds.begin(), adds.end()), adds.end());
@@ -286,10 +341,12 @@ class KmerSet {
 
   mutable ksc::DeviceBuffer offsets_, keys_;
   mutable std::int64_t n_ = 0;
-  mutable bool resident_ = false;
+  mutable Flag resident_;
   mutable std::vector<std::uint64_t> pending_add_, pending_remove_;
+  mutable std::unordered_set<std::uint64_t> pending_add_index_;
   mutable std::vector<std::uint64_t> host_;
-  mutable bool host_valid_ = false;
+  mutable Flag host_valid_;  // host_ mirrors the resident part (not the pending edits)
+  mutable Lock mu_;
 
   friend class KmerSetCompact<K, N, KeyType>;
 };

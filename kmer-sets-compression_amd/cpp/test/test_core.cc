@@ -2,6 +2,7 @@
 // reference's own tests (test/kmer.cc, test/kmer_set.cc, test/spss.cc,
 // test/kmer_set_compact.cc, test/kmer_set_set.cc) with seeded inputs.  Needs a GPU:
 // every set operation below runs through libkmersets_hip.so.
+#include <algorithm>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -9,6 +10,7 @@
 #include <functional>
 #include <set>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "core/kmer.h"
@@ -141,6 +143,67 @@ static void TestKmerSet() {
     EXPECT_TRUE(s1.Equals(s1, 1) && s2.Equals(s2, 1) && s3.Equals(s3, 1));
     EXPECT_TRUE(s1.Equals(s2, 1) && s2.Equals(s1, 1));
     EXPECT_TRUE(!s1.Equals(s3, 1) && !s3.Equals(s1, 1));
+  }
+}
+
+// Single-k-mer edits interleaved with queries (the reference's `while (!visited.Contains(cur)) visited.Add(cur)`,
+// lib/core/spss.h:206-216), Remove-then-Add order, and const Contains from several threads at once on a set
+// without a host copy (spss.h:80-90 calls it from pool threads): every thread fills in the same cache.
+static void TestKmerSetEditsAndThreads() {
+  const int K = 9, N = 10;
+  using KeyType = std::uint8_t;
+  using Set = KmerSet<K, N, KeyType>;
+  {
+    Set visited;
+    std::set<std::uint64_t> model;
+    std::uint64_t cur = 12345;
+    int steps = 0;
+    while (!visited.Contains(Kmer<K>(cur))) {
+      EXPECT_TRUE(model.count(cur) == 0);
+      visited.Add(Kmer<K>(cur));
+      model.insert(cur);
+      cur = ksc::Mix64(cur) % 4000;  // a rho-shaped walk: comes back to a k-mer it has seen
+      steps++;
+    }
+    EXPECT_TRUE(steps > 10 && model.count(cur) == 1);
+    EXPECT_EQ(visited.Size(), static_cast<std::int64_t>(model.size()));
+    for (std::uint64_t b = 0; b < 4000; b += 7) EXPECT_EQ(visited.Contains(Kmer<K>(b)), model.count(b) == 1);
+    // Remove, then Add of the same k-mer: it is in; Add, then Remove: it is out
+    const Kmer<K> x(*model.begin());
+    visited.Remove(x);
+    EXPECT_TRUE(!visited.Contains(x));
+    visited.Add(x);
+    EXPECT_TRUE(visited.Contains(x));
+    EXPECT_EQ(visited.Size(), static_cast<std::int64_t>(model.size()));
+    visited.Add(Kmer<K>(5000));
+    visited.Remove(Kmer<K>(5000));
+    EXPECT_TRUE(!visited.Contains(Kmer<K>(5000)));
+    EXPECT_EQ(visited.Size(), static_cast<std::int64_t>(model.size()));
+  }
+  {
+    const Set s = RandomKmerSet<K, N, KeyType>(20000, true);
+    Set empty;
+    EXPECT_TRUE(!empty.Contains(Kmer<K>(1)));  // not resident yet
+    EXPECT_EQ(empty.Size(), 0);
+    EXPECT_TRUE(!empty.Contains(Kmer<K>(1)));  // an empty resident set
+    // a copy whose host cache is empty: rebuilt from the device by whichever thread gets there first
+    Set inter = Intersection(s, s, 1);
+    const std::vector<Kmer<K>> all = s.Find(1);
+    std::vector<int> bad(8, 0);
+    std::vector<std::thread> threads;
+    for (int t = 0; t < 8; t++)
+      threads.emplace_back([&, t]() {
+        const Set& r = inter;
+        for (std::size_t i = t; i < all.size(); i += 8)
+          if (!r.Contains(all[i])) bad[t]++;
+        for (std::uint64_t b = t; b < 3000; b += 8) {
+          const Kmer<K> q(b * 77 + 1);
+          const bool want = std::binary_search(all.begin(), all.end(), q, [](const Kmer<K>& l, const Kmer<K>& rr) { return l.Bits() < rr.Bits(); });
+          if (r.Contains(q) != want) bad[t]++;
+        }
+      });
+    for (std::thread& t : threads) t.join();
+    for (int t = 0; t < 8; t++) EXPECT_EQ(bad[t], 0);
   }
 }
 
@@ -365,6 +428,7 @@ int main() {
   try {
     TestKmer();
     TestKmerSet();
+    TestKmerSetEditsAndThreads();
     TestSpss();
     TestCompact();
     TestCounter();

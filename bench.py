@@ -339,15 +339,24 @@ def main():
         import subprocess
         import tempfile
 
-        native = os.path.join(tempfile.mkdtemp(prefix="ksh_oracle_"), "libkmersets_oracle_native.so")
-        oracle_build = "-O3 -march=native -DNDEBUG (compiled on this host)"
+        import shutil
+
+        native_dir = tempfile.mkdtemp(prefix="ksh_oracle_")
+        native = os.path.join(native_dir, "libkmersets_oracle_native.so")
+        oracle_build, oracle_native = "-O3 -march=native -DNDEBUG (compiled on this host)", True
         try:
             subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "-s", "native", "NATIVE_OUT=" + native],
                            check=True, timeout=600, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
             os.environ["KSH_ORACLE_LIB"] = native
-        except Exception:  # noqa: BLE001 -- no compiler on this host: the prebuilt portable copy
-            oracle_build = "-O3 (prebuilt portable copy: the native build failed)"
+        except Exception as e:  # noqa: BLE001 -- no compiler on this host: the prebuilt portable copy, and say so
+            oracle_build, oracle_native = "-O3 (prebuilt portable copy: the native build failed)", False
+            print("bench.py: the native build of the oracle failed (%s): the CPU baseline is timed on the portable "
+                  "-O3 copy" % e, file=sys.stderr)
         import oracle_lib as ol
+
+        ol.lib()  # (loaded now: the temporary directory can go once the library is mapped)
+        os.environ.pop("KSH_ORACLE_LIB", None)
+        shutil.rmtree(native_dir, ignore_errors=True)
 
         cs, ci = args.cpu_sets, args.cpu_iterations
         # the reference posts n_workers^2 chunks per parallel step, each with its own 2^N key buffers
@@ -386,6 +395,7 @@ def main():
         cpu_baseline = {
             "value": big["cpu_mkmers_per_s"], "unit": "Mk-mers/s", "cores": cores, "kind": "port",
             "cpu": cpu_model(), "host_cores_available": host_cores(), "oracle_build": oracle_build,
+            "oracle_native": oracle_native,
             "sample": "oracle KmerSetSet (C++ port of lib/core/kmer_set_set.h:109-427 with the reference's "
                       "bucket-parallel / pooled structure), %d sets of %d k-mers of the same family, first %d "
                       "iterations, N_proc = %d; %.1f s at %d workers"

@@ -380,6 +380,10 @@ int ksh_kss_node_holder(const ksh_kss* k, int32_t i, int32_t* rank);
 #define KSH_COMM_ID_BYTES 128
 typedef struct ksh_comm ksh_comm;
 typedef struct ksh_comm_fns {
+  /* = sizeof(ksh_comm_fns) of the header the caller was compiled against (ksh_version() >= 2): members beyond it
+   * are taken as NULL, so the struct can grow without old callers being read past their end; zero-initialise
+   * the struct and set the members you have */
+  size_t struct_size;
   void* user;
   /* d_recv receives world * bytes, rank-major */
   int (*allgather)(void* user, const void* d_send, void* d_recv, size_t bytes);

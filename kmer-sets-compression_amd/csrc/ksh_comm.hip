@@ -14,6 +14,8 @@
 
 #include <dlfcn.h>
 
+#include <algorithm>
+#include <cstddef>
 #include <cstring>
 #include <vector>
 
@@ -299,6 +301,8 @@ int ksh_comm_create_rccl(ksh_ctx* ctx, int32_t rank, int32_t world, const unsign
 int ksh_comm_create_custom(ksh_ctx* ctx, int32_t rank, int32_t world, const ksh_comm_fns* fns, ksh_comm** out) {
   if (!ctx || !out) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
   if (world < 1 || rank < 0 || rank >= world) return fail(KSH_INVALID_ARGUMENT, "bad rank / world");
+  if (fns && (fns->struct_size < offsetof(ksh_comm_fns, abort) || fns->struct_size > 4096))
+    return fail(KSH_INVALID_ARGUMENT, "ksh_comm_fns::struct_size = %zu: set it to sizeof(ksh_comm_fns)", fns->struct_size);
   if (world > 1 && (!fns || !fns->allgather || !fns->send || !fns->recv))
     return fail(KSH_INVALID_ARGUMENT, "a custom transport needs allgather, send and recv");
   ksh_comm* c = new ksh_comm;
@@ -306,7 +310,10 @@ int ksh_comm_create_custom(ksh_ctx* ctx, int32_t rank, int32_t world, const ksh_
   c->rank = rank;
   c->world = world;
   c->custom = true;
-  if (fns) c->fns = *fns;
+  if (fns) {  // (only what the caller's struct holds: members past its struct_size stay NULL)
+    std::memcpy(&c->fns, fns, std::min(fns->struct_size, sizeof(ksh_comm_fns)));
+    c->fns.struct_size = sizeof(ksh_comm_fns);
+  }
   *out = c;
   return KSH_OK;
 }

@@ -563,7 +563,7 @@ int launch_xor_keys(ksh_ctx* ctx, const ksh_set_view* s, unsigned blocks, unsign
 
 extern "C" {
 
-int ksh_version(void) { return 1; }
+int ksh_version(void) { return 2; }  // 2: ksh_comm_fns::struct_size, lanes, encode routes
 
 const char* ksh_last_error(void) { return g_last_error.c_str(); }
 
@@ -829,7 +829,10 @@ int ksh_dsu_components(ksh_ctx* ctx, int64_t n, const int32_t* d_x, const int32_
   DevDsu dsu{static_cast<unsigned long long*>(words)};
   arena_reset(ctx);
   int* d_bad = static_cast<int*>(arena_alloc(ctx, sizeof(int)));
-  if (!d_bad) return fail(KSH_INTERNAL, "scratch arena too small");
+  if (!d_bad) {
+    pool_free(ctx, words);
+    return fail(KSH_INTERNAL, "scratch arena too small");
+  }
   KSH_HIP(hipMemsetAsync(d_bad, 0, sizeof(int), ctx->stream));
   hipLaunchKernelGGL(k_dsu_reset, dim3(unsigned((n + 255) / 256)), dim3(256), 0, ctx->stream, dsu.a, n);
   if (m > 0)

@@ -1387,7 +1387,7 @@ __global__ __launch_bounds__(256) void k_rank_walk(const uint32_t* __restrict__ 
   const uint2 own = link_pair(link, r);
   uint32_t lk = leave_link(own, r);
   if (lk == kNone) {
-    rinfo[i] = make_rinfo(true, 0, r);
+    rec_post(rinfo + i, make_rinfo(true, 0, r));
     if (enter_link(own, r) == kNone) log.arrived(i, 0, r);  // a k-mer on its own: no walk arrives at it
     return;
   }
@@ -1397,7 +1397,9 @@ __global__ __launch_bounds__(256) void k_rank_walk(const uint32_t* __restrict__ 
     cur = step_to(cur, lk);
     steps++;
     if (sampled_ruler(cur) || steps >= 0x3FFFFFFFu) {
-      rinfo[i] = make_rinfo(false, steps, cur);
+      // (its own record too with an agent-scope store: its mirror image posts the same word in the same launch,
+      // and other walkers look at it)
+      rec_post(rinfo + i, make_rinfo(false, steps, cur));
       rec_post(rinfo + dense_index(cur ^ 1), make_rinfo(false, steps, r ^ 1));
       log.arrived(i, steps, cur);
       return;
@@ -1410,7 +1412,7 @@ __global__ __launch_bounds__(256) void k_rank_walk(const uint32_t* __restrict__ 
     // image arrives while it is under way -- 2.40 against 2.41 ms)
     lk = leave_link(link_pair(link, cur), cur);
     if (lk == kNone) {
-      rinfo[i] = make_rinfo(true, steps, cur);
+      rec_post(rinfo + i, make_rinfo(true, steps, cur));
       // the chain that starts at cur ^ 1 (an unsampled k-mer) has ruler r ^ 1 ahead of it
       rec_post(chain_info + (cur >> 1), make_chain_info(true, steps, dense_index(r ^ 1)));
       log.arrived(i, steps, cur);
@@ -1454,7 +1456,7 @@ __global__ __launch_bounds__(256) void k_rank_heads(const uint32_t* __restrict__
     cur = step_to(cur, lk);
     off++;
     if (sampled_ruler(cur)) {
-      chain_info[t] = make_chain_info(true, off, dense_index(cur));
+      rec_post(chain_info + t, make_chain_info(true, off, dense_index(cur)));
       rec_post(rinfo + dense_index(cur ^ 1), make_rinfo(true, off, s0 ^ 1));  // its walk ends at the chain end s0 ^ 1
       log.arrived(e, off, cur);
       return;
@@ -1465,7 +1467,7 @@ __global__ __launch_bounds__(256) void k_rank_heads(const uint32_t* __restrict__
     }
     lk = leave_link(link_pair(link, cur), cur);
     if (lk == kNone || off >= 0x3FFFFFFFu) {
-      chain_info[t] = make_chain_info(false, off, cur);
+      rec_post(chain_info + t, make_chain_info(false, off, cur));
       rec_post(chain_info + (cur >> 1), make_chain_info(false, off, s0 ^ 1));  // the mirror chain, from cur ^ 1 to s0 ^ 1
       log.arrived(e, off, cur);
       return;
@@ -2449,7 +2451,11 @@ __global__ __launch_bounds__(256) void k_string_ids(
 __global__ __launch_bounds__(256) void k_string_assign(
     const uint32_t* __restrict__ u_len, const unsigned long long* __restrict__ walk, int64_t n_u,
     const uint8_t* __restrict__ scls, const uint32_t* __restrict__ sid_at, bool one_sequence,
-    uint32_t* __restrict__ u_sid, uint32_t* __restrict__ u_koff, uint8_t* __restrict__ u_flip) {
+    uint32_t* __restrict__ u_sid, uint32_t* __restrict__ u_koff, uint8_t* __restrict__ u_flip,
+    const int* __restrict__ unfinished) {
+  // (the last jump round still changed something: the cover holds a loop that the cut missed, the host reports it
+  // after this batch of launches -- until then nothing is derived from walks that have not reached their ends)
+  if (unfinished && *unfinished) return;
   const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (u >= n_u) return;
   const unsigned long long wr = walk[2 * u + 1], wl = walk[2 * u];
@@ -2504,7 +2510,9 @@ __global__ __launch_bounds__(256) void k_unitig_place(const uint32_t* __restrict
                                                        const int64_t* __restrict__ str_start,
                                                        const uint32_t* __restrict__ lens,
                                                        const uint32_t* __restrict__ u_head, int64_t n_u,
-                                                       UnitigPlace* __restrict__ place_at_head) {
+                                                       UnitigPlace* __restrict__ place_at_head,
+                                                       const int* __restrict__ unfinished) {
+  if (unfinished && *unfinished) return;  // (see k_string_assign: string ids from unfinished walks index nothing)
   const int64_t u = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (u >= n_u) return;
   const uint32_t sid = u_sid[u];
@@ -3344,7 +3352,13 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       hipLaunchKernelGGL(k_l2_walk<false>, dim3(nblk(n_dense)), dim3(256), 0, st, rinfo, n_dense, r2, l2_head, l2_stamp);
     }
     // log5(records) + 3 launches end every chain (a loop of rulers never ends: k_rulers_done sees it); all of
-    // them are enqueued at once, a round after the last one that changed anything returns at its first load
+    // them are enqueued at once, a round after the last one that changed anything returns at its first load.
+    // (The kernels behind the rounds are safe on records that have not reached an end: every `next` field of a
+    // ruler, level-2 or chain-start record is a valid record index at every moment, a record without the end
+    // flag resolves to "on a loop" in chain_end_of / k_l2_resolve, and k_rulers_done raises the flag that sends
+    // the set through the stamping pass.  The path cover's rounds below are different: string ids derived from
+    // an unfinished walk would index the string table, so k_string_assign / k_unitig_place look at the last
+    // round's flag first.)
     int max_rounds = 3;  // a record's reach grows five-fold per launch (four hops): log5 of the records, and spare
     for (int64_t x = n_jump; x > 1; x /= (kJumpHops + 1)) max_rounds++;
     max_rounds = std::min(max_rounds, kJumpRoundsMax);
@@ -3500,13 +3514,14 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     hipLaunchKernelGGL(k_string_ids, dim3(nblk(n_u)), dim3(256), 0, st, n_u, p->scls, p->sc01, p->sc2, p->s_nk, d_t2,
                        slow, g->k, sid_at, p->lens, p->str_start);
     hipLaunchKernelGGL(k_string_assign, dim3(nblk(n_u)), dim3(256), 0, st, p->u_len, walk, n_u, p->scls, sid_at,
-                       slow, p->u_sid, p->u_koff, p->u_flip);
+                       slow, p->u_sid, p->u_koff, p->u_flip, &ctl->walk_live[walk_rounds - 1]);
   }
   // string starts in bases (a scan over n_u slots: the slots past the last string hold zero)
   arena_reset(ctx);
   KSH_TRY(scan_exclusive_i64(ctx, p->str_start, p->str_start, n_u, &ctl->n_bases));
   hipLaunchKernelGGL(k_unitig_place, dim3(nblk(n_u)), dim3(256), 0, st, p->u_len, p->u_sid, p->u_koff,
-                     p->u_flip, p->str_start, p->lens, p->u_head, n_u, reinterpret_cast<UnitigPlace*>(p->c01));
+                     p->u_flip, p->str_start, p->lens, p->u_head, n_u, reinterpret_cast<UnitigPlace*>(p->c01),
+                     walk_rounds > 0 ? &ctl->walk_live[walk_rounds - 1] : nullptr);
   KSH_HIP(hipGetLastError());
   // one look at everything the unitig level left behind: strings by class, bases, the last walk round's flag
   // (one copy: the block from t2 to its end, 436 bytes of the 512 pinned ones)

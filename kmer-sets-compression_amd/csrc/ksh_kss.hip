@@ -437,7 +437,10 @@ static int gather_i64(ksh_kss* k, const std::vector<int64_t>& send, std::vector<
   if (count > k->gx_cap) {  // (sized for the build's largest gather when it starts; growing may fail: then the rank leaves, see comm_abort)
     void *a = nullptr, *b = nullptr;
     KSH_TRY(pool_alloc(ctx, count * 2 * 8, &a));
-    KSH_TRY(pool_alloc(ctx, count * 2 * 8 * world, &b));
+    if (const int rc = pool_alloc(ctx, count * 2 * 8 * world, &b); rc != KSH_OK) {
+      pool_free(ctx, a);
+      return rc;
+    }
     pool_free(ctx, k->gx_send);
     pool_free(ctx, k->gx_recv);
     k->gx_send = static_cast<int64_t*>(a);
@@ -546,14 +549,20 @@ static int recv_set_on(ksh_kss* k, int peer, KssSet* out, bool side) {
     dst = ctx->slot[kSlotEncode];
     if (need > ctx->slot_bytes[kSlotEncode])
       return fail(KSH_INTERNAL, "rank %d cannot take %zu bytes sent to it: %s", k->rank, need, k->local_msg.c_str());
-  } else {
-    KSH_HIP(hipMemcpyAsync(s.off, k->xfer_off, size_t(nb + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
+  } else if (hipMemcpyAsync(s.off, k->xfer_off, size_t(nb + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream) != hipSuccess) {
+    free_set(ctx, &s);
+    return fail(KSH_INTERNAL, "hipMemcpyAsync of the received offsets failed");
   }
+  int rc = KSH_OK;
   if (side) {
-    KSH_TRY(comm_side_recv(k->comm, dst, size_t(n) * k->g.key_bytes, peer));
-    KSH_TRY(comm_side_join_main(k->comm));
+    rc = comm_side_recv(k->comm, dst, size_t(n) * k->g.key_bytes, peer);
+    if (rc == KSH_OK) rc = comm_side_join_main(k->comm);
   } else {
-    KSH_TRY(comm_recv(k->comm, dst, size_t(n) * k->g.key_bytes, peer));
+    rc = comm_recv(k->comm, dst, size_t(n) * k->g.key_bytes, peer);
+  }
+  if (rc != KSH_OK) {  // (the transport failed: the set that was to take the keys goes back to the pool)
+    free_set(ctx, &s);
+    return rc;
   }
   if (!alive(k)) KSH_HIP(hipStreamSynchronize(ctx->stream));  // (the scratch is free again when this returns)
   k->p2p_bytes_received += (nb + 1) * 8 + n * k->g.key_bytes;

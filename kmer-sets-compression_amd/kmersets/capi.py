@@ -49,7 +49,7 @@ COMM_ABORT_FN = C.CFUNCTYPE(None, C.c_void_p)
 
 
 class CommFns(C.Structure):
-    _fields_ = [("user", C.c_void_p), ("allgather", COMM_ALLGATHER_FN), ("send", COMM_P2P_FN),
+    _fields_ = [("struct_size", C.c_size_t), ("user", C.c_void_p), ("allgather", COMM_ALLGATHER_FN), ("send", COMM_P2P_FN),
                 ("recv", COMM_P2P_FN), ("abort", COMM_ABORT_FN)]
 
 
@@ -934,7 +934,7 @@ class Comm:
                     f()
 
             self._keep = (COMM_ALLGATHER_FN(allgather), COMM_P2P_FN(send), COMM_P2P_FN(recv), COMM_ABORT_FN(abort))
-            self._fns = CommFns(None, *self._keep)
+            self._fns = CommFns(C.sizeof(CommFns), None, *self._keep)
             check(lib().ksh_comm_create_custom(ctx.h, self.rank, self.world, C.byref(self._fns), C.byref(h)))
             self.kind = "custom"
         self.h = h

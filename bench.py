@@ -28,6 +28,11 @@ Prints ONE JSON line on rank 0.
                context's stream, against the 8 TB/s HBM peak; the probe-inclusive figure
                (36 B per k-mer: the key + 8 neighbour lookups) is reported beside it; `traffic`
                from profiles/pmc_adjacency.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes).
+               The timed builds run the independent encodes of a check on several streams at once
+               (lanes, ksh_ctx_set_lanes): a launch's duration there depends on what shares the GPU
+               with it, so the kernel's own figure comes from ONE more build of the same inputs on ONE
+               stream, run inside this script right after the timed region; the timed region's sums
+               (stream time and union of the spans) are under roofline.timed_region.
   cpu_baseline the oracle's port of the same loop, compiled on this host with the reference's release
                flags (-O3 -march=native -DNDEBUG), bucket-parallel threads as the reference has
                them: the first I iterations of a 16 x 10^7 family at n_workers = all host cores,
@@ -204,9 +209,28 @@ def main():
         kss = build()
     fence()
     elapsed = time.perf_counter() - t0
-    timers = {name: (ctx.timing_read(kind), ctx.timing_units(kind), ctx.timing_wall(kind))
-              for name, kind in (("k_adjacency", 3), ("ranking_walks", 4), ("emit_walks", 5))}
+    KINDS = (("k_adjacency", 3), ("ranking_walks", 4), ("emit_walks", 5))
+    timers = {name: (ctx.timing_read(kind), ctx.timing_units(kind), ctx.timing_wall(kind)) for name, kind in KINDS}
     ctx.enable_timing(False)
+    # The roofline leg proper: ONE more build of the same inputs on ONE stream (lanes = 1), every launch of the
+    # stage bracketed by HIP events on that stream.  In the timed region above several encodes share the GPU
+    # (lanes): a launch's duration there depends on whose kernels run beside it, so it says how the streams
+    # overlap, not what the kernel does with the GPU; both are reported (`roofline.timed_region`).
+    lanes_used = args.lanes if args.lanes > 0 else int(os.environ.get("KSH_LANES", "3"))
+    timers_timed, excl_wall = timers, None
+    if world == 1 and lanes_used != 1:
+        kss.close()
+        ctx.set_lanes(1)
+        ctx.enable_timing(1)
+        ctx.timing_reset()
+        fence()
+        e0 = time.perf_counter()
+        kss = build()
+        fence()
+        excl_wall = time.perf_counter() - e0
+        timers = {name: (ctx.timing_read(kind), ctx.timing_units(kind), ctx.timing_wall(kind)) for name, kind in KINDS}
+        ctx.enable_timing(False)
+        ctx.set_lanes(args.lanes)
 
     st = kss.stats()
     it, cp, imp = kss.trace()
@@ -424,25 +448,35 @@ def main():
         traffic_per_kmer = None
 
     if rank == 0:
-        # The stage's launches run on several streams at once (lanes): adj_ms sums their HIP-event durations over
-        # the streams (what a kernel trace's per-kernel averages add up to: a launch that shares the GPU with
-        # another lane's kernels takes longer), adj_wall_ms is the length of the UNION of those spans, i.e. the time
-        # during which the GPU was running the stage on at least one stream.  The GPU's rate on the stage is the
-        # stage's bytes over the union; the per-stream figure is kept beside it.
+        # `timers`: the one-stream build (the stage's launches alone on the GPU: sum of spans == their union);
+        # `timers_timed`: the timed region, where launches of different lanes overlap -- stream time = the sum of
+        # the spans (what a kernel trace's per-kernel durations add up to), union = the time during which the
+        # stage was running on at least one stream.
         (adj_ms, adj_launches), adj_units, adj_wall_ms = timers["k_adjacency"]
         kmers_per_launch = adj_units / max(adj_launches, 1)
-        avg_launch_ms = adj_wall_ms / max(adj_launches, 1)
-        avg_launch_stream_ms = adj_ms / max(adj_launches, 1)
+        avg_launch_ms = adj_ms / max(adj_launches, 1)
         bytes_per_launch = ENCODE_BYTES_PER_KMER * kmers_per_launch
-        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if adj_wall_ms > 0 else 0.0
-        achieved_stream = bytes_per_launch / (avg_launch_stream_ms * 1e-3) / 1e9 if adj_ms > 0 else 0.0
+        achieved = bytes_per_launch / (avg_launch_ms * 1e-3) / 1e9 if adj_ms > 0 else 0.0
+        (t_ms, t_launches), t_units, t_wall_ms = timers_timed["k_adjacency"]
+        timed_region = {
+            "lanes": lanes_used, "launches": int(t_launches), "kmers": int(t_units),
+            "stream_time_ms": t_ms, "union_ms": t_wall_ms,
+            "ns_per_kmer_stream_time": t_ms * 1e6 / max(t_units, 1), "ns_per_kmer_union": t_wall_ms * 1e6 / max(t_units, 1),
+            "frac_stream_time": ENCODE_BYTES_PER_KMER * t_units / max(t_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
+            "frac_union": ENCODE_BYTES_PER_KMER * t_units / max(t_wall_ms * 1e-3, 1e-12) / 1e9 / HBM_PEAK_GBS,
+            "share_of_timed_region_union": t_wall_ms * 1e-3 / elapsed,
+            "note": "HIP events around every launch of the stage in the %d timed builds; launches of different lanes "
+                    "overlap and share the GPU by time, so a launch takes longer there than alone" % args.steps,
+        }
         if traffic_per_kmer is not None:
             traffic = traffic_per_kmer * kmers_per_launch
         other = {}
         for name in ("ranking_walks", "emit_walks"):
             (ms, n), units, wall = timers[name]
-            other[name] = {"ms_total_stream_time": ms, "ms_union": wall, "launches": n,
-                           "ns_per_kmer": wall * 1e6 / max(units, 1), "ns_per_kmer_stream_time": ms * 1e6 / max(units, 1)}
+            (tms, tn), tunits, twall = timers_timed[name]
+            other[name] = {"ms_total": ms, "launches": n, "ns_per_kmer": ms * 1e6 / max(units, 1),
+                           "timed_region_ns_per_kmer_stream_time": tms * 1e6 / max(tunits, 1),
+                           "timed_region_ns_per_kmer_union": twall * 1e6 / max(tunits, 1)}
         out = {
             "metric": "Mk-mers/s processed in kmerset-multiple-compress; bytes/k-mer after SPSS",
             "value": value,
@@ -484,21 +518,17 @@ def main():
                 "traffic_source": traffic_src,
                 "launches": int(adj_launches),
                 "avg_launch_ms": avg_launch_ms,
-                "timing": "HIP events around every launch of the stage on the stream it runs on; launches of different "
-                          "lanes overlap: avg_launch_ms = (union of the spans over all streams) / launches, "
-                          "avg_launch_stream_ms = (sum of the spans) / launches (what a kernel trace adds up to)",
-                "lanes": args.lanes if args.lanes > 0 else int(os.environ.get("KSH_LANES", "3")),
-                "avg_launch_stream_ms": avg_launch_stream_ms,
-                "achieved_stream_time": achieved_stream,
-                "frac_stream_time": achieved_stream / HBM_PEAK_GBS,
+                "timing": "HIP events on the context's stream around every launch of the stage, in one build of the "
+                          "same inputs on ONE stream (lanes = 1) run right after the timed builds%s"
+                          % ("" if excl_wall is None else ": %.1f ms for that build" % (excl_wall * 1e3)),
                 "kmers_per_launch": kmers_per_launch,
-                "ns_per_kmer": adj_wall_ms * 1e6 / max(adj_units, 1),
-                "ns_per_kmer_stream_time": adj_ms * 1e6 / max(adj_units, 1),
+                "ns_per_kmer": adj_ms * 1e6 / max(adj_units, 1),
+                "timed_region": timed_region,
                 "algorithmic_bytes_per_kmer": ENCODE_BYTES_PER_KMER,
                 "algorithmic_bytes_per_launch": bytes_per_launch,
                 "probe_inclusive_bytes_per_kmer": ENCODE_PROBE_BYTES_PER_KMER,
                 "probe_inclusive_frac": achieved / HBM_PEAK_GBS * ENCODE_PROBE_BYTES_PER_KMER / ENCODE_BYTES_PER_KMER,
-                "share_of_timed_region": adj_wall_ms * 1e-3 / elapsed,
+                "share_of_one_stream_build": adj_ms * 1e-3 / (excl_wall if excl_wall else elapsed / args.steps),
                 "other_kernels": other,
             },
             "cpu_baseline": cpu_baseline,

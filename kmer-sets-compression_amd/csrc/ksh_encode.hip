@@ -2978,6 +2978,14 @@ inline int64_t l2_threshold() {
   }();
   return v;
 }
+// (Measured and dropped, round 4: with several encodes in flight on different streams (lanes), dynamic LDS added to
+// the walk / forward-probe / emit launches to cap how many of their workgroups share a CU, so that another lane's
+// kernels find wave slots beside them -- the hope being that the LDS-bound probes and the walks that wait on HBM
+// would use the CU together.  64 x 10^8 build at 3 lanes, ms: no cap 779.8; walks at 4 workgroups per CU 782.0;
+// walks and emit at 4: 804.2; walks at 8: 777.2; walks at 4 and the forward probe at 3: 797.1; walks at 2: 862.5.
+// A kernel trace of the 3-lane build shows three kernels running 62 % of the time and their summed durations
+// 2.3 x those of the one-lane build: concurrent kernels share the GPU by time, not by resource; what lanes
+// buy is the idle time between one encode's kernels and behind its host round trips.)
 inline unsigned nblk(int64_t n) { return unsigned(std::max<int64_t>(1, (n + 255) / 256)); }
 
 template <typename T>

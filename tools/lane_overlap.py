@@ -5,6 +5,7 @@ build's span (from the last k_str_bases-led burst of decode kernels to the end),
 usage: lane_overlap.py kernel_trace.csv [--from-kernel NAME]"""
 import collections
 import csv
+import re
 import sys
 
 rows = []
@@ -14,7 +15,8 @@ rows.sort()
 
 
 def short(n):
-    return n.split("ksh::")[-1].split("(")[0].split("<")[0][:32]
+    m = re.search(r"ksh::(k_\w+)", n)
+    return m.group(1) if m else n.split("(")[0][:32]
 
 
 # the last build: after the largest gap between two ksh kernels in the second half of the trace

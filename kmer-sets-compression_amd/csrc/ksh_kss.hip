@@ -822,10 +822,13 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
     pool_free(ctx, d_ids);
   }
 
-  // KSH_OWNED_WEIGHTS=sharded: the weight tables by pair list + one all-gather of int64 per iteration
+  // The weight tables by pair list + ONE all-gather of int64 per iteration (the exchange north_star names;
+  // lib/core/kmer_set_set.h:205-218,385-425): the default since the full-size merges are deferred to the end of
+  // their interval (below) and the all-gather no longer sits behind the rank that runs an iteration's merge.
+  // KSH_OWNED_WEIGHTS=replicated: every rank weighs its replica of the samples, nothing is exchanged.
   static const bool shard_weights = [] {
     const char* e = getenv("KSH_OWNED_WEIGHTS");
-    return e && std::string(e) == "sharded";
+    return !(e && std::string(e) == "replicated");
   }();
   const auto weigh = [&](const std::vector<std::pair<int, int>>& pairs, std::vector<int64_t>* w) {
     return shard_weights && world > 1 ? sample_weights_sharded(k, ids, pairs, w) : sample_weights(k, ids, pairs, w);
@@ -978,26 +981,31 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
       for (double l : load) lightest = std::min(lightest, l);
       for (int r = 0; r < world; r++) lag[size_t(r)] = lookahead ? load[size_t(r)] - lightest : 0.0;
     }
+    // books an encoded node (c.valid: the encode ran and succeeded)
+    const auto book_node = [&](size_t q, KssCompact c) {
+      const size_t node = pd->stale[q];
+      if (c.valid) {
+        k->n_encodes++;
+        k->n_encoded_kmers += k->sets[node].n;
+        pd->send[3 * q] = c.n_strings;
+        pd->send[3 * q + 1] = c.n_bases;
+        pd->send[3 * q + 2] = c.size;
+      } else {
+        c = KssCompact{};
+      }
+      c.valid = false;  // known here, not yet everywhere
+      c.holder = rank;
+      k->compacts[node] = c;
+    };
     const auto encode_node = [&](size_t q) {
       const size_t node = pd->stale[q];
       KssCompact c;
       c.valid = false;
       if (alive(k) && k->sets[node].off) {  // (a failed rank's slots stay -1; its status travels with them)
         poison(k, encode_set(ctx, g, k->sets[node], k->canonical, &c));
-        if (alive(k)) {
-          c.valid = false;  // known here, not yet everywhere
-          k->n_encodes++;
-          k->n_encoded_kmers += k->sets[node].n;
-          pd->send[3 * q] = c.n_strings;
-          pd->send[3 * q + 1] = c.n_bases;
-          pd->send[3 * q + 2] = c.size;
-        } else {
-          c = KssCompact{};
-          c.valid = false;
-        }
+        if (!alive(k)) c = KssCompact{}, c.valid = false;
       }
-      c.holder = rank;
-      k->compacts[node] = c;
+      book_node(q, c);
     };
     // 1. what I give away leaves first, under my own encodes
     std::vector<size_t> given;
@@ -1010,9 +1018,30 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
         given.push_back(node);
       }
     }
-    // 2. my own nodes
-    for (size_t q = 0; q < n_tasks; q++)
-      if (encoder[q] == rank && k->owner[pd->stale[q]] == rank) encode_node(q);
+    // 2. my own nodes: independent encodes, several at once on the context's lanes
+    {
+      std::vector<size_t> mine;
+      int64_t n_max = 0;
+      for (size_t q = 0; q < n_tasks; q++)
+        if (encoder[q] == rank && k->owner[pd->stale[q]] == rank) {
+          mine.push_back(q);
+          n_max = std::max(n_max, k->sets[pd->stale[q]].n);
+        }
+      std::vector<KssCompact> done(n_tasks);
+      for (KssCompact& c : done) c.valid = false;
+      if (alive(k) && !mine.empty())
+        poison(k, run_on_lanes(
+                      ctx, largest_first(mine, [&](size_t q) { return k->sets[pd->stale[q]].n; }),
+                      encode_scratch_bytes(g, n_max), [&](ksh_ctx* lane) { return encode_reserve(lane, g, n_max); },
+                      [&](ksh_ctx* lane, size_t q) {
+                        const size_t node = pd->stale[q];
+                        if (!k->sets[node].off) return int(KSH_OK);
+                        const int rc = encode_set(lane, g, k->sets[node], k->canonical, &done[q]);
+                        if (rc != KSH_OK) done[q].valid = false;
+                        return rc;
+                      }));
+      for (size_t q : mine) book_node(q, done[q]);
+    }
     // 3. what I take, as it arrives
     for (size_t q = 0; q < n_tasks; q++) {
       const size_t node = pd->stale[q];
@@ -1142,9 +1171,87 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
     return KSH_OK;
   };
 
+  // ---- the full-size merges of an interval, deferred to its end.  Nothing the control loop decides reads the
+  // full sets (the arg-max reads sample weights, the samples of a merge's results are the merge of the samples),
+  // so an iteration only RECORDS its merge -- who runs it (the owner of j), who sends k -- and every rank works
+  // its part of the list off, in iteration order, right before the point where the sets are read: the
+  // encodes of the next check (or the end).  The order of the sends and receives between any two ranks is the
+  // list's order on both, as it was when every merge ran in its iteration.  What it buys: with the weight
+  // tables dealt out by pair list (one all-gather per iteration) no rank waits any more for the one that runs
+  // the iteration's merge -- the merges of an interval run side by side on their executors, 2-3 per rank
+  // instead of 9 one after the other with seven ranks waiting.  KSH_OWNED_MERGES=inline runs
+  // every merge in its iteration, as before.
+  static const bool defer_merges = [] {
+    const char* e = getenv("KSH_OWNED_MERGES");
+    return !(e && std::string(e) == "inline");
+  }();
+  struct MergeTask {
+    int iteration, j, kk, n, ex, src;
+    size_t row;  // its row of my_rows
+  };
+  std::vector<MergeTask> merge_tasks;
+  const auto retire_set = [&](KssSet* st) {
+    retire(k, st->off);
+    retire(k, st->keys);
+    *st = KssSet{};
+  };
+  const auto run_merge = [&](const MergeTask& t) {
+    const int j = t.j, kk = t.kk, n = t.n, ex = t.ex, src = t.src;
+    if (rank == ex) {
+      PhaseTimer pt(k, 2);
+      KssSet pulled;
+      if (src != ex) KSH_TRY(recv_set(k, src, &pulled));
+      const KssSet& set_k = src != ex ? pulled : k->sets[size_t(kk)];
+      KssSet sn, sj, sk;
+      int64_t original_size = -1;
+      // rank-local from here: a failure (an allocation under memory pressure) leaves the three results
+      // empty, the rank goes on with the protocol and every rank hears of it at the next exchange
+      if (alive(k) && !(k->sets[size_t(j)].off && set_k.off))
+        poison(k, fail(KSH_INTERNAL, "iteration %d: rank %d does not hold both sets of the pair", t.iteration, rank));
+      if (alive(k)) {
+        const ksh_set_view vj = view_of(k->sets[size_t(j)]), vk = view_of(set_k);
+        original_size = vj.n_keys + vk.n_keys;
+        int64_t totals[3] = {0, 0, 0};
+        KSH_LOCAL(k, alloc_offsets(ctx, g, &sn));
+        KSH_LOCAL(k, alloc_offsets(ctx, g, &sj));
+        KSH_LOCAL(k, alloc_offsets(ctx, g, &sk));
+        KSH_LOCAL(k, ksh_pair_plan(ctx, g, &vj, &vk, sn.off, sj.off, sk.off, totals));
+        KSH_LOCAL(k, alloc_keys(ctx, g, totals[0], &sn));
+        KSH_LOCAL(k, alloc_keys(ctx, g, totals[1], &sj));
+        KSH_LOCAL(k, alloc_keys(ctx, g, totals[2], &sk));
+        KSH_LOCAL(k, ksh_pair_write(ctx, g, &vj, &vk, sn.keys, sj.keys, sk.keys));
+        if (!alive(k)) {
+          free_set(ctx, &sn);
+          free_set(ctx, &sj);
+          free_set(ctx, &sk);
+        }
+      }
+      if (src != ex) retire_set(&pulled); else retire_set(&k->sets[size_t(kk)]);
+      retire_set(&k->sets[size_t(j)]);
+      k->sets[size_t(j)] = sj;
+      k->sets[size_t(kk)] = sk;
+      k->sets[size_t(n)] = sn;
+      int64_t* row = my_rows.data() + 5 * t.row;
+      row[3] = original_size;
+      row[4] = sn.n + sj.n + sk.n - original_size;
+    } else if (rank == src) {
+      PhaseTimer pt(k, 2);
+      KSH_TRY(send_set(k, k->sets[size_t(kk)], ex));
+      KSH_HIP(hipStreamSynchronize(ctx->stream));  // the keys have left before their buffer is reused
+      retire_set(&k->sets[size_t(kk)]);
+    }
+    return int(KSH_OK);
+  };
+  const auto run_deferred_merges = [&]() {
+    for (const MergeTask& t : merge_tasks) KSH_TRY(run_merge(t));
+    merge_tasks.clear();
+    return int(KSH_OK);
+  };
+
   for (int i = 0;; i++) {
     if (max_iterations >= 0 && i >= max_iterations) break;
     if (i > 0 && i % interval == 0) {
+      KSH_TRY(run_deferred_merges());  // the sets the check's encodes read
       Pending next;
       next.id = ++n_checks;
       next.iteration = i;
@@ -1227,53 +1334,10 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
     executor.push_back(ex);
     my_rows.insert(my_rows.end(), {int64_t(j), int64_t(kk), weight, -1, 0});
     k->sets.emplace_back();
-    const auto retire_set = [&](KssSet* st) {
-      retire(k, st->off);
-      retire(k, st->keys);
-      *st = KssSet{};
-    };
-    if (rank == ex) {
-      PhaseTimer pt(k, 2);
-      KssSet pulled;
-      if (src != ex) KSH_TRY(recv_set(k, src, &pulled));
-      const KssSet& set_k = src != ex ? pulled : k->sets[size_t(kk)];
-      KssSet sn, sj, sk;
-      int64_t original_size = -1;
-      // rank-local from here: a failure (an allocation under memory pressure) leaves the three results
-      // empty, the rank goes on with the protocol and every rank hears of it at the next exchange
-      if (alive(k) && !(k->sets[size_t(j)].off && set_k.off))
-        poison(k, fail(KSH_INTERNAL, "iteration %d: rank %d does not hold both sets of the pair", i, rank));
-      if (alive(k)) {
-        const ksh_set_view vj = view_of(k->sets[size_t(j)]), vk = view_of(set_k);
-        original_size = vj.n_keys + vk.n_keys;
-        int64_t totals[3] = {0, 0, 0};
-        KSH_LOCAL(k, alloc_offsets(ctx, g, &sn));
-        KSH_LOCAL(k, alloc_offsets(ctx, g, &sj));
-        KSH_LOCAL(k, alloc_offsets(ctx, g, &sk));
-        KSH_LOCAL(k, ksh_pair_plan(ctx, g, &vj, &vk, sn.off, sj.off, sk.off, totals));
-        KSH_LOCAL(k, alloc_keys(ctx, g, totals[0], &sn));
-        KSH_LOCAL(k, alloc_keys(ctx, g, totals[1], &sj));
-        KSH_LOCAL(k, alloc_keys(ctx, g, totals[2], &sk));
-        KSH_LOCAL(k, ksh_pair_write(ctx, g, &vj, &vk, sn.keys, sj.keys, sk.keys));
-        if (!alive(k)) {
-          free_set(ctx, &sn);
-          free_set(ctx, &sj);
-          free_set(ctx, &sk);
-        }
-      }
-      if (src != ex) retire_set(&pulled); else retire_set(&k->sets[size_t(kk)]);
-      retire_set(&k->sets[size_t(j)]);
-      k->sets[size_t(j)] = sj;
-      k->sets[size_t(kk)] = sk;
-      k->sets[size_t(n)] = sn;
-      int64_t* row = my_rows.data() + my_rows.size() - 5;
-      row[3] = original_size;
-      row[4] = sn.n + sj.n + sk.n - original_size;
-    } else if (rank == src) {
-      PhaseTimer pt(k, 2);
-      KSH_TRY(send_set(k, k->sets[size_t(kk)], ex));
-      KSH_HIP(hipStreamSynchronize(ctx->stream));  // the keys have left before their buffer is reused
-      retire_set(&k->sets[size_t(kk)]);
+    {
+      const MergeTask task{i, j, kk, n, ex, src, my_rows.size() / 5 - 1};
+      if (defer_merges) merge_tasks.push_back(task);
+      else KSH_TRY(run_merge(task));
     }
     for (int node : {j, kk}) {
       KssCompact& c = k->compacts[size_t(node)];
@@ -1305,8 +1369,10 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
     bool stop = false;
     KSH_TRY(resolve(&pend, &stop));
     stopped = stopped || stop;
+    if (stop) merge_tasks.clear();  // (they belong to the interval that was just undone; the same decision on every rank)
   }
   (void)stopped;
+  KSH_TRY(run_deferred_merges());
   KSH_TRY(total_spss_weight_now(&k->final_spss_weight));
 
   // the trace: every row from the rank that ran its merge

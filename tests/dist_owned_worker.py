@@ -1,6 +1,8 @@
 """Worker of tests/test_gpu_kmer_set_set.py::test_owned_build: one of N ranks (all on GPU 0; gloo
 through host memory is the transport, because RCCL refuses several ranks on one device) building
-one KmerSetSet with ksh_kss_build_owned.  Every input is decoded by its owner only; every rank
+one KmerSetSet with ksh_kss_build_owned.  KSH_OWNED_BACKEND=nccl (::test_owned_build_rccl_two_gpus, on a
+box with two GPUs or more): one GPU per rank and the library's own RCCL transport on device buffers --
+ncclSend / ncclRecv pairs, the side communicator, the deferred all-gathers.  Every input is decoded by its owner only; every rank
 checks the replicated state (trace, checkpoints, DAG, sizes) against the oracle, and the rank that
 owns a node checks its set and its SPSS strings; nobody else can read them."""
 import json
@@ -22,10 +24,19 @@ def main():
     k, n, kb, n_sets, size, seed = (int(x) for x in sys.argv[1:7])
     layout = sys.argv[7] if len(sys.argv) > 7 else "block"
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-    dist.init_process_group("gloo")
+    backend = os.environ.get("KSH_OWNED_BACKEND", "gloo")
+    if backend == "nccl":
+        local = int(os.environ.get("LOCAL_RANK", "0"))
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        coll_dev = torch.device("cuda", local)
+    else:
+        local = 0
+        dist.init_process_group("gloo")
+        torch.cuda.set_device(0)
+        coll_dev = "cpu"
     rank, world = dist.get_rank(), dist.get_world_size()
-    torch.cuda.set_device(0)
-    ctx = capi.Context(0)
+    ctx = capi.Context(local)
     sets = synth.phylogeny_sets(k, n_sets, size, seed=seed)
     osets = [ol.Set.from_kmers(k, n, kb, s) for s in sets]
     ocompacts = [s.compact() for s in osets]
@@ -37,7 +48,10 @@ def main():
     owners = capi.block_owners(n_sets, world) if layout == "block" else [i % world for i in range(n_sets)]
     dcompacts = [capi.DeviceSpss.from_strings(g, c.strings(), ctx.device) if owners[i] == rank else None
                  for i, c in enumerate(ocompacts)]
-    dkss = capi.OwnedKmerSetSet(ctx, dcompacts, ids, dist, "cpu", owners=owners)
+    dkss = capi.OwnedKmerSetSet(ctx, dcompacts, ids, dist, coll_dev, owners=owners)
+    transport = dkss.comm.kind
+    ranks_seen = dkss.comm.ranks_seen()
+    assert ranks_seen == world, (ranks_seen, world)
 
     it, cp, imp = dkss.trace()
     assert np.array_equal(it, okss.iterations()), (it, okss.iterations())
@@ -69,17 +83,19 @@ def main():
     # Get(i) through the gathered (size, hash) table == the input, for every input, on every rank
     for i in range(n_sets):
         assert dkss.get_size_and_hash(i) == (osets[i].size(), osets[i].hash()), i
-    mine = torch.zeros(okss.size(), dtype=torch.int64)
+    mine = torch.zeros(okss.size(), dtype=torch.int64, device=coll_dev)
     mine[held] = 1
     dist.all_reduce(mine)
     assert int(mine.min()) == 1 and int(mine.max()) == 1      # every node lives on exactly one rank
     cs = dkss.comm_stats()
     vec = torch.tensor([dkss.stats()["n_encodes"], cs["p2p_sets"], cs["p2p_bytes_sent"], cs["p2p_bytes_received"],
-                        len(held), cs["checks_deferred"], cs["rollbacks"], cs["sets_migrated"]], dtype=torch.int64)
+                        len(held), cs["checks_deferred"], cs["rollbacks"], cs["sets_migrated"]], dtype=torch.int64,
+                       device=coll_dev)
     allv = [torch.zeros_like(vec) for _ in range(world)]
     dist.all_gather(allv, vec)
     if rank == 0:
-        print(json.dumps({"ok": True, "iterations": int(len(it)), "nodes": okss.size(),
+        print(json.dumps({"ok": True, "transport": transport, "ranks_seen": ranks_seen,
+                          "iterations": int(len(it)), "nodes": okss.size(),
                           "encodes_per_rank": [int(v[0]) for v in allv],
                           "sets_sent_per_rank": [int(v[1]) for v in allv],
                           "bytes_sent": sum(int(v[2]) for v in allv), "bytes_received": sum(int(v[3]) for v in allv),

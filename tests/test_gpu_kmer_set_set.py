@@ -189,6 +189,39 @@ def test_owned_build(gpu, world, shape, layout):
         assert res["rollbacks"] == 1      # this family stops at a check: the interval after it was undone
 
 
+@pytest.mark.parametrize("layout", ["striped", "block"])
+def test_owned_build_rccl_two_gpus(gpu, layout):
+    """The first thing to run on a box with more than one GPU: the owner-sharded build with ONE
+    GPU PER RANK over the library's RCCL transport -- ncclAllGather on the context's stream, ungrouped ncclSend /
+    ncclRecv pairs for the sets that travel, the second communicator for the deferred check exchanges --
+    against the oracle, exactly as test_owned_build does over gloo.  Skips on a one-GPU box (where RCCL
+    refuses two ranks on one device): nobody has to remember to run it the day a multi-GPU node appears."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    import torch
+
+    n_gpus = torch.cuda.device_count()
+    if n_gpus < 2:
+        pytest.skip("needs two GPUs (this box has %d): RCCL with more than one rank stays unverified" % n_gpus)
+    world = min(n_gpus, 4)
+    here = os.path.dirname(os.path.abspath(__file__))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0", KSH_OWNED_BACKEND="nccl")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(29611 + (layout == "block")),
+           os.path.join(here, "dist_owned_worker.py"), "23", "14", "4", "8", "30000", "5", layout]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    res = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
+    assert res["ok"] and res["transport"] == "rccl" and res["ranks_seen"] == world and res["iterations"] > 0
+    assert sum(res["nodes_per_rank"]) == res["nodes"] and res["bytes_sent"] == res["bytes_received"]
+    if layout == "striped":
+        assert sum(res["sets_sent_per_rank"]) > 0
+    assert res["checks_deferred"] == res["checks"] > 0
+
+
 def test_owned_build_eight_ranks(gpu):
     """The owner-sharded build at the rank count it is designed for: 8 ranks, 64 sets of 2 x 10^5 k-mers
     (k = 23), block owners (owners[i] = i * 8 // 64) -- the deal of a check's encodes over eight ranks, the
@@ -241,24 +274,32 @@ def test_owned_build_failure_reaches_every_rank(gpu, inject):
             assert "rank %d failed" % failed in m, res
 
 
-def test_owned_build_sharded_weights(gpu):
-    """KSH_OWNED_WEIGHTS=sharded: the weight tables dealt out by pair list, one all-gather of per-pair int64
-    weights per iteration (lib/core/kmer_set_set.h:205-218,385-425; the collective north_star names) -- the
-    same trace, checkpoints, DAG and nodes as the oracle, by the other control mode.  4 rank threads."""
+@pytest.mark.parametrize("mode", ["sharded", "replicated", "sharded+inline-merges"])
+def test_owned_build_control_modes(gpu, mode):
+    """The two control modes and the two merge schedules of the owner-sharded build, each against the oracle (4 rank
+    threads).  "sharded" (the default): the weight tables dealt out by pair list, one all-gather of per-pair
+    int64 weights per iteration (lib/core/kmer_set_set.h:205-218,385-425; the collective north_star names), the
+    full-size merges deferred to the end of their interval.  "replicated": every rank weighs its replica of the
+    samples, no exchange.  "inline-merges": every merge in its iteration, as before round 4."""
     import json
     import os
     import subprocess
     import sys
 
     here = os.path.dirname(os.path.abspath(__file__))
-    env = dict(os.environ, KSH_OWNED_WEIGHTS="sharded")
+    env = dict(os.environ, KSH_OWNED_WEIGHTS=mode.split("+")[0])
+    if "inline" in mode:
+        env["KSH_OWNED_MERGES"] = "inline"
     cmd = [sys.executable, os.path.join(here, "owned_threads_worker.py"), "23", "14", "4", "16", "40000", "9", "4",
            "block"]
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     res = json.loads([x for x in r.stdout.splitlines() if x.startswith("{")][-1])
     assert res["ok"] and res["iterations"] > 0
-    assert res["weight_gathers"] >= res["iterations"] + 1      # the initial table + one per iteration (+ an undone interval's)
+    if mode == "replicated":
+        assert res["weight_gathers"] == 0
+    else:
+        assert res["weight_gathers"] >= res["iterations"] + 1  # the initial table + one per iteration (+ an undone interval's)
 
 
 def test_owned_build_without_lookahead(gpu, monkeypatch):

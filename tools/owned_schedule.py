@@ -25,6 +25,9 @@ def main():
     ap.add_argument("--link-gbs", type=float, default=64.0, help="one xGMI link, one direction, GB/s")
     ap.add_argument("--allgather-us", type=float, default=40.0,
                     help="one small all-gather of int64 over RCCL incl. its host staging, microseconds (assumed)")
+    ap.add_argument("--sample-merge-us", type=float, default=150.0,
+                    help="the merge of an iteration's two 2 %% samples, which every rank runs for itself (plan with its "
+                         "read-back + write; assumed -- the single-GPU build has no counterpart to measure)")
     args = ap.parse_args()
     d = json.load(open(args.trace))
     n0, key_bytes, world = d["n_inputs"], d["key_bytes"], args.gpus
@@ -42,9 +45,16 @@ def main():
     t_p2p = t_merge = 0.0
     sets_moved = bytes_moved = 0
     per_check = []
+    # the full-size merges deferred to the end of their interval (what the library does since round 4): every rank
+    # works its part of the interval's list off in iteration order; a receiver's merge waits for the sender to get
+    # there.  Per-rank clocks inside an interval, the interval costs the latest one.
+    t_merge_deferred = 0.0
+    clock = [0.0] * world
 
     def check():
-        nonlocal t_barrier
+        nonlocal t_barrier, t_merge_deferred, clock
+        t_merge_deferred += max(clock)
+        clock = [0.0] * world
         load = [0.0] * world
         for node in stale:
             load[owner[node]] += sizes_now[node] * enc_rate
@@ -66,7 +76,11 @@ def main():
             t_p2p += nbytes / (args.link_gbs * 1e9)
             sets_moved += 1
             bytes_moved += nbytes
+            arrive = clock[src] + nbytes / (args.link_gbs * 1e9)
+            clock[src] = arrive
+            clock[ex] = max(clock[ex], arrive)
         t_merge += original * merge_rate
+        clock[ex] += original * merge_rate
         nn, nj, nk = triples[it]
         sizes_now[j], sizes_now[k] = nj, nk
         sizes_now.append(nn)
@@ -179,6 +193,17 @@ def main():
     out["allgather_us_assumed"] = args.allgather_us
     out["expected_total_sharded_control_s"] = decode + control_sharded + t_merge + t_p2p + t_impl
     out["speedup_sharded_control"] = t1 / out["expected_total_sharded_control_s"]
+    # ---- the same with the full-size merges deferred to the end of their interval (KSH_OWNED_MERGES, the default
+    # since round 4): the all-gather of an iteration no longer sits behind anybody's merge; an interval's merges run
+    # side by side on their executors (transfers included: merges_deferred_s).  Every rank still runs the merge of
+    # the iteration's two SAMPLES for itself (sample_merge_us each, assumed), in both control modes.
+    sample_merges = len(rows) * args.sample_merge_us * 1e-6
+    out["sample_merges_s"] = sample_merges
+    out["merges_deferred_s"] = t_merge_deferred
+    out["expected_total_replicated_deferred_s"] = decode + control + sample_merges + t_merge_deferred + t_impl
+    out["speedup_replicated_deferred"] = t1 / out["expected_total_replicated_deferred_s"]
+    out["expected_total_sharded_deferred_s"] = decode + control_sharded + sample_merges + t_merge_deferred + t_impl
+    out["speedup_sharded_deferred"] = t1 / out["expected_total_sharded_deferred_s"]
     out["note"] = "arithmetic over the measured single-GPU phases and merge sequence: modelled, not measured"
     print(json.dumps(out, indent=1))
 

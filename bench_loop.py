@@ -30,6 +30,11 @@ def main():
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--max-iterations", type=int, default=-1)
     ap.add_argument("--lanes", type=int, default=0, help="ksh_ctx_set_lanes (0 = default, 1 = one stream)")
+    ap.add_argument("--repeats", default="",
+                    help="SEGMENTS,COPIES: a repeat-rich family -- the ancestor genome carries SEGMENTS stretches of "
+                         "50..500 bases copied to COPIES other places each (synth.plant_repeats): branching unitig "
+                         "graphs, deep matchings, loop cuts (lib/core/spss.h:1445-1644) instead of a few long unitigs")
+    ap.add_argument("--rate", type=float, default=0.002, help="substitutions per base and tree edge")
     ap.add_argument("--cpu-iterations", type=int, default=0,
                     help="also time the oracle on the first I iterations (0 = skip)")
     ap.add_argument("--cpu-size", type=float, default=0, help="set size for the CPU leg (default: --size)")
@@ -77,10 +82,16 @@ def main():
     ctx.set_lanes(args.lanes)
     dev = ctx.device
     t0 = time.perf_counter()
-    kmers = synth_torch.phylogeny_sets(k, n_sets, size, args.seed, dev)
+    repeats = tuple(int(x) for x in args.repeats.split(",")) if args.repeats else None
+    kmers = synth_torch.phylogeny_sets(k, n_sets, size, args.seed, dev, rate=args.rate, repeats=repeats)
     compacts = []
+    graph = None
     for km in kmers:
         compacts.append(ctx.spss_encode(synth_torch.device_set(g, km), mode=0))
+        if graph is None:   # the shape of the first input's unitig graph
+            es = ctx.spss_encode_stats()
+            graph = {"kmers": int(km.numel()), "unitigs": es["unitigs"], "strings": es["strings"],
+                     "matching_rounds": es["rounds"], "routes": sorted(ctx.spss_encode_routes())}
     sizes = [int(km.numel()) for km in kmers]
     del kmers
     torch.cuda.synchronize()
@@ -138,6 +149,11 @@ def main():
         "scaling": "strong",
         "encodes_per_rank": encodes,
         "phase_seconds": st["phase_seconds"],
+        "encodes": {"n": st["n_encodes"], "kmers": st["n_encoded_kmers"],
+                    "ns_per_kmer": st["phase_seconds"]["encodes"] * 1e9 / max(st["n_encoded_kmers"], 1)},
+        "first_input_graph": graph,
+        "family": "phylogeny, rate %g per base and edge%s" % (args.rate, (", planted repeats: %d segments x %d copies"
+                                                                         % repeats) if repeats else ""),
         "first_build_wall_s": first_wall,
         "config": {"workload": "%d canonical k=%d sets of %d k-mers, full KmerSetSet loop" % (n_sets, k, size),
                    "input_build_s": t_inputs,

@@ -85,8 +85,37 @@ def mutate(bases, rate, edge_seed):
     return out
 
 
-def phylogeny_genomes(n_sets, length, seed, rate=0.002):
+def plant_repeats(bases, n_segments, copies, seed, min_len=50, max_len=500):
+    """A repeat-rich ancestor: `n_segments` source stretches of min_len .. max_len bases (short ones likelier: the
+    length is min_len + (max_len - min_len) * u^3) are each copied to `copies` other places of the genome, later
+    copies over earlier ones where they meet.  Every copy puts the segment's k-mers at one more locus, so the
+    compacted de Bruijn graph branches at both ends of every copy: about 2 * n_segments * copies more unitigs and
+    junctions with several candidate edges for the greedy path cover (lib/core/spss.h:1445-1644), which a random
+    genome hardly has.  Counter-based hashes of (seed, segment, copy): the torch twin plants the same bases."""
+    n = bases.size
+    out = bases.copy()
+    seg = np.arange(n_segments, dtype=U)
+    with np.errstate(over="ignore"):
+        h0 = mix64(mix64(U(seed) * U(0xA24BAED4963EE407) + U(7)) + seg * U(3))
+        h1 = mix64(h0 + U(1))
+    u = (h1 >> U(11)).astype(np.float64) / float(1 << 53)
+    length = (min_len + (max_len - min_len) * u ** 3).astype(np.int64)
+    src = (h0 % U(max(1, n - max_len))).astype(np.int64)
+    for c in range(copies):
+        with np.errstate(over="ignore"):
+            dst = (mix64(h0 + U(0x9E3779B97F4A7C15) * U(c + 2)) % U(max(1, n - max_len))).astype(np.int64)
+        # all of a round's copies read the genome as it was BEFORE the planting (sources are never rewritten
+        # mid-round), and land in ascending segment order
+        at = np.repeat(dst - np.cumsum(length) + length, length) + np.arange(int(length.sum()))
+        frm = np.repeat(src - np.cumsum(length) + length, length) + np.arange(int(length.sum()))
+        out[at] = bases[frm]
+    return out
+
+
+def phylogeny_genomes(n_sets, length, seed, rate=0.002, repeats=None):
     genomes = [random_genome(length, 0x5EED0000 + seed)]
+    if repeats:
+        genomes[0] = plant_repeats(genomes[0], repeats[0], repeats[1], seed)
     edge = 0
     while len(genomes) < n_sets:
         nxt = []
@@ -98,10 +127,11 @@ def phylogeny_genomes(n_sets, length, seed, rate=0.002):
     return genomes[:n_sets]
 
 
-def phylogeny_sets(k, n_sets, size, seed, rate=0.002):
-    """n_sets sorted arrays of canonical k-mers (uint64); |S_i| a little under `size`."""
+def phylogeny_sets(k, n_sets, size, seed, rate=0.002, repeats=None):
+    """n_sets sorted arrays of canonical k-mers (uint64); |S_i| a little under `size`.  repeats = (segments,
+    copies): the ancestor genome carries planted repeats (plant_repeats)."""
     return [canonical_set_of_bases(g, k)
-            for g in phylogeny_genomes(n_sets, size + k - 1, seed, rate)]
+            for g in phylogeny_genomes(n_sets, size + k - 1, seed, rate, repeats)]
 
 
 def genome_with_tips(k, size, seed, every=400):

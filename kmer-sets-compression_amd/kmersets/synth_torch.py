@@ -71,9 +71,44 @@ def canonical_set_of_bases(bases, k):
     return torch.unique_consecutive(out)
 
 
-def phylogeny_sets(k, n_sets, size, seed, device, rate=0.002):
+def plant_repeats(bases, n_segments, copies, seed, min_len=50, max_len=500):
+    """synth.plant_repeats on the device: the same bases."""
+    dev = bases.device
+    n = bases.numel()
+    seg = torch.arange(n_segments, dtype=torch.int64, device=dev)
+    h0 = mix64(seg * 3 + _c(_mix64_scalar((seed * 0xA24BAED4963EE407 + 7) & _MASK64)))
+    h1 = mix64(h0 + 1)
+    u = lsr(h1, 11).double() / float(1 << 53)
+    length = (min_len + (max_len - min_len) * u ** 3).to(torch.int64)
+    span = max(1, n - max_len)
+
+    def umod(x, m):          # x as an unsigned 64-bit number, modulo m (m < 2^62)
+        return (lsr(x, 1) % m * 2 + (x & 1)) % m
+
+    src = umod(h0, span)
+    out = bases.clone()
+    total = int(length.sum().item())
+    within = torch.arange(total, dtype=torch.int64, device=dev)
+    start = torch.cumsum(length, 0) - length
+    frm = torch.repeat_interleave(src - start, length) + within
+    for c in range(copies):
+        dst = umod(mix64(h0 + _c((0x9E3779B97F4A7C15 * (c + 2)) & _MASK64)), span)
+        at = torch.repeat_interleave(dst - start, length) + within
+        # (numpy's out[at] = v keeps the LAST write to an index; index_put_ on the device keeps an arbitrary
+        # one: write in ascending position order through a stable sort and keep each index's last writer)
+        order = torch.argsort(at, stable=True)
+        at_s, v_s = at[order], bases[frm][order]
+        last = torch.ones_like(at_s, dtype=torch.bool)
+        last[:-1] = at_s[1:] != at_s[:-1]
+        out[at_s[last]] = v_s[last]
+    return out
+
+
+def phylogeny_sets(k, n_sets, size, seed, device, rate=0.002, repeats=None):
     """Same sets as synth.phylogeny_sets, as sorted int64 tensors on `device`."""
     genomes = [random_genome(size + k - 1, 0x5EED0000 + seed, device)]
+    if repeats:
+        genomes[0] = plant_repeats(genomes[0], repeats[0], repeats[1], seed)
     edge = 0
     while len(genomes) < n_sets:
         nxt = []

@@ -98,6 +98,21 @@ def test_loop_lanes(gpu, lanes):
         c.close()
 
 
+def test_loop_repeat_rich_family(ctx):
+    """The whole loop on a repeat-rich family (bench_loop.py --repeats): every node's strings, the trace and the
+    checkpoints against the oracle where the encodes are the expensive, branching kind."""
+    k, n, kb = 23, 14, 4
+    sets = synth.phylogeny_sets(k, 6, 120_000, seed=37, rate=0.003, repeats=(500, 6))
+    osets = [ol.Set.from_kmers(k, n, kb, s) for s in sets]
+    ocompacts = [s.compact() for s in osets]
+    ids = synth.sample_bucket_ids(n, seed=38)
+    okss = ol.KmerSetSet(ocompacts, ids)
+    dcompacts = [capi.DeviceSpss.from_strings(capi.geom(k, n), c.strings(), ctx.device) for c in ocompacts]
+    dkss = capi.DeviceKmerSetSet(ctx, dcompacts, ids)
+    assert compare(sets, osets, okss, dkss) > 0
+    dkss.close()
+
+
 def test_loop_truncated_and_no_merge(ctx):
     k, n, kb = 23, 14, 4
     sets, osets, okss, dkss = build_both(ctx, k, n, kb, 6, 20000, 9, max_iterations=2)

@@ -14,8 +14,9 @@
  * Device layout of a k-mer set (replaces 2^N absl::flat_hash_set<KeyType>,
  * lib/core/kmer_set.h:247-251):
  *     offsets : int64[2^N + 1]   bucket b holds keys[offsets[b] .. offsets[b+1])
- *     keys    : u32 or u64       low (2K - N) bits of the k-mer, ascending inside
- *                                a bucket; key_bytes = 4 when 2K-N <= 32, else 8
+ *     keys    : u16, u32 or u64  low (2K - N) bits of the k-mer, ascending inside a bucket;
+ *                                key_bytes = 2 when 2K-N <= 16 (the reference's (15, 14, uint16_t)),
+ *                                4 when 2K-N <= 32, else 8
  * i.e. the set is one ascending array of 2K-bit k-mers with a bucket index.
  *
  * All pointers named d_* are device pointers on the context's GPU.  Functions
@@ -47,7 +48,7 @@ typedef struct ksh_ctx ksh_ctx;
 typedef struct ksh_geom {
   int32_t k;             /* k-mer length, 2 <= k <= 31                         */
   int32_t n_bucket_bits; /* N: top N bits of the 2K-bit k-mer pick the bucket  */
-  int32_t key_bytes;     /* device key width: 4 or 8                           */
+  int32_t key_bytes;     /* device key width: 2, 4 or 8 (>= ceil((2k - N) / 8)) */
   int32_t reserved;
 } ksh_geom;
 
@@ -120,6 +121,12 @@ int ksh_ctx_timing_units(ksh_ctx* ctx, int kind, int64_t* units);
  * ksh_ctx_timing_wall is the length of the UNION of a kind's timed spans over all lanes, i.e. the wall time
  * during which at least one launch of the kind was running. */
 int ksh_ctx_set_lanes(ksh_ctx* ctx, int n_lanes);
+/* Device memory behind a context, bytes: stats = { pooled buffers handed out and not yet given back (the sets,
+ * containers and samples of a KmerSetSet live here), the maximum of that since the context was made or the peak was
+ * last reset, pooled buffers cached for reuse, the context's own scratch (encode / decode / text slots, arena, pair
+ * plan), everything its helper lanes hold, number of helper lanes }.  reset_peak != 0: the peak restarts at the
+ * current value.  (DESIGN.md 7.2's memory table is checked against these in tests/test_gpu_full_size.py.) */
+int ksh_ctx_mem_stats(ksh_ctx* ctx, int64_t stats[6], int reset_peak);
 int ksh_ctx_timing_wall(ksh_ctx* ctx, int kind, float* wall_ms);
 
 /* ---- KmerSet::Size / Hash  (lib/core/kmer_set.h:65-71, :224-244) --------------------- */
@@ -219,7 +226,11 @@ int ksh_spss_size(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int64
  * plan : bucket histogram -> d_offsets (int64[2^N + 1]); n_keys = k-mer positions
  *        (an upper bound on the set size: repeated k-mers collapse in write).
  * write: scatter + per-bucket sort, duplicates dropped; d_keys holds n_keys(plan)
- *        keys; d_offsets is rewritten if duplicates were dropped; n_keys = set size. */
+ *        keys; d_offsets is rewritten if duplicates were dropped; n_keys = set size.
+ * Limit: n_bucket_bits <= 14 (KSH_INVALID_ARGUMENT beyond): the counting pass keeps one 4-byte counter per
+ * bucket in a workgroup's 64 KB of LDS.  The reference's template takes any N (lib/core/kmer_set.h:20-31); its
+ * CLIs instantiate N = 10 and 14 (src/kmerset-multiple-compress.cc:156-157).  The same limit holds for
+ * ksh_kmer_count_write and for everything that decodes (ksh_kss_build*, ksh_kss_get, ksh_spss_from_text_*). */
 int ksh_spss_decode_plan(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int canonical,
                          int64_t* d_offsets, int64_t* n_keys);
 int ksh_spss_decode_write(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int canonical,

@@ -105,6 +105,8 @@ int pool_alloc(ksh_ctx* ctx, size_t bytes, void** out) {
   if (it != ctx->pool_free_blocks.end() && it->first <= want + want / 4) {
     *out = it->second;
     ctx->pool_cached_bytes -= it->first;
+    ctx->pool_live_bytes += it->first;
+    ctx->pool_peak_bytes = std::max(ctx->pool_peak_bytes, ctx->pool_live_bytes);
     ctx->pool_free_blocks.erase(it);
     return KSH_OK;
   }
@@ -120,6 +122,8 @@ int pool_alloc(ksh_ctx* ctx, size_t bytes, void** out) {
       return fail(KSH_INTERNAL, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
   }
   ctx->pool_sizes[*out] = want;
+  ctx->pool_live_bytes += want;
+  ctx->pool_peak_bytes = std::max(ctx->pool_peak_bytes, ctx->pool_live_bytes);
   return KSH_OK;
 }
 
@@ -133,6 +137,7 @@ void pool_free(ksh_ctx* ctx, void* p) {
   }
   ctx->pool_free_blocks.emplace(it->second, p);
   ctx->pool_cached_bytes += it->second;
+  ctx->pool_live_bytes -= std::min(ctx->pool_live_bytes, it->second);
   // keep the cache bounded: drop the largest blocks beyond 96 GiB
   while (ctx->pool_cached_bytes > (size_t(96) << 30) && !ctx->pool_free_blocks.empty()) {
     auto last = std::prev(ctx->pool_free_blocks.end());
@@ -738,6 +743,24 @@ int ksh_ctx_enable_timing(ksh_ctx* ctx, int enable) {
   ctx->timing = enable > 0;
   ctx->timing_stride = enable > 0 ? enable : 1;
   return KSH_OK;  // (the lanes take the setting over whenever they are used)
+}
+
+static size_t scratch_bytes_of(const ksh_ctx* c) {
+  return c->slot_bytes[0] + c->slot_bytes[1] + c->slot_bytes[2] + c->arena_bytes + c->plan_bytes;
+}
+
+int ksh_ctx_mem_stats(ksh_ctx* ctx, int64_t stats[6], int reset_peak) {
+  if (!ctx || !stats) return fail(KSH_INVALID_ARGUMENT, "NULL argument");
+  std::lock_guard<std::mutex> lock(ctx->pool_mu);
+  stats[0] = int64_t(ctx->pool_live_bytes);
+  stats[1] = int64_t(ctx->pool_peak_bytes);
+  stats[2] = int64_t(ctx->pool_cached_bytes);
+  stats[3] = int64_t(scratch_bytes_of(ctx));
+  stats[4] = 0;
+  for (const ksh_ctx* lane : ctx->lanes) stats[4] += int64_t(scratch_bytes_of(lane) + lane->pool_live_bytes + lane->pool_cached_bytes);
+  stats[5] = int64_t(ctx->lanes.size());
+  if (reset_peak) ctx->pool_peak_bytes = ctx->pool_live_bytes;
+  return KSH_OK;
 }
 
 int ksh_ctx_set_lanes(ksh_ctx* ctx, int n_lanes) {

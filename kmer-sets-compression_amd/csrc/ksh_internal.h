@@ -108,6 +108,7 @@ struct ksh_ctx {
   std::multimap<size_t, void*> pool_free_blocks;
   std::unordered_map<void*, size_t> pool_sizes;
   size_t pool_cached_bytes = 0;
+  size_t pool_live_bytes = 0, pool_peak_bytes = 0;  // handed out and not yet given back; its maximum (ksh_ctx_mem_stats)
   // test hook (KSH_FAIL_INJECT, ksh_kss_build_owned): once inject_skip allocations of at least
   // inject_min_bytes have succeeded, every further one fails; -1: off
   long long inject_skip = -1;

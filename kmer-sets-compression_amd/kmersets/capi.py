@@ -109,6 +109,7 @@ def lib():
         "ksh_ctx_timing_read": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float), C.POINTER(i64)]),
         "ksh_ctx_timing_units": (C.c_int, [vp, C.c_int, C.POINTER(i64)]),
         "ksh_ctx_set_lanes": (C.c_int, [vp, C.c_int]),
+        "ksh_ctx_mem_stats": (C.c_int, [vp, C.POINTER(i64), C.c_int]),
         "ksh_ctx_timing_wall": (C.c_int, [vp, C.c_int, C.POINTER(C.c_float)]),
         "ksh_set_hash": (C.c_int, [vp, GP, SP, C.POINTER(C.c_uint64)]),
         "ksh_dsu_components": (C.c_int, [vp, i64, vp, vp, i64, vp]),
@@ -397,6 +398,13 @@ class Context:
         ms = C.c_float()
         check(lib().ksh_ctx_timing_wall(self.h, kind, C.byref(ms)))
         return ms.value
+
+    def mem_stats(self, reset_peak=False):
+        """Device bytes behind the context: pooled buffers in use, their peak, cached, own scratch, lanes' total."""
+        st = (C.c_int64 * 6)()
+        check(lib().ksh_ctx_mem_stats(self.h, st, int(bool(reset_peak))))
+        return {"pool_live": st[0], "pool_peak": st[1], "pool_cached": st[2], "scratch": st[3], "lanes": st[4],
+                "n_lanes": st[5]}
 
     def set_lanes(self, n):
         """Independent jobs of one call (a check's encodes, the inputs' decodes) on up to n streams at once; 1: one

@@ -100,5 +100,24 @@ def test_config4_64x1e8_k23(ctx):
 
 
 def test_k31_8x5e8(ctx):
+    """configs[4]'s geometry (k = 31, 8-byte keys, 5 x 10^8 k-mers per set) at eight sets -- a quarter of one
+    rank's 32-set share of the 256 (the full share, 128 GB of resident keys, is the owner-sharded build's; with
+    its encode scratch and the 20 GB of samples it has no room for a second build's warm pool on one 288 GB GPU,
+    DESIGN.md 7.2) -- and the memory rows of that table checked against the context's counters: the pooled
+    buffers (sets, containers, a merge's three results) and the encode scratch per lane."""
+    before = ctx.mem_stats(reset_peak=True)
     n_proc, weight, packed, lens, nodes, it, cp = _loop_properties(ctx, 31, 8, int(5e8), seed=5)
     assert len(it) >= 4 and nodes > 8
+    m = ctx.mem_stats()
+    n, key = 5e8, 8
+    sets_bytes = 8 * n * key                         # the resident inputs: 32 GB
+    # peak of the pooled buffers: the resident sets, the three results of the largest merge beside its two inputs
+    # (<= 3 more sets), the nodes' SPSS containers (< 0.3 B per k-mer), the decode's intermediate keys (10 B per
+    # k-mer of one input per lane) -- with the pool's <= 12.5 % rounding
+    bound = (sets_bytes + 3 * n * key + 0.3 * 8 * n + 3 * 10 * n) * 1.125 + before["pool_live"]
+    assert m["pool_peak"] <= bound, (m, bound)
+    assert m["pool_peak"] >= sets_bytes              # (the counter does count: the inputs alone are 32 GB)
+    # encode scratch of one lane: DESIGN.md 2's ~70 B per k-mer + fine index, with slot_reserve's 12.5 % to spare
+    per_lane = 80 * n
+    assert m["scratch"] <= per_lane + (2 << 30), m
+    assert m["lanes"] <= m["n_lanes"] * (per_lane + (8 << 30)), m

@@ -552,6 +552,13 @@ __device__ int block_unique_write(const KeyT* __restrict__ lds, int cnt, KeyT* _
   for (int w = 0; w < kSortThreads / 64; w++) total += sh->wave_cnt[w];
   if (threadIdx.x == 0 && below)
     for (int w = 0; w < kSortThreads / 64; w++) *below += sh->wave_below[w];
+  if (total == cnt) {
+    // nothing dropped (every real SPSS: no k-mer twice): the sorted range goes out as it lies, in whole lines --
+    // from the loop below a wave's stores are `per` keys apart
+    for (int i = threadIdx.x; i < cnt; i += kSortThreads) dst[i] = lds[i];
+    __syncthreads();
+    return total;
+  }
   for (int i = c0; i < c1; i++) {
     if (i == 0 || lds[i] != lds[i - 1]) {
       bool keep = true;

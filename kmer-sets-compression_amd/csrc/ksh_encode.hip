@@ -925,6 +925,10 @@ __device__ __forceinline__ int lds_lower_bound(const KeyT* a, int lo, int hi, Ke
 __device__ unsigned long long g_fwd_dbg[8];
 
 
+// (Measured and dropped, round 4: a hybrid -- the Next window staged and searched in LDS, the four Prev(x, c) probed in
+// global memory through the fine index (their targets are as local as the windows: neighbouring threads hit the
+// same lines), so that the LDS pipeline carries 11 of the 39 dependent reads and the vector-memory pipeline the
+// rest: 2.60 ms per 10^8 against 1.85.)
 template <typename KeyT, int kFwdCapNext = FwdCfg<KeyT>::kCapNext>
 __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_fwd_staged(DevSet<KeyT> set, const int64_t* __restrict__ bounds,
                                                               const uint32_t* __restrict__ rc0,

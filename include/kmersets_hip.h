@@ -114,9 +114,11 @@ int ksh_ctx_timing_units(ksh_ctx* ctx, int kind, int64_t* units);
  * reference runs on its thread pool too) -- run them on up to n_lanes HIP streams of the context's GPU at once,
  * each from a host thread of its own with scratch of its own (one job's LDS-bound probe kernels then overlap
  * another's walks, which wait on HBM, and nobody's host round trips leave the GPU idle); results are the same,
- * node ids being fixed before the jobs start.  The helper lanes live inside the context (created on first use,
- * mapped scratch kept, freed by ksh_ctx_destroy) and are left out when their scratch does not fit the free
- * memory.  n_lanes = 1: everything on the context's stream, as before; 0: the default (KSH_LANES, else 3).
+ * node ids being fixed before the jobs start.  The lanes are helper contexts that live inside the context
+ * (created on first use, mapped scratch kept, freed by ksh_ctx_destroy); every job runs on one of them and
+ * allocates its result from the context's own pool, which only hands out while jobs run.  Lanes whose scratch
+ * does not fit the free memory are left out; with fewer than two the jobs run on the context's stream, one
+ * after the other.  n_lanes = 1: everything on the context's stream, as before; 0: the default (KSH_LANES, else 3).
  * With lanes, ksh_ctx_timing_read / _units sum over the lanes (stream time: spans of different lanes overlap);
  * ksh_ctx_timing_wall is the length of the UNION of a kind's timed spans over all lanes, i.e. the wall time
  * during which at least one launch of the kind was running. */

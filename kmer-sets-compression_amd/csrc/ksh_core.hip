@@ -195,8 +195,16 @@ int run_on_lanes(ksh_ctx* ctx, const std::vector<size_t>& order, size_t need_byt
   const int wanted = ctx->lane_parent ? 1 : (ctx->lanes_wanted > 0 ? ctx->lanes_wanted : lanes_default());
   const size_t n_lanes = std::min<size_t>(size_t(wanted), order.size());
   KSH_HIP(hipStreamSynchronize(ctx->stream));  // what the jobs read was written on this stream
-  std::vector<ksh_ctx*> use{ctx};
-  for (size_t l = 1; l < n_lanes; l++) {
+  // With two lanes or more EVERY job runs on a helper context, the calling thread's too: the context's own pool
+  // hands out the jobs' results, from several threads, and must not at the same time serve a job's short-lived
+  // scratch -- a block that a job on this context's stream gave back with kernels still queued behind it (the
+  // decode's intermediate keys, an encode's unitig block: fine on ONE stream, where the next user queues up
+  // behind them) would be handed to another lane as its result while those kernels run.  (Found the hard way:
+  // tools/scale_sweep.py, (19, 10) sets of 2.7 x 10^7 k-mers -- oversize buckets, so the bucket sort's scratch
+  // copy is the size of a set's keys -- faulted the GPU)  During a run the context's pool only
+  // hands out; what it holds was last used before the drain above or on a lane drained at the end of a run.
+  std::vector<ksh_ctx*> use;
+  for (size_t l = 1; l <= n_lanes && n_lanes >= 2; l++) {
     if (ctx->lanes.size() < l) {
       ksh_ctx* lane = nullptr;
       if (ksh_ctx_create(ctx->device, nullptr, &lane) != KSH_OK) break;  // (no stream, no pinned page: go on with fewer)
@@ -220,7 +228,7 @@ int run_on_lanes(ksh_ctx* ctx, const std::vector<size_t>& order, size_t need_byt
     lane->timing_stride = ctx->timing_stride;
     use.push_back(lane);
   }
-  if (use.size() == 1) {
+  if (use.size() < 2) {  // one lane (asked for, or all that fits): everything on the context's own stream
     for (size_t q : order) KSH_TRY(job(ctx, q));
     return KSH_OK;
   }
@@ -247,7 +255,7 @@ int run_on_lanes(ksh_ctx* ctx, const std::vector<size_t>& order, size_t need_byt
   ctx->lanes_busy = true;
   std::vector<std::thread> threads;
   for (size_t l = 1; l < use.size(); l++) threads.emplace_back(work, use[l]);
-  work(ctx);
+  work(use[0]);
   for (std::thread& t : threads) t.join();
   ctx->lanes_busy = false;
   if (first_rc.load() != KSH_OK) return fail(first_rc.load(), "%s", first_msg.c_str());

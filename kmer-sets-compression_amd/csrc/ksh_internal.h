@@ -148,8 +148,8 @@ int pool_alloc(ksh_ctx* ctx, size_t bytes, void** out);
 void pool_free(ksh_ctx* ctx, void* p);
 void pool_trim(ksh_ctx* ctx);
 
-// Runs job(lane, q) for every q of `order` (most expensive first), on the context's stream and on up to
-// lanes_wanted - 1 helper contexts at once, each from a host thread of its own; the calling thread is lane 0.
+// Runs job(lane, q) for every q of `order` (most expensive first) on up to lanes_wanted helper contexts at once,
+// each from a host thread of its own (the calling thread works one of them); with one lane, on the context itself.
 // `prepare(lane)` reserves the scratch the largest job needs and is called for a helper lane before it is
 // used (a lane that cannot get its scratch -- memory -- is left out, that is no error); `need_bytes` is what
 // that reservation takes, checked against the free memory first.  The context's stream is drained before

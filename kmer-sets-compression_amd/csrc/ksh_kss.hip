@@ -169,6 +169,7 @@ static int decode_to_set(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s
   if (rc == KSH_OK) rc = alloc_keys(home, g, n, out);
   if (rc == KSH_OK) rc = ksh_spss_decode_write(ctx, g, sp, canonical_flag, out->off, out->keys, &n);
   if (rc != KSH_OK) {
+    (void)hipStreamSynchronize(ctx->stream);  // (nothing of this job is still writing into what goes back to the pool)
     free_set(home, out);
     return rc;
   }
@@ -187,6 +188,7 @@ static int encode_set(ksh_ctx* ctx, const ksh_geom* g, const KssSet& s, int cano
   if (rc == KSH_OK) rc = pool_alloc(home, std::max<size_t>(size_t(ns) * 4, 16), reinterpret_cast<void**>(&out->lens));
   if (rc == KSH_OK) rc = ksh_spss_encode_write(ctx, out->words, out->lens);
   if (rc != KSH_OK) {
+    (void)hipStreamSynchronize(ctx->stream);
     free_compact(home, out);
     return rc;
   }

@@ -98,6 +98,36 @@ def test_loop_lanes(gpu, lanes):
         c.close()
 
 
+def test_loop_lanes_oversize_buckets(gpu):
+    """(19, 10) sets of 1.7 x 10^7 k-mers: 16 600 keys per bucket, more than the bucket sort's LDS window holds, so every
+    decode takes a scratch copy the size of the set's keys from the pool and gives it back with the sort still
+    queued -- fine on one stream, and the block that faulted the GPU when a job of another lane received it as its
+    RESULT (tools/scale_sweep.py --seed 11, case 53).  Four inputs on three lanes, three builds:
+    every Get(i) == input i by Size and XOR Hash, the nodes' sizes add up."""
+    import torch
+    from kmersets import synth_torch
+
+    k, n = 19, 10
+    g = capi.geom(k, n)
+    c = capi.Context(0)
+    c.set_lanes(3)
+    try:
+        fam = synth_torch.phylogeny_sets(k, 4, 17_000_001, 472687, c.device, rate=0.02)
+        sets = [synth_torch.device_set(g, f) for f in fam]
+        del fam
+        compacts = [c.spss_encode(d, mode=0) for d in sets]
+        want = [(d.n_keys, c.set_hash(d)) for d in sets]
+        ids = synth.sample_bucket_ids(n, seed=5)
+        for _ in range(3):
+            kss = capi.DeviceKmerSetSet(c, compacts, ids)
+            assert [kss.get_size_and_hash(i) for i in range(4)] == want
+            assert sum(kss.node_size(i) for i in range(kss.size())) == kss.stats()["final_total_size"]
+            kss.close()
+        torch.cuda.synchronize()
+    finally:
+        c.close()
+
+
 def test_loop_repeat_rich_family(ctx):
     """The whole loop on a repeat-rich family (bench_loop.py --repeats): every node's strings, the trace and the
     checkpoints against the oracle where the encodes are the expensive, branching kind."""

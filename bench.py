@@ -218,6 +218,8 @@ def main():
     # overlap, not what the kernel does with the GPU; both are reported (`roofline.timed_region`).
     lanes_used = args.lanes if args.lanes > 0 else int(os.environ.get("KSH_LANES", "3"))
     timers_timed, excl_wall = timers, None
+    st = kss.stats()                 # (of the last TIMED build: phases, encode counts, SPSS sizes)
+    it, cp, imp = kss.trace()
     if world == 1 and lanes_used != 1:
         kss.close()
         ctx.set_lanes(1)
@@ -231,9 +233,10 @@ def main():
         timers = {name: (ctx.timing_read(kind), ctx.timing_units(kind), ctx.timing_wall(kind)) for name, kind in KINDS}
         ctx.enable_timing(False)
         ctx.set_lanes(args.lanes)
+        phase_seconds_one_stream = kss.stats()["phase_seconds"]
+    else:
+        phase_seconds_one_stream = None
 
-    st = kss.stats()
-    it, cp, imp = kss.trace()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -505,6 +508,7 @@ def main():
                                "all-gather / send-recv on device buffers" % (n_sets // world, comm.kind.upper()),
             },
             "phase_seconds_last_build": st["phase_seconds"],
+            "phase_seconds_one_stream_build": phase_seconds_one_stream,
             "roofline": {
                 "bound": "hbm",
                 "kernel": "neighbour-probe stage of the SPSS encode (k_rc_hist / k_rc_columns / k_rc_scatter_l1+l2 / k_rc_bounds / "

@@ -80,17 +80,22 @@ struct SetPtrs {
   const int64_t* off;
 };
 
-// One segment per (pair p, sampled bucket i): s = p * n_ids + i.
+// One segment per (sampled bucket i, pair p): s = i * n_pairs + p -- bucket-major, so that the workgroups in
+// flight at any time work on the same few sampled buckets of all sets (64 sets x 6 100 keys x 4 B = 1.5 MB per
+// bucket of a 10^8-k-mer family: L2-resident) instead of streaming every set's whole 8 MB sample once per pair
+// it takes part in (2 016 pairs of 64 sets: 63 times).
 template <typename KeyT>
 struct PairSegs {
   const SetPtrs* sets;
   const int32_t* bucket_ids;
   const int32_t* pairs;
   int32_t n_ids;
+  int32_t n_pairs;
   __device__ void get(int64_t s, const KeyT*& a, int64_t& a_lo, int64_t& a_hi, const KeyT*& b,
                       int64_t& b_lo, int64_t& b_hi) const {
-    const int64_t p = s / n_ids;
-    const int32_t bucket = bucket_ids[s - p * n_ids];
+    const int64_t i = s / n_pairs;
+    const int64_t p = s - i * n_pairs;
+    const int32_t bucket = bucket_ids[i];
     const SetPtrs sa = sets[pairs[2 * p]];
     const SetPtrs sb = sets[pairs[2 * p + 1]];
     a = static_cast<const KeyT*>(sa.keys);
@@ -627,19 +632,29 @@ __global__ __launch_bounds__(256) void k_result_offsets(
   }
 }
 
-// weights[p] = common keys over the segments [p * n_ids, (p + 1) * n_ids).
+// weights[p] = common keys over the segments i * n_pairs + p, i = 0 .. n_ids - 1 (one wave per pair: the lanes
+// take the sampled buckets in turn, a segment's count is the difference of the common-key prefixes at its
+// first tile and at the next segment's).
 __global__ __launch_bounds__(256) void k_pair_weight_gather(
     const int64_t* __restrict__ tile_base, const int64_t* __restrict__ tile_ioff,
     const int64_t* __restrict__ total_m, int64_t n_segs, int32_t n_ids, int32_t n_pairs,
     int64_t* __restrict__ weights) {
-  const int32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  const int32_t p = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int lane = threadIdx.x & 63;
   if (p >= n_pairs) return;
   const int64_t total_tiles = tile_base[n_segs];
-  const int64_t t0 = tile_base[int64_t(p) * n_ids];
-  const int64_t t1 = tile_base[int64_t(p + 1) * n_ids];
-  const int64_t m0 = t0 < total_tiles ? tile_ioff[t0] : *total_m;
-  const int64_t m1 = t1 < total_tiles ? tile_ioff[t1] : *total_m;
-  weights[p] = m1 - m0;
+  int64_t sum = 0;
+  for (int32_t i = lane; i < n_ids; i += 64) {
+    const int64_t s = int64_t(i) * n_pairs + p;
+    const int64_t t0 = tile_base[s], t1 = tile_base[s + 1];
+    if (t1 == t0) continue;  // (an empty segment has no tile)
+    const int64_t m0 = t0 < total_tiles ? tile_ioff[t0] : *total_m;
+    const int64_t m1 = t1 < total_tiles ? tile_ioff[t1] : *total_m;
+    sum += m1 - m0;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) sum += __shfl_xor(sum, d, 64);
+  if (lane == 0) weights[p] = sum;
 }
 
 // The same for every pair of a batch: pair p owns segments [p * nb, (p + 1) * nb]; its prefixes
@@ -1044,7 +1059,7 @@ int pair_weights_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sets, in
                          hipMemcpyHostToDevice, ctx->stream));
   KSH_HIP(hipMemcpyAsync(d_ids, bucket_ids, size_t(n_ids) * 4, hipMemcpyHostToDevice, ctx->stream));
   KSH_HIP(hipMemcpyAsync(d_pairs, pairs, size_t(n_pairs) * 8, hipMemcpyHostToDevice, ctx->stream));
-  PairSegs<KeyT> segs{d_sets, d_ids, d_pairs, n_ids};
+  PairSegs<KeyT> segs{d_sets, d_ids, d_pairs, n_ids, n_pairs};
   KSH_TRY((plan_tile_base<KeyT>(ctx, segs, n_segs, tile_base, nullptr)));
   // exact tile count (the sampled slices are ~2 % of each set; no useful bound without it)
   KSH_HIP(hipMemcpyAsync(ctx->h_pinned, tile_base + n_segs, sizeof(int64_t), hipMemcpyDeviceToHost,
@@ -1067,7 +1082,7 @@ int pair_weights_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sets, in
   p.tile_base = tile_base;
   KSH_TRY(label_tiles(ctx, tile_base, n_segs, p.owner));
   KSH_TRY((plan_count<KeyT>(ctx, segs, p, 2, false)));
-  hipLaunchKernelGGL(k_pair_weight_gather, dim3(blocks_for(n_pairs, 256)), dim3(256), 0,
+  hipLaunchKernelGGL(k_pair_weight_gather, dim3(blocks_for(int64_t(n_pairs) * 64, 256)), dim3(256), 0,
                      ctx->stream, p.tile_base, p.tile_ioff, p.total_m, n_segs, n_ids, n_pairs,
                      d_weights);
   KSH_HIP(hipGetLastError());

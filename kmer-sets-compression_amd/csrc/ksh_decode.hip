@@ -217,11 +217,19 @@ __global__ __launch_bounds__(kDecL1Threads) void k_decode_l1(
       }
     }
     __syncthreads();
-    if (tid < kSg) {
-      uint32_t before = 0;
-      for (int b = 0; b < tid; b++) before += s_cnt[b];
-      s_lbase[tid] = before;
-      if (tid == kSg - 1) s_lbase[kSg] = before + s_cnt[tid];
+    if (tid < 64) {
+      // exclusive scan of the kSg counts by the first wave, two counts per lane (see k_rc_scatter_l1)
+      static_assert(kSg == 128, "two super-buckets per lane of one wave");
+      const uint32_t c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
+      uint32_t inc = c0 + c1;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (tid >= d) inc += o;
+      }
+      s_lbase[2 * tid] = inc - c0 - c1;
+      s_lbase[2 * tid + 1] = inc - c1;
+      if (tid == 63) s_lbase[kSg] = inc;
     }
     __syncthreads();
 #pragma unroll

@@ -463,10 +463,19 @@ __global__ __launch_bounds__(kL1Threads) void k_rc_scatter_l1(DevSet<KeyT> set, 
       rank[j] = atomicAdd(&s_cnt[grp[j] >> lo_bits], 1u);
     }
     __syncthreads();
-    if (tid < kSg) {
-      uint32_t before = 0;
-      for (int b = 0; b < tid; b++) before += s_cnt[b];
-      s_lbase[tid] = before;
+    if (tid < 64) {
+      // exclusive scan of the kSg counts by the first wave, two counts per lane (it used to be 128 threads adding up
+      // to 127 counts each, one after the other, while fourteen waves waited at the barrier)
+      static_assert(kSg == 128, "two super-groups per lane of one wave");
+      const uint32_t c0 = s_cnt[2 * tid], c1 = s_cnt[2 * tid + 1];
+      uint32_t inc = c0 + c1;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t o = __shfl_up(inc, d, 64);
+        if (tid >= d) inc += o;
+      }
+      s_lbase[2 * tid] = inc - c0 - c1;
+      s_lbase[2 * tid + 1] = inc - c1;
     }
     __syncthreads();
 #pragma unroll

@@ -2,7 +2,7 @@
 build's span (from the last k_str_bases-led burst of decode kernels to the end), and reports
   - wall, busy (union of all kernel spans), idle, and the time during which 1 / 2 / 3+ kernels were running;
   - per kernel name: launches, summed duration (stream time), and the part of it spent alone on the GPU.
-usage: lane_overlap.py kernel_trace.csv [--from-kernel NAME]"""
+usage: lane_overlap.py kernel_trace.csv [BUILD]   (BUILD: index of the build in the trace, default -1)"""
 import collections
 import csv
 import re
@@ -19,12 +19,24 @@ def short(n):
     return m.group(1) if m else n.split("(")[0][:32]
 
 
-# the last build: after the largest gap between two ksh kernels in the second half of the trace
+# the builds of the trace: every build starts with the Size() of its inputs (k_sum_lens, one per input, within its
+# first tenth of a second); a build ends where the next one starts.  argv[2] = which build (default -1: the last
+# one; bench.py's last build is its one-stream roofline leg, the one before it the last TIMED build: -2)
 ksh = [r for r in rows if "ksh::" in r[2]]
-half = ksh[len(ksh) // 3:]
-gaps = [(half[i + 1][0] - max(x[1] for x in half[max(0, i - 8):i + 1]), i) for i in range(len(half) - 1)]
-g, at = max(gaps)
-build = half[at + 1:] if g > 5e6 else ksh
+starts = []
+prev = None
+for i, r in enumerate(ksh):
+    if "k_sum_lens" in r[2]:
+        if prev is None or r[0] - prev > 100e6:
+            starts.append(i)
+        prev = r[0]
+which = int(sys.argv[2]) if len(sys.argv) > 2 else -1
+if starts:
+    b0 = starts[which]
+    later = [x for x in starts if x > b0]
+    build = ksh[b0:(later[0] if later else len(ksh))]
+else:
+    build = ksh
 t0, t1 = build[0][0], max(x[1] for x in build)
 ev = []
 for s, e, n in build:

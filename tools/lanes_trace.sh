@@ -9,7 +9,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for L in "${@:-1 3}"; do
   rocprofv3 --kernel-trace --output-format csv -d $O/${TAG}_l${L} -o t -- python3 $R/bench.py --steps 1 --warmup 1 --lanes $L --no-cpu-baseline --no-verify --no-pair-merge > $O/${TAG}_l${L}.json 2> $O/${TAG}_l${L}.err
-  python3 $R/tools/lane_overlap.py "$(find $O/${TAG}_l${L} -name '*kernel_trace.csv' | head -1)" > $O/${TAG}_l${L}_overlap.txt
+  python3 $R/tools/lane_overlap.py "$(find $O/${TAG}_l${L} -name '*kernel_trace.csv' | head -1)" -2 > $O/${TAG}_l${L}_overlap.txt
   rm -rf $O/${TAG}_l${L}
   head -3 $O/${TAG}_l${L}_overlap.txt
 done

@@ -216,7 +216,7 @@ def main():
     # stage bracketed by HIP events on that stream.  In the timed region above several encodes share the GPU
     # (lanes): a launch's duration there depends on whose kernels run beside it, so it says how the streams
     # overlap, not what the kernel does with the GPU; both are reported (`roofline.timed_region`).
-    lanes_used = args.lanes if args.lanes > 0 else int(os.environ.get("KSH_LANES", "3"))
+    lanes_used = args.lanes if args.lanes > 0 else int(os.environ.get("KSH_LANES", "4"))
     timers_timed, excl_wall = timers, None
     st = kss.stats()                 # (of the last TIMED build: phases, encode counts, SPSS sizes)
     it, cp, imp = kss.trace()

@@ -118,7 +118,7 @@ int ksh_ctx_timing_units(ksh_ctx* ctx, int kind, int64_t* units);
  * (created on first use, mapped scratch kept, freed by ksh_ctx_destroy); every job runs on one of them and
  * allocates its result from the context's own pool, which only hands out while jobs run.  Lanes whose scratch
  * does not fit the free memory are left out; with fewer than two the jobs run on the context's stream, one
- * after the other.  n_lanes = 1: everything on the context's stream, as before; 0: the default (KSH_LANES, else 3).
+ * after the other.  n_lanes = 1: everything on the context's stream, as before; 0: the default (KSH_LANES, else 4).  The lanes run on two disjoint shares of the CUs, odd and even lanes (KSH_LANE_CUS=1: every lane on all CUs).
  * With lanes, ksh_ctx_timing_read / _units sum over the lanes (stream time: spans of different lanes overlap);
  * ksh_ctx_timing_wall is the length of the UNION of a kind's timed spans over all lanes, i.e. the wall time
  * during which at least one launch of the kind was running. */

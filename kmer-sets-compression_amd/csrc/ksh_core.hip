@@ -183,7 +183,7 @@ static void lanes_release_scratch(ksh_ctx* ctx) {
 static int lanes_default() {
   static const int v = [] {
     const char* e = getenv("KSH_LANES");
-    const int n = e ? atoi(e) : 3;
+    const int n = e ? atoi(e) : 4;
     return n < 1 ? 1 : (n > 8 ? 8 : n);
   }();
   return v;
@@ -207,7 +207,36 @@ int run_on_lanes(ksh_ctx* ctx, const std::vector<size_t>& order, size_t need_byt
   for (size_t l = 1; l <= n_lanes && n_lanes >= 2; l++) {
     if (ctx->lanes.size() < l) {
       ksh_ctx* lane = nullptr;
-      if (ksh_ctx_create(ctx->device, nullptr, &lane) != KSH_OK) break;  // (no stream, no pinned page: go on with fewer)
+      // The lanes share the GPU by SPACE, two shares of the CUs, odd and even lanes (hipExtStreamCreateWithCUMask;
+      // the lower and the upper half of the mask's bits: on gfx942 / gfx950 consecutive bits go round the XCDs, so
+      // every XCD gives half of its CUs to either share).  Kernels of different encodes that time-share a CU get
+      // in each other's way -- a CU full of walk waves keeps the probe's workgroups out until they drain, a 78 KB
+      // LDS window beside 21 KB ones leaves LDS nobody fits --; on disjoint CUs two lanes per share pack well:
+      // 64 x 10^8 build, one box: 3 lanes 782 ms, 4: 793, 6: 765, 8: 762; 4 lanes on 2 shares 737 (734 - 741 on three
+      // boxes), 5 on 2: 752, 2 on 2: 765, 4 on 4: 762, 3 on 3 (shares that cut through XCDs unevenly): 899, 4 on 2 with
+      // the shares by XCD parity: 757 (profiles/r04_lanes_occupancy_ab.txt).  KSH_LANE_CUS=1: every lane on all CUs.
+      static const int split = [] {
+        const char* e = getenv("KSH_LANE_CUS");
+        const int n = e ? atoi(e) : 2;
+        return n < 1 ? 1 : (n > 8 ? 8 : n);
+      }();
+      hipStream_t masked = nullptr;
+      if (split > 1) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess) {
+          const int n_cu = prop.multiProcessorCount;
+          std::vector<uint32_t> mask(size_t((n_cu + 31) / 32), 0u);
+          const int share = int(l - 1) % split;
+          for (int cu = 0; cu < n_cu; cu++)
+            if (cu * split / n_cu == share) mask[size_t(cu / 32)] |= 1u << (cu % 32);
+          if (hipExtStreamCreateWithCUMask(&masked, uint32_t(mask.size()), mask.data()) != hipSuccess) {
+            (void)hipGetLastError();
+            masked = nullptr;  // (a plain stream then)
+          }
+        }
+      }
+      if (ksh_ctx_create(ctx->device, masked, &lane) != KSH_OK) break;  // (no stream, no pinned page: go on with fewer)
+      if (masked) lane->own_stream = true;
       lane->lane_parent = ctx;
       ctx->lanes.push_back(lane);
     }

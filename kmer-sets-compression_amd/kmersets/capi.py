@@ -408,7 +408,7 @@ class Context:
 
     def set_lanes(self, n):
         """Independent jobs of one call (a check's encodes, the inputs' decodes) on up to n streams at once; 1: one
-        stream, 0: the default (KSH_LANES, else 3)."""
+        stream, 0: the default (KSH_LANES, else 4)."""
         check(lib().ksh_ctx_set_lanes(self.h, int(n)))
 
     # KmerSet::Hash / Size -------------------------------------------------------

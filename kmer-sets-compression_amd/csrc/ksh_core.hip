@@ -49,6 +49,57 @@ int check_geom(const ksh_geom* g) {
   return KSH_OK;
 }
 
+static void pool_trim_locked(ksh_ctx* ctx);
+static void lanes_release_scratch(ksh_ctx* ctx);
+
+static size_t device_total_bytes() {
+  static const size_t total = [] {
+    size_t f = 0, t = 0;
+    return hipMemGetInfo(&f, &t) == hipSuccess ? t : size_t(288) << 30;
+  }();
+  return total;
+}
+// the margin kept free for everybody else (the caller's own allocator, the runtime's queues and code objects)
+static size_t device_margin_bytes() { return std::max<size_t>(size_t(2) << 30, device_total_bytes() / 64); }
+
+static bool device_has_room(size_t bytes) {
+  size_t f = 0, t = 0;
+  if (hipMemGetInfo(&f, &t) != hipSuccess) return true;  // (cannot tell: let hipMalloc answer)
+  return f >= bytes + device_margin_bytes();
+}
+
+// `pool_locked`: the caller holds ctx->pool_mu (pool_alloc)
+static int device_alloc_impl(ksh_ctx* ctx, size_t bytes, void** out, bool pool_locked) {
+  *out = nullptr;
+  if (!device_has_room(bytes)) {
+    // what this context only caches
+    if (pool_locked) {
+      pool_trim_locked(ctx);
+    } else {
+      pool_trim(ctx);
+    }
+    // ... its parent (a lane's results live in the parent's pool: its cached blocks are nobody's)
+    if (!device_has_room(bytes) && ctx->lane_parent) pool_trim(ctx->lane_parent);
+    // ... and the scratch of idle lanes (mapped again when they are next used)
+    if (!device_has_room(bytes) && !ctx->lanes.empty() && !ctx->lanes_busy) lanes_release_scratch(ctx);
+    if (!device_has_room(bytes)) {
+      size_t f = 0, t = 0;
+      (void)hipMemGetInfo(&f, &t);
+      return fail(KSH_INTERNAL, "out of device memory: %zu bytes asked for, %zu of %zu free (a margin of %zu is kept)", bytes,
+                  f, t, device_margin_bytes());
+    }
+  }
+  const hipError_t e = hipMalloc(out, bytes);
+  if (e != hipSuccess) {
+    (void)hipGetLastError();
+    *out = nullptr;
+    return fail(KSH_INTERNAL, "hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+  }
+  return KSH_OK;
+}
+
+int device_alloc(ksh_ctx* ctx, size_t bytes, void** out) { return device_alloc_impl(ctx, bytes, out, false); }
+
 int arena_reserve(ksh_ctx* ctx, size_t bytes) {
   if (bytes <= ctx->arena_bytes) return KSH_OK;
   KSH_HIP(hipStreamSynchronize(ctx->stream));
@@ -56,7 +107,7 @@ int arena_reserve(ksh_ctx* ctx, size_t bytes) {
   ctx->arena = nullptr;
   ctx->arena_bytes = 0;
   size_t want = bytes + (bytes >> 2) + (1u << 20);
-  KSH_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->arena), want));
+  KSH_TRY(device_alloc(ctx, want, reinterpret_cast<void**>(&ctx->arena)));
   ctx->arena_bytes = want;
   ctx->arena_used = 0;
   return KSH_OK;
@@ -76,7 +127,7 @@ int slot_reserve(ksh_ctx* ctx, int which, size_t bytes) {
   ctx->slot[which] = nullptr;
   ctx->slot_bytes[which] = 0;
   size_t want = bytes + (bytes >> 3) + (1u << 16);
-  KSH_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->slot[which]), want));
+  KSH_TRY(device_alloc(ctx, want, reinterpret_cast<void**>(&ctx->slot[which])));
   ctx->slot_bytes[which] = want;
   return KSH_OK;
 }
@@ -87,9 +138,6 @@ static size_t pool_round(size_t bytes) {
   while (gran * 16 <= bytes) gran <<= 1;  // gran in (bytes/16, bytes/8]: at most 12.5 % slack
   return (bytes + gran - 1) / gran * gran;
 }
-
-static void pool_trim_locked(ksh_ctx* ctx);
-static void lanes_release_scratch(ksh_ctx* ctx);
 
 int pool_alloc(ksh_ctx* ctx, size_t bytes, void** out) {
   std::lock_guard<std::mutex> lock(ctx->pool_mu);
@@ -110,17 +158,7 @@ int pool_alloc(ksh_ctx* ctx, size_t bytes, void** out) {
     ctx->pool_free_blocks.erase(it);
     return KSH_OK;
   }
-  hipError_t e = hipMalloc(out, want);
-  if (e != hipSuccess) {
-    pool_trim_locked(ctx);  // give the cached blocks back and retry once
-    e = hipMalloc(out, want);
-    if (e != hipSuccess && !ctx->lanes.empty() && !ctx->lanes_busy) {
-      lanes_release_scratch(ctx);  // ... and the idle lanes' scratch (mapped again when they are next used)
-      e = hipMalloc(out, want);
-    }
-    if (e != hipSuccess)
-      return fail(KSH_INTERNAL, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
-  }
+  KSH_TRY(device_alloc_impl(ctx, want, out, true));  // (gives the cached blocks back first when memory is short)
   ctx->pool_sizes[*out] = want;
   ctx->pool_live_bytes += want;
   ctx->pool_peak_bytes = std::max(ctx->pool_peak_bytes, ctx->pool_live_bytes);
@@ -138,8 +176,9 @@ void pool_free(ksh_ctx* ctx, void* p) {
   ctx->pool_free_blocks.emplace(it->second, p);
   ctx->pool_cached_bytes += it->second;
   ctx->pool_live_bytes -= std::min(ctx->pool_live_bytes, it->second);
-  // keep the cache bounded: drop the largest blocks beyond 96 GiB
-  while (ctx->pool_cached_bytes > (size_t(96) << 30) && !ctx->pool_free_blocks.empty()) {
+  // keep the cache bounded: drop the largest blocks beyond a quarter of the device's memory (at most 96 GiB)
+  const size_t cache_cap = std::min<size_t>(size_t(96) << 30, device_total_bytes() / 4);
+  while (ctx->pool_cached_bytes > cache_cap && !ctx->pool_free_blocks.empty()) {
     auto last = std::prev(ctx->pool_free_blocks.end());
     ctx->pool_cached_bytes -= last->first;
     ctx->pool_sizes.erase(last->second);
@@ -248,6 +287,11 @@ int run_on_lanes(ksh_ctx* ctx, const std::vector<size_t>& order, size_t need_byt
     if (have < need_bytes) {
       if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) break;
       if (free_b < (need_bytes - have) + need_bytes / 4 + (size_t(4) << 30)) break;
+      // ... and the lanes together hold at most two fifths of the device: the sets, the results and the caller's
+      // own allocator need the rest (four lanes of a 5 x 10^8-k-mer k = 31 encode would be 190 of 288 GB)
+      size_t lanes_total = need_bytes;
+      for (size_t q = 0; q + 1 < l; q++) lanes_total += std::max(need_bytes, ctx->lanes[q]->slot_bytes[kSlotEncode] + ctx->lanes[q]->slot_bytes[kSlotDecode] + ctx->lanes[q]->arena_bytes);
+      if (lanes_total > total_b / 5 * 2) break;
     }
     if (prepare(lane) != KSH_OK) {
       (void)hipGetLastError();
@@ -308,7 +352,7 @@ int plan_reserve(ksh_ctx* ctx, size_t bytes) {
   ctx->plan = nullptr;
   ctx->plan_bytes = 0;
   size_t want = bytes + (bytes >> 2) + (1u << 16);
-  KSH_HIP(hipMalloc(reinterpret_cast<void**>(&ctx->plan), want));
+  KSH_TRY(device_alloc(ctx, want, reinterpret_cast<void**>(&ctx->plan)));
   ctx->plan_bytes = want;
   return KSH_OK;
 }
@@ -625,6 +669,12 @@ int ksh_malloc(int device, size_t bytes, void** d_ptr) {
   *d_ptr = nullptr;
   KSH_HIP(hipSetDevice(device));
   if (bytes == 0) bytes = 16;
+  // (no context here to give cached memory back: refuse rather than let the runtime run out, see device_alloc)
+  if (!device_has_room(bytes)) {
+    size_t f = 0, t = 0;
+    (void)hipMemGetInfo(&f, &t);
+    return fail(KSH_INTERNAL, "out of device memory: %zu bytes asked for, %zu of %zu free", bytes, f, t);
+  }
   KSH_HIP(hipMalloc(d_ptr, bytes));
   return KSH_OK;
 }

@@ -908,7 +908,7 @@ int decode_write_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_spss_view* s, int 
   if (kept != ctx->dec_kmers) {
     // repeated k-mers in the input: close the gaps (rare; through a temporary copy)
     void* tmp = nullptr;
-    KSH_HIP(hipMalloc(&tmp, size_t(ctx->dec_kmers) * sizeof(KeyT)));
+    KSH_TRY(device_alloc(ctx, size_t(ctx->dec_kmers) * sizeof(KeyT), &tmp));
     KSH_HIP(hipMemcpyAsync(tmp, keys, size_t(ctx->dec_kmers) * sizeof(KeyT), hipMemcpyDeviceToDevice,
                            ctx->stream));
     hipLaunchKernelGGL((k_compact_buckets<KeyT>), dim3(unsigned(nb)), dim3(256), 0, ctx->stream,

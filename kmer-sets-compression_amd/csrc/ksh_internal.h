@@ -136,6 +136,12 @@ struct ksh_ctx {
 
 namespace ksh {
 
+// hipMalloc that never lets the runtime run out of memory: when the device's free memory (hipMemGetInfo) does
+// not hold `bytes` plus a margin, the context's pool (and its parent's, and idle lanes' scratch) give back what
+// they only cache, and if that is not enough the call FAILS here with KSH_INTERNAL.  (ROCm 7.2's own
+// out-of-memory path crashes the process: hipMalloc -> KfdDriver::AllocateMemory -> GpuAgent::Trim ->
+// AqlQueue::AsyncReclaimMainScratch, SIGSEGV)
+int device_alloc(ksh_ctx* ctx, size_t bytes, void** out);
 int arena_reserve(ksh_ctx* ctx, size_t bytes);
 inline void arena_reset(ksh_ctx* ctx) { ctx->arena_used = 0; }
 // Returns nullptr when the arena is too small (callers reserve first).

@@ -791,8 +791,7 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
     for (size_t p : payload) slot = std::max(slot, p);
     char* d_send = nullptr;
     KSH_LOCAL(k, pool_alloc(ctx, slot, reinterpret_cast<void**>(&d_send)));
-    if (alive(k) && hipMalloc(reinterpret_cast<void**>(&k->sample_block), slot * size_t(world)) != hipSuccess)
-      poison(k, fail(KSH_INTERNAL, "hipMalloc(%zu) of the samples' receive buffer failed", slot * size_t(world)));
+    if (alive(k)) poison(k, device_alloc(ctx, slot * size_t(world), reinterpret_cast<void**>(&k->sample_block)));
     {  // the payload exchange needs its buffers on every rank: agree on that first
       std::vector<int64_t> none, unused;
       KSH_TRY(gather_i64(k, none, &unused));
@@ -2084,8 +2083,8 @@ int ksh_kss_get(const ksh_kss* k, int32_t i, int64_t** d_offsets, void** d_keys,
   // hand the result over in plain hipMalloc'ed buffers (the caller releases them with ksh_free)
   {
     KssSet out;
-    KSH_HIP(hipMalloc(reinterpret_cast<void**>(&out.off), size_t(nb + 1) * 8));
-    KSH_HIP(hipMalloc(&out.keys, std::max<size_t>(size_t(acc.n) * g->key_bytes, 16)));
+    KSH_TRY(device_alloc(ctx, size_t(nb + 1) * 8, reinterpret_cast<void**>(&out.off)));
+    KSH_TRY(device_alloc(ctx, std::max<size_t>(size_t(acc.n) * g->key_bytes, 16), &out.keys));
     KSH_HIP(hipMemcpyAsync(out.off, acc.off, size_t(nb + 1) * 8, hipMemcpyDeviceToDevice, ctx->stream));
     if (acc.n)
       KSH_HIP(hipMemcpyAsync(out.keys, acc.keys, size_t(acc.n) * g->key_bytes, hipMemcpyDeviceToDevice,

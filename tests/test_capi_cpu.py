@@ -47,3 +47,35 @@ def test_geometry_validation_is_host_side(lib):
     assert capi.geom(31, 14).key_bytes == 8
     assert capi.geom(15, 14).key_bytes == 2   # the reference's (15, 14, uint16_t)
     assert capi.geom(9, 10, 1).key_bytes == 2 and capi.geom(19, 10).key_bytes == 4
+
+
+def test_custom_transport_struct_is_size_tagged(lib):
+    """ksh_comm_fns starts with its own size (ksh_version() >= 2): a struct that does not say how large it is, is
+    refused on the host, before any device is touched (a caller compiled against an older, shorter struct would
+    otherwise be read past its end)."""
+    assert lib.ksh_version() >= 2
+    assert capi.CommFns._fields_[0][0] == "struct_size"
+    fns = capi.CommFns()          # zero-initialised: struct_size == 0
+    h = C.c_void_p()
+    # (no context without a GPU: the argument check comes first either way)
+    rc = lib.ksh_comm_create_custom(None, 0, 2, C.byref(fns), C.byref(h))
+    assert rc == capi.KSH_INVALID_ARGUMENT and not h.value
+
+
+def test_repeat_rich_generator_twins_agree():
+    """synth.plant_repeats (numpy) and synth_torch.plant_repeats plant the same bases, so the repeat-rich family of
+    bench_loop.py --repeats is the one the parity tests check against the oracle at small sizes."""
+    import numpy as np
+    import torch
+
+    from kmersets import synth, synth_torch
+
+    g = synth.random_genome(150_000, 9)
+    a = synth.plant_repeats(g, 200, 5, 13)
+    b = synth_torch.plant_repeats(torch.from_numpy(g.astype(np.int64)), 200, 5, 13).numpy().astype(np.uint8)
+    assert (a != g).sum() > 10_000 and np.array_equal(a, b)
+    s1 = synth.phylogeny_sets(23, 2, 100_000, 3, repeats=(150, 6))
+    s2 = synth_torch.phylogeny_sets(23, 2, 100_000, 3, torch.device("cpu"), repeats=(150, 6))
+    assert all(np.array_equal(x, y.numpy().astype(np.uint64)) for x, y in zip(s1, s2))
+    # the repeats make the set smaller than the genome: shared k-mers collapse
+    assert len(s1[0]) < len(synth.phylogeny_sets(23, 2, 100_000, 3)[0])

@@ -16,7 +16,7 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py --dump-trace $O/${TAG}_trace.json "$@" > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 cut -c1-700 $O/${TAG}_bench.json; echo
-for L in 1 3; do
+for L in 1 4; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_stats_l$L -o stats -- python3 $R/bench.py --steps 1 --warmup 1 --lanes $L --no-cpu-baseline --no-verify --no-pair-merge > $O/${TAG}_bench_under_rocprof_l$L.json 2> $O/${TAG}_rocprof_stats_l$L.err
   T="$(find $O/${TAG}_stats_l$L -name '*kernel_trace.csv' | head -1)"
   python3 $R/tools/gpu_gaps.py "$T" > $O/${TAG}_gaps_l$L.txt

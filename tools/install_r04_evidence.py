@@ -25,11 +25,11 @@ def main():
     names = {
         "bench.json": "r04_bench_64x1e8.json",
         "kernel_stats_l1.csv": "r04_kernel_stats_64x1e8_one_stream.csv",
-        "kernel_stats_l3.csv": "r04_kernel_stats_64x1e8_three_lanes.csv",
+        "kernel_stats_l4.csv": "r04_kernel_stats_64x1e8_four_lanes.csv",
         "gaps_l1.txt": "r04_gpu_idle_gaps_one_stream.txt",
-        "gaps_l3.txt": "r04_gpu_idle_gaps_three_lanes.txt",
+        "gaps_l4.txt": "r04_gpu_idle_gaps_four_lanes.txt",
         "overlap_l1.txt": "r04_lane_overlap_one_stream.txt",
-        "overlap_l3.txt": "r04_lane_overlap_three_lanes.txt",
+        "overlap_l4.txt": "r04_lane_overlap_four_lanes.txt",
         "trace.json": "r04_trace_64x1e8.json",
         "pmc_ranking_walks.json": "r04_pmc_ranking_walks_16x1e8.json",
         "pmc_emit_from_logs.json": "r04_pmc_emit_from_logs_16x1e8.json",

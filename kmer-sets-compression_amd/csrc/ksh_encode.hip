@@ -934,6 +934,13 @@ __device__ __forceinline__ int lds_lower_bound(const KeyT* a, int lo, int hi, Ke
 __device__ unsigned long long g_fwd_dbg[8];
 
 
+// (Measured and dropped, round 4: the five searches of a k-mer IN LOCKSTEP -- branch-free halving of all open ranges
+// per step, the LDS reads of a step issued together and waited for together, so that the longest dependent chain is
+// the Next search's 12 reads instead of 11 + 4 x 7 one after the other; 64 vector registers, no spills, the oracle's
+// strings: 2.30 ms per 10^8 against 1.85, 213 us against 176 on the difference set.  With 32 waves per CU the
+// LDS pipeline is kept busy by OTHER waves while one waits; what a wave's own reads in flight together add is
+// predication and state (five ranges, five probes per step), not throughput.
+// gpurun_out/r04/encs_lock_kernel_stats.csv)
 // (Measured and dropped, round 4: a hybrid -- the Next window staged and searched in LDS, the four Prev(x, c) probed in
 // global memory through the fine index (their targets are as local as the windows: neighbouring threads hit the
 // same lines), so that the LDS pipeline carries 11 of the 39 dependent reads and the vector-memory pipeline the

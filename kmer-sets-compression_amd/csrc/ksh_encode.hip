@@ -815,6 +815,10 @@ __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 512 ? 8 : (kRcThreads >=
       }
       __syncthreads();
       KSH_PMARK(1, 4 + 7 * pass);  // slice index built
+      // (what every record of the pass reads from the batch: once, not per record -- the compiler cannot hoist an
+      // LDS read over the compare-and-swaps on `slots`)
+      const int p0_shift = bt.idx_shift[0];
+      const uint32_t p0_win_lo = uint32_t(bt.win_lo[0]);
 #pragma unroll 1
       for (int64_t r = r0 + tid; r < r1; r += kRcThreads) {
         const RcRecord<KeyT> rr = nxt;
@@ -823,10 +827,10 @@ __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 512 ? 8 : (kRcThreads >=
         const uint32_t mark = (rr.t << 1) | 1u;
         if (pass == 0) {
           const uint64_t gkey = gkey_top | (low << 2);  // the bucket key of Next(rx, A)
-          const int sl = int((gkey & seg_mask) >> bt.idx_shift[0]);
+          const int sl = int((gkey & seg_mask) >> p0_shift);
           for (int i = sidx[sl], end = sidx[sl + 1]; i < end; i++) {
             const uint64_t d = uint64_t(skeys[i]) - gkey;  // members: gkey .. gkey + 3
-            if (d < 4 && bt.win_lo[0] + i != int64_t(rr.t)) mark_hit(&slots[i], mark);
+            if (d < 4 && p0_win_lo + uint32_t(i) != rr.t) mark_hit(&slots[i], mark);
           }
         } else {
           const uint64_t tb = uint64_t(rr.key) >> low_bits;
@@ -921,13 +925,33 @@ __global__ __launch_bounds__(256) void k_fwd_bounds(DevSet<KeyT> set, int64_t n_
   }
 }
 
+// First position of [lo, hi) whose key is >= key (hi when there is none).  Halving form: the trip count depends on
+// the range's length alone -- the lanes of a wave that search the same bucket's part of a window leave the loop
+// together -- and a step is a read, a compare and a select.
 template <typename KeyT>
 __device__ __forceinline__ int lds_lower_bound(const KeyT* a, int lo, int hi, KeyT key) {
-  while (lo < hi) {
-    const int mid = (lo + hi) >> 1;
-    if (a[mid] < key) lo = mid + 1; else hi = mid;
+  int len = hi - lo;
+  if (len <= 0) return lo;
+  while (len > 1) {
+    const int half = len >> 1;
+    lo = a[lo + half - 1] < key ? lo + half : lo;
+    len -= half;
   }
-  return lo;
+  return lo + (a[lo] < key ? 1 : 0);
+}
+// The position of `key` in [lo, hi), or -1: the same search; the range's last key decides.
+template <typename KeyT>
+__device__ __forceinline__ int lds_find(const KeyT* a, int lo, int hi, KeyT key) {
+  int len = hi - lo;
+  if (len <= 0) return -1;
+  while (len > 1) {
+    const int half = len >> 1;
+    lo = a[lo + half - 1] < key ? lo + half : lo;
+    len -= half;
+  }
+  const KeyT at = a[lo];
+  if (at == key) return lo;
+  return (at < key && lo + 1 < hi && a[lo + 1] == key) ? lo + 1 : -1;
 }
 
 // KSH_FWD_DEBUG=1: how often the staged forward probe falls back to global probes (per k-mer and cause)
@@ -956,7 +980,10 @@ __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_
   __shared__ KeyT s_next[kFwdCapNext];
   __shared__ KeyT s_prev[4][kFwdCapPrev];
   __shared__ int64_t s_b[2 * kFwdBounds];     // this boundary's and the next one's records
-  __shared__ int64_t s_boff[6][kFwdSpan + 1];  // bucket offsets: ranges 0..4 from their first bucket on; [5]: the chunk's own
+  // where the buckets begin, in window coordinates (32-bit: the searches' bounds need no 64-bit clamps): for range r
+  // < 5 the position in its window of the first key of bucket fb[r] + j, clamped to [0, len[r]]; [5]: the chunk's own
+  // buckets relative to its first index
+  __shared__ int s_rel[6][kFwdSpan + 1];
   const int tid = threadIdx.x;
   const int64_t chunk = blockIdx.x;
   const int64_t t = chunk * kFwdChunk + tid;
@@ -973,16 +1000,11 @@ __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_
   KSH_PMARK(0, 1);  // the bound record has arrived
   const uint64_t x_first = uint64_t(s_b[10]), x_last = uint64_t(s_b[kFwdBounds + 11]);
   // first bucket of: the five ranges, the chunk itself
-  int64_t fb[6];
-  fb[0] = int64_t(kmer_next(x_first, k, 0) >> set.key_bits);
+  int fb[6];
+  fb[0] = int(kmer_next(x_first, k, 0) >> set.key_bits);
 #pragma unroll
-  for (int cc = 0; cc < 4; cc++) fb[1 + cc] = int64_t(kmer_prev(x_first, k, cc) >> set.key_bits);
-  fb[5] = int64_t(x_first >> set.key_bits);
-  if (tid < 6 * (kFwdSpan + 1)) {
-    const int r = tid / (kFwdSpan + 1), j = tid % (kFwdSpan + 1);
-    const int64_t b = fb[r] + j;
-    s_boff[r][j] = b <= set.n_buckets ? set.off[b] : set.n;
-  }
+  for (int cc = 0; cc < 4; cc++) fb[1 + cc] = int(kmer_prev(x_first, k, cc) >> set.key_bits);
+  fb[5] = int(x_first >> set.key_bits);
   // usable[r]: range r is staged (a range that wraps around a top base has hi < lo)
   bool usable[5];
   int len[5];
@@ -997,6 +1019,29 @@ __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_
   if ((x_first >> (2 * k - 2)) != (x_last >> (2 * k - 2))) {
     usable[0] = false;
     len[0] = 0;
+  }
+  if (tid < 6 * (kFwdSpan + 1)) {
+    const int r = tid / (kFwdSpan + 1), j = tid % (kFwdSpan + 1);
+    const int64_t b = int64_t(fb[r]) + j;
+    const int64_t at = b <= set.n_buckets ? set.off[b] : set.n;
+    int64_t rel;
+    if (r < 5) {
+      // (dynamic indexing of lo_of / len would put them in scratch: pick by comparison)
+      int64_t lo_r = lo_of[0];
+      int len_r = len[0];
+#pragma unroll
+      for (int q = 1; q < 5; q++)
+        if (r == q) {
+          lo_r = lo_of[q];
+          len_r = len[q];
+        }
+      rel = at - lo_r;
+      rel = rel < 0 ? 0 : (rel > len_r ? len_r : rel);
+    } else {
+      rel = at - chunk * kFwdChunk;
+      rel = rel < -(int64_t(1) << 30) ? -(int64_t(1) << 30) : (rel > (int64_t(1) << 30) ? (int64_t(1) << 30) : rel);
+    }
+    s_rel[r][j] = int(rel);
   }
   {
     // every load of the staging before the first LDS store: one round trip, not ten
@@ -1027,46 +1072,51 @@ __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_
   int64_t my_b = fb[5];
   {
     int j = 0;
-    while (j < kFwdSpan && s_boff[5][j + 1] <= t) j++;
+    while (j < kFwdSpan && s_rel[5][j + 1] <= tid) j++;
     my_b += j;
     if (j == kFwdSpan)
       while (set.off[my_b + 1] <= t) my_b++;
   }
   const uint64_t x = (uint64_t(my_b) << set.key_bits) | uint64_t(my_key);
-  if (revcomp(x, k) == x) *self_rc = 1;
+  // one reverse complement per k-mer: rc(Prev(x, c)) = Next(rc(x), 3 - c) is a shift and an or (the canonical tests of
+  // the four candidates used to be four more bit reversals of 64-bit words, a fifth of the thread's vector ALU work)
+  const uint64_t rx = revcomp(x, k);
+  const uint64_t rx_next = (rx << 2) & kmer_mask(k);
+  if (rx == x) *self_rc = 1;
   int cnt[2] = {0, 0};
   uint32_t single[2] = {kNone, kNone};
-  // [blo, bhi) of bucket b, from the offsets kept for range r; false when b is beyond them
-  const auto bucket_range = [&](int r, int64_t b, int64_t* blo, int64_t* bhi) {
-    const int64_t j = b - fb[r];
+  // the part [lo, hi) of window r that bucket b's keys take; false when b is beyond the buckets kept for r
+  const auto bucket_range = [&](int r, int b, int* lo, int* hi) {
+    const int j = b - fb[r];
     if (j < 0 || j >= kFwdSpan) return false;
-    *blo = s_boff[r][j];
-    *bhi = s_boff[r][j + 1];
+    *lo = s_rel[r][j];
+    *hi = s_rel[r][j + 1];
     return true;
   };
+  const uint32_t t32 = uint32_t(t);
+  uint32_t lo32[5];
+#pragma unroll
+  for (int r = 0; r < 5; r++) lo32[r] = uint32_t(lo_of[r]);
   // side 1: Next(x, .), neighbour as is
   {
     const uint64_t g0 = kmer_next(x, k, 0);
-    int64_t blo, bhi;
+    int lo, hi;
 #ifdef KSH_FWD_DEBUG
     atomicAdd(&g_fwd_dbg[0], 1ull);
     if (!usable[0]) atomicAdd(&g_fwd_dbg[1], 1ull);
-    else if (!bucket_range(0, int64_t(g0 >> set.key_bits), &blo, &bhi)) atomicAdd(&g_fwd_dbg[2], 1ull);
+    else if (!bucket_range(0, int(g0 >> set.key_bits), &lo, &hi)) atomicAdd(&g_fwd_dbg[2], 1ull);
     if (s_b[kFwdBounds + 5] - s_b[0] > kFwdCapNext) atomicAdd(&g_fwd_dbg[5], 1ull);
     if ((x_first >> (2 * k - 2)) != (x_last >> (2 * k - 2))) atomicAdd(&g_fwd_dbg[6], 1ull);
 #endif
-    if (usable[0] && bucket_range(0, int64_t(g0 >> set.key_bits), &blo, &bhi)) {
+    if (usable[0] && bucket_range(0, int(g0 >> set.key_bits), &lo, &hi)) {
       const KeyT gkey = KeyT(g0 & set.key_mask());
-      const int64_t hi0 = lo_of[0] + len[0];
-      const int lo = int((blo > lo_of[0] ? blo : lo_of[0]) - lo_of[0]);
-      const int hi = int((bhi < hi0 ? bhi : hi0) - lo_of[0]);
       if (lo < hi) {
         int i = lds_lower_bound(s_next, lo, hi, gkey);
-        for (; i < hi && uint64_t(s_next[i]) - uint64_t(gkey) < 4; i++) {
-          const int64_t idx = lo_of[0] + i;
-          if (idx == t) continue;
+        for (; i < hi && KeyT(s_next[i] - gkey) < KeyT(4); i++) {  // (gkey ends in base A: no wrap below it)
+          const uint32_t idx = lo32[0] + uint32_t(i);
+          if (idx == t32) continue;
           cnt[1]++;
-          single[1] = uint32_t(idx) << 1;
+          single[1] = idx << 1;
         }
       }
     } else {
@@ -1082,29 +1132,27 @@ __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     const uint64_t z = kmer_prev(x, k, c);
-    if (revcomp(z, k) < z) continue;
+    if ((rx_next | uint64_t(3 - c)) < z) continue;  // rc(z) < z: not canonical, cannot be in the set
     if (z == x) continue;
-    int64_t idx = -1;
-    int64_t blo, bhi;
+    int lo, hi;
 #ifdef KSH_FWD_DEBUG
     if (!usable[1 + c]) atomicAdd(&g_fwd_dbg[3], 1ull);
-    else if (!bucket_range(1 + c, int64_t(z >> set.key_bits), &blo, &bhi)) atomicAdd(&g_fwd_dbg[4], 1ull);
+    else if (!bucket_range(1 + c, int(z >> set.key_bits), &lo, &hi)) atomicAdd(&g_fwd_dbg[4], 1ull);
 #endif
-    if (usable[1 + c] && bucket_range(1 + c, int64_t(z >> set.key_bits), &blo, &bhi)) {
+    if (usable[1 + c] && bucket_range(1 + c, int(z >> set.key_bits), &lo, &hi)) {
       const KeyT zkey = KeyT(z & set.key_mask());
-      const int64_t hi0 = lo_of[1 + c] + len[1 + c];
-      const int lo = int((blo > lo_of[1 + c] ? blo : lo_of[1 + c]) - lo_of[1 + c]);
-      const int hi = int((bhi < hi0 ? bhi : hi0) - lo_of[1 + c]);
-      if (lo < hi) {
-        const int i = lds_lower_bound(s_prev[c], lo, hi, zkey);
-        if (i < hi && s_prev[c][i] == zkey) idx = lo_of[1 + c] + i;
+      const int i = lds_find(s_prev[c], lo, hi, zkey);
+      if (i >= 0) {
+        cnt[0]++;
+        single[0] = (lo32[1 + c] + uint32_t(i)) << 1;
       }
     } else {
-      idx = set.find(z);
+      const int64_t idx = set.find(z);
+      if (idx >= 0) {
+        cnt[0]++;
+        single[0] = uint32_t(idx) << 1;
+      }
     }
-    if (idx < 0) continue;
-    cnt[0]++;
-    single[0] = uint32_t(idx) << 1;
   }
   KSH_PMARK(0, 5);    // Prev side done
   const uint32_t r[2] = {rc.x, rc.y};

@@ -1097,9 +1097,14 @@ __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_
   uint32_t lo32[5];
 #pragma unroll
   for (int r = 0; r < 5; r++) lo32[r] = uint32_t(lo_of[r]);
+  // candidates whose range is not staged (a range that wraps a top base, overflows its window or spans too many
+  // buckets: about a seventh of the k-mers of a canonical set) are probed in global memory AFTER the staged
+  // searches, all of a wave's pending Prev candidates in the same trips of one loop -- at their five separate
+  // places a wave ran each fall-back whenever any of its lanes needed it
+  uint32_t pend = 0;  // bit c: Prev(x, c); bit 4: the Next group
+  const uint64_t g0 = kmer_next(x, k, 0);
   // side 1: Next(x, .), neighbour as is
   {
-    const uint64_t g0 = kmer_next(x, k, 0);
     int lo, hi;
 #ifdef KSH_FWD_DEBUG
     atomicAdd(&g_fwd_dbg[0], 1ull);
@@ -1120,11 +1125,7 @@ __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_
         }
       }
     } else {
-      set.for_group4(g0, [&](int64_t idx) {
-        if (idx == t) return;
-        cnt[1]++;
-        single[1] = uint32_t(idx) << 1;
-      });
+      pend |= 16u;
     }
   }
   KSH_PMARK(0, 4);    // Next side done
@@ -1147,11 +1148,24 @@ __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_
         single[0] = (lo32[1 + c] + uint32_t(i)) << 1;
       }
     } else {
-      const int64_t idx = set.find(z);
-      if (idx >= 0) {
-        cnt[0]++;
-        single[0] = uint32_t(idx) << 1;
-      }
+      pend |= 1u << c;
+    }
+  }
+  if (pend & 16u)
+    set.for_group4(g0, [&](int64_t idx) {
+      if (idx == t) return;
+      cnt[1]++;
+      single[1] = uint32_t(idx) << 1;
+    });
+  pend &= 15u;
+#pragma unroll 1
+  while (pend) {
+    const int c = __ffs(int(pend)) - 1;
+    pend &= pend - 1;
+    const int64_t idx = set.find(kmer_prev(x, k, c));
+    if (idx >= 0) {
+      cnt[0]++;
+      single[0] = uint32_t(idx) << 1;
     }
   }
   KSH_PMARK(0, 5);    // Prev side done

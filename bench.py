@@ -114,6 +114,10 @@ def main():
     ap.add_argument("--lanes", type=int, default=0,
                     help="independent encodes / decodes of a build on this many HIP streams at once "
                          "(ksh_ctx_set_lanes; 0 = the library's default, 1 = one stream)")
+    ap.add_argument("--owned", action="store_true",
+                    help="with --gpus 1: the owner-sharded build (ksh_kss_build_owned) over a ONE-rank RCCL communicator "
+                         "instead of ksh_kss_build -- what the multi-GPU path costs on one GPU (its control loop on "
+                         "samples, the deferred merges), for the N-GPU model's terms")
     ap.add_argument("--dump-trace", default="",
                     help="write the last build's merge sequence, node sizes and phase times to this file "
                          "(input of tools/owned_schedule.py)")
@@ -139,10 +143,15 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    owned = world > 1 or args.owned
+    if owned:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world == 1:
+            os.environ.setdefault("MASTER_PORT", "29591")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -176,10 +185,10 @@ def main():
     torch.cuda.synchronize()
     t_inputs = time.perf_counter() - t0
 
-    comm = capi.Comm(ctx, dist, coll_dev) if world > 1 else None     # one RCCL communicator for all builds
+    comm = capi.Comm(ctx, dist, coll_dev) if owned else None     # one RCCL communicator for all builds
 
     def build():
-        if world == 1:
+        if not owned:
             return capi.DeviceKmerSetSet(ctx, compacts, ids, max_iterations=args.max_iterations)
         return capi.OwnedKmerSetSet(ctx, compacts, ids, dist, coll_dev, max_iterations=args.max_iterations,
                                     owners=owners, comm=comm)
@@ -220,7 +229,7 @@ def main():
     timers_timed, excl_wall = timers, None
     st = kss.stats()                 # (of the last TIMED build: phases, encode counts, SPSS sizes)
     it, cp, imp = kss.trace()
-    if world == 1 and lanes_used != 1:
+    if not owned and lanes_used != 1:
         kss.close()
         ctx.set_lanes(1)
         ctx.enable_timing(1)
@@ -244,7 +253,7 @@ def main():
     n_proc = st["n_processed"]
     value = n_proc * args.steps / elapsed / 1e6
     multi_gpu = None
-    if world > 1:
+    if owned:
         cs = kss.comm_stats()
         v = torch.tensor([st["n_encodes"], st["n_encoded_kmers"], cs["p2p_sets"], cs["p2p_bytes_sent"],
                           cs["gather_bytes"]], dtype=torch.int64, device=coll_dev)
@@ -261,7 +270,7 @@ def main():
                      "p2p_bytes_sent_per_rank": [r[3] for r in rows], "allgather_bytes_per_rank": [r[4] for r in rows],
                      "note": "last timed build"}
 
-    if args.dump_trace and rank == 0 and world == 1:
+    if args.dump_trace and rank == 0 and not owned:
         n_in = len(compacts)
         node_sizes = [kss.node_size(i) for i in range(kss.size())]
         # sizes of (child, j', k') right after every merge: replay the trace backwards from the final sizes
@@ -294,7 +303,7 @@ def main():
             if got != (want.n_keys, ctx.set_hash(want)):
                 bad.append(i)
             del want
-        if world > 1:
+        if owned:
             b = torch.tensor([len(bad), checked], dtype=torch.int64, device=coll_dev)
             dist.all_reduce(b)
             n_bad, checked = int(b[0].item()), int(b[1].item())
@@ -317,14 +326,14 @@ def main():
         "note": "from the last timed build; bytes = sum over nodes of ceil(2 * Weight / 8) + StreamVByte-0124 "
                 "size of the lengths (SURVEY.md 8d, metric 2)",
     }
-    if world > 1:
+    if owned:
         lb = torch.tensor([st["length_bytes"]], dtype=torch.int64, device=coll_dev)
         dist.all_reduce(lb)       # a node's lengths live on the rank that holds its SPSS
         spss["bytes_per_kmer"] = (st["packed_bytes"] + int(lb.item())) / total
 
     # ---- pair-merge block (configs[1]; the round-1 headline, kept as an extra key)
     pair_merge = None
-    if rank == 0 and world == 1 and not args.no_pair_merge:
+    if rank == 0 and not owned and not args.no_pair_merge:
         kss.close()
         kss = None
         pm_sets = [synth_torch.device_set(g, km) for km in synth_torch.phylogeny_sets(k, 4, int(1e7), 2, dev)]
@@ -360,7 +369,7 @@ def main():
 
     # ---- CPU baseline: the oracle's port of the loop, threads as the reference has them
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and not owned and not args.no_cpu_baseline:
         # the copy that is timed is compiled here, on the host it runs on, with the reference's release
         # flags (CMakeLists.txt:5); the portable build the tests load is the fall-back
         import subprocess
@@ -502,7 +511,7 @@ def main():
                 "iterations": int(it.shape[0]), "nodes": st["nodes"],
                 "input_build_s": t_inputs, "first_build_wall_s": first_wall,
                 "sum_input_mkmers_per_s": total * args.steps / elapsed / 1e6,
-                "parallelism": "1 GPU" if world == 1 else
+                "parallelism": "1 GPU" if not owned else
                                "1 process per GPU, owner-sharded sets (contiguous blocks of %d), replicated control "
                                "loop on the all-gathered 2 %% samples, merges and encodes on the owner of j, %s "
                                "all-gather / send-recv on device buffers" % (n_sets // world, comm.kind.upper()),
@@ -546,7 +555,7 @@ def main():
         kss.close()
     if comm is not None:
         comm.close()
-    if world > 1:
+    if owned:
         dist.barrier()
         dist.destroy_process_group()
     ctx.close()

@@ -717,25 +717,38 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
     }
   }
 
-  // ---- inputs: decoded by their owners only
-  for (int32_t i = 0; i < n_inputs; i++) {
-    KssCompact c;
-    c.holder = k->owner[size_t(i)];
-    k->sets.emplace_back();
-    if (c.holder == rank) {
-      if (!inputs[i].d_words && inputs[i].n_bases > 0)
-        poison(k, fail(KSH_INVALID_ARGUMENT, "rank %d owns input %d but was not given its container", rank, i));
-      c.words = const_cast<uint64_t*>(inputs[i].d_words);
-      c.lens = const_cast<uint32_t*>(inputs[i].d_lens);
-      c.n_strings = inputs[i].n_strings;
-      c.n_bases = inputs[i].n_bases;
-      c.owned = false;
-      KSH_LOCAL(k, ksh_spss_size(ctx, g, &inputs[i], &c.size));
-      PhaseTimer pt(k, 0);
-      KSH_LOCAL(k, decode_to_set(ctx, g, &inputs[i], k->canonical, &k->sets.back()));
-      if (!alive(k)) free_set(ctx, &k->sets.back());
+  // ---- inputs: decoded by their owners only, several at once on the rank's lanes (§3.7)
+  {
+    std::vector<size_t> mine;
+    int64_t most_bases = 0;
+    for (int32_t i = 0; i < n_inputs; i++) {
+      KssCompact c;
+      c.holder = k->owner[size_t(i)];
+      k->sets.emplace_back();
+      if (c.holder == rank) {
+        if (!inputs[i].d_words && inputs[i].n_bases > 0)
+          poison(k, fail(KSH_INVALID_ARGUMENT, "rank %d owns input %d but was not given its container", rank, i));
+        c.words = const_cast<uint64_t*>(inputs[i].d_words);
+        c.lens = const_cast<uint32_t*>(inputs[i].d_lens);
+        c.n_strings = inputs[i].n_strings;
+        c.n_bases = inputs[i].n_bases;
+        c.owned = false;
+        mine.push_back(size_t(i));
+        most_bases = std::max(most_bases, inputs[i].n_bases);
+      }
+      k->compacts.push_back(c);
     }
-    k->compacts.push_back(c);
+    PhaseTimer pt(k, 0);
+    if (alive(k) && !mine.empty())
+      poison(k, run_on_lanes(
+                    ctx, largest_first(mine, [&](size_t i) { return inputs[i].n_bases; }),
+                    size_t(most_bases) * size_t(g->key_bytes + 3) + (size_t(256) << 20), [](ksh_ctx*) { return int(KSH_OK); },
+                    [&](ksh_ctx* lane, size_t i) {
+                      KSH_TRY(ksh_spss_size(lane, g, &inputs[i], &k->compacts[i].size));
+                      return decode_to_set(lane, g, &inputs[i], k->canonical, &k->sets[i]);
+                    }));
+    if (!alive(k))
+      for (size_t i : mine) free_set(ctx, &k->sets[i]);
   }
   {
     std::vector<int64_t> send(3 * size_t(n_inputs), -1), recv;

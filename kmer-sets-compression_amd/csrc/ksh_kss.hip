@@ -952,7 +952,10 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
   std::vector<double> lag(size_t(world), 0.0);
 
   // encodes the stale nodes this rank owns (after the deal); fills stale / send
-  const auto encode_stale = [&](Pending* pd) {
+  // protocol_only: the check before this one is already known to stop the loop (peek_stop below), so whatever
+  // is encoded here goes with the roll-back -- the rank still takes part in every hand-over of the deal (its
+  // peers may not know yet and are waiting for its sends and receives) but skips the encodes themselves
+  const auto encode_stale = [&](Pending* pd, bool protocol_only) {
     PhaseTimer pt(k, 3);
     pd->stale.clear();
     for (size_t q = 0; q < k->compacts.size(); q++)
@@ -1015,7 +1018,7 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
       const size_t node = pd->stale[q];
       KssCompact c;
       c.valid = false;
-      if (alive(k) && k->sets[node].off) {  // (a failed rank's slots stay -1; its status travels with them)
+      if (!protocol_only && alive(k) && k->sets[node].off) {  // (a failed rank's slots stay -1; its status travels with them)
         poison(k, encode_set(ctx, g, k->sets[node], k->canonical, &c));
         if (!alive(k)) c = KssCompact{}, c.valid = false;
       }
@@ -1043,7 +1046,7 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
         }
       std::vector<KssCompact> done(n_tasks);
       for (KssCompact& c : done) c.valid = false;
-      if (alive(k) && !mine.empty())
+      if (!protocol_only && alive(k) && !mine.empty())
         poison(k, run_on_lanes(
                       ctx, largest_first(mine, [&](size_t q) { return k->sets[pd->stale[q]].n; }),
                       encode_scratch_bytes(g, n_max), [&](ksh_ctx* lane) { return encode_reserve(lane, g, n_max); },
@@ -1120,6 +1123,32 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
       return fail(KSH_INTERNAL, "rank %d failed; every rank gives the build up", failed);
     }
     return KSH_OK;
+  };
+
+  // Has the exchange of this unresolved check arrived already, and does it stop the loop?  (No state is touched;
+  // resolve() takes the same decision from the same numbers afterwards.)  A rank that gets to the next check after
+  // the slowest rank of this one -- the slowest itself, or any rank when there is only one -- sees it and spares
+  // itself the next check's encodes, which the roll-back would throw away: 24 encodes, 0.04 s of the 64 x 10^8 build.
+  const auto peek_stop = [&](const Pending* pd) {
+    const ksh_kss::Exchange& x = k->xchg[pd->id & 1];
+    if (hipEventQuery(x.arrived) != hipSuccess) {
+      (void)hipGetLastError();  // (hipErrorNotReady is no error)
+      return false;
+    }
+    const size_t count = pd->send.size(), vals = count - 1;
+    for (size_t r = 0; r < size_t(world); r++)
+      if (x.h_recv[r * count + vals] != 0) return false;  // a rank has failed: resolve() reports it
+    const std::vector<KssCompact>& at_check = pd->compacts;
+    std::vector<int64_t> bases(at_check.size(), -1);
+    for (size_t q = 0; q < pd->stale.size(); q++) {
+      const int64_t* from = x.h_recv + size_t(at_check[pd->stale[q]].holder) * count + 3 * q;
+      if (from[0] < 0 || from[1] < 0 || from[2] < 0) return false;
+      bases[pd->stale[q]] = from[1];
+    }
+    int64_t updated = 0;
+    for (size_t q = 0; q < at_check.size(); q++) updated += bases[q] >= 0 ? bases[q] : at_check[q].n_bases;
+    const float improvement = static_cast<float>(total_spss_weight - updated) / total_spss_weight;
+    return improvement <= improvement_threshold;
   };
 
   // the decision of an unresolved check; *stop_out: the loop ends at that check
@@ -1269,7 +1298,7 @@ static int build_owned(ksh_kss* k, const ksh_spss_view* inputs, int32_t n_inputs
       Pending next;
       next.id = ++n_checks;
       next.iteration = i;
-      KSH_TRY(encode_stale(&next));
+      KSH_TRY(encode_stale(&next, lookahead && pend.active && peek_stop(&pend)));
       KSH_TRY(start_exchange(&next));
       if (pend.active) {
         bool stop = false;

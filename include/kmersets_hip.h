@@ -316,14 +316,15 @@ enum {
   KSH_ROUTE_RC_64 = 1 << 4,
   KSH_ROUTE_RC_BATCHED = 1 << 5,         /* some group's ranges took several batches of its LDS window */
   KSH_ROUTE_SCATTER_TWO_LEVEL = 1 << 6,  /* k_rc_scatter_l1 / _l2 instead of k_rc_scatter */
-  KSH_ROUTE_FWD_STAGED = 1 << 7,         /* k_adj_fwd_staged instead of k_adj_fwd */
+  KSH_ROUTE_FWD_STAGED = 1 << 7,         /* k_adj_fwd_staged (KSH_FWD=staged) instead of k_adj_fwd */
   KSH_ROUTE_RANK_ONE_LAUNCH = 1 << 8,    /* all ruler walkers in one launch (mirror images racing) */
   KSH_ROUTE_HEADS_ONE_LAUNCH = 1 << 9,   /* the same for the chain-start walkers */
   KSH_ROUTE_JUMP_TWO_LEVEL = 1 << 10,    /* pointer jumping over the level-2 rulers (k_l2_*) */
   KSH_ROUTE_RANK_STAMPED = 1 << 11,      /* the stamping walks (sets with a non-branching loop, KSH_RANK=stamp) */
   KSH_ROUTE_EMIT_LOGS = 1 << 12,         /* strings written from the ranking walks' logs */
   KSH_ROUTE_LONG_STRETCHES = 1 << 13,    /* ... and some stretch outgrew its log (the long list) */
-  KSH_ROUTE_MATCH_MORE_ROUNDS = 1 << 14  /* the matching needed more than its first batch of rounds */
+  KSH_ROUTE_MATCH_MORE_ROUNDS = 1 << 14, /* the matching needed more than its first batch of rounds */
+  KSH_ROUTE_FWD_TARGETS = 1 << 15        /* k_adj_fwd_targets: forward probes marked at their targets, one search per k-mer */
 };
 int ksh_spss_encode_routes(ksh_ctx* ctx, int64_t* routes);
 /* Frees the current plan's device memory (also done by the next plan / ctx_destroy). */

@@ -1180,6 +1180,291 @@ __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_
   KSH_PMARK(0, 6);    // searched and stored (the first wave)
 }
 
+// ---------------------------------------------------------------------------------- E1d
+// The forward half with ONE search per k-mer (round 4).  An edge "as is" is seen from both of its ends like an
+// edge through a reverse complement: y = Next(x, c) iff x = Prev(y, x's top base).  So the four Prev(x, c)
+// searches of k_adj_fwd_staged find nothing that the Next searches of other k-mers do not find as well -- it is
+// enough that every Next probe leaves its mark at the TARGET, as k_adj_rc's probes do.  The cut of the work that
+// makes the targets local: a workgroup owns a window W of kTgtChunk consecutive k-mers of the set, cut where
+// the (K-1)-base prefix changes, i.e. all k-mers whose prefix w lies in [v, v'), and it streams the k-mers Q
+// whose SUFFIX lies in [v, v'): four ranges of the set, one per top base a, [a v, a v').  Every Next(q, .) of a
+// q in Q is in W or nowhere, and nobody else's is.  W is staged in LDS with a mark per key (8 KB at 4-byte keys
+// against the 20 KB of five windows); every q searches once, counts what it finds (its side 1) and marks the
+// found (their side 0: none -> q -> several); the marks are combined with rc0 and stored by the window's owner.
+// Per k-mer: one staged key and one streamed key instead of six staged keys, one search instead of five, no
+// reverse complement (a target found in the set IS canonical), no range that overflows its window.  Only the
+// counts of Q vary: a canonical set keeps a k-mer that starts with T^j only if it ends in A^j, so the window
+// over the last prefixes of the set spans a wide range of them and its stream is long (measured: 1.8 x 10^5 k-mers
+// for the last window of a 10^8-k-mer genome set, 473 us of one workgroup at the end of a 1.37 ms kernel; a
+// median window streams 800).  A window whose stream is longer than kTgtStreamMax is therefore cut again, evenly in
+// the prefix range (its stream is even there, its staged keys are not): k_tgt_split counts the parts and
+// k_tgt_subcuts searches their bounds, both on the device; the parts run as workgroups behind the windows'.
+constexpr int kTgtChunk = 1024;
+constexpr int kTgtThreads = 512;
+constexpr int kTgtStreamMax = 2048;
+constexpr int kTgtSpan = 16;    // bucket offsets kept per range
+constexpr int kTgtBounds = 6;   // per cut: [0] index b of the cut, [1] v = the (K-1)-base prefix there, [2 + a] first index >= a v
+struct TgtTask {
+  int64_t c;     // the window
+  int j, m;      // part j of m (j = 1 .. m - 1; part 0 is the window's own workgroup)
+};
+
+// Eight lanes per cut c (c = 0 .. n_chunks): lanes 0..4 read the k-mers around index c * kTgtChunk and agree on
+// the cut (the first index >= c * kTgtChunk where the prefix changes: at most 3 further, a prefix has four
+// k-mers), lanes 0..3 then search the four stream bounds.
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_tgt_bounds(DevSet<KeyT> set, int64_t n_chunks, int64_t* __restrict__ bounds) {
+  const int64_t id = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t c = id >> 3;
+  const int j = int(id & 7);
+  const bool live = c <= n_chunks;
+  const int k = set.k;
+  const int64_t base = (live ? c : 0) * kTgtChunk;
+  // prefix of the k-mer at base - 1 + j (j = 0 .. 4); past the end: none
+  const int64_t p = base - 1 + j;
+  uint64_t pref = ~uint64_t(0);
+  if (live && j < 5 && p >= 0 && p < set.n) pref = set.kmer(p) >> 2;
+  const int lane0 = int(threadIdx.x & 63) & ~7;
+  const uint64_t before = __shfl(pref, lane0, 64);  // the k-mer in front of the nominal cut
+  // (lanes 1..4: index base .. base + 3) the cut is the first of them that is past the end or starts a new prefix
+  const bool breaks = j >= 1 && j < 5 && (p >= set.n || pref != before);
+  const unsigned long long m = __ballot(breaks) >> lane0;
+  const int first = __ffsll((long long)(m & 0x1Eull)) - 1;  // 1 .. 4 (a prefix has at most four k-mers)
+  int64_t b = base - 1 + first;
+  uint64_t v = __shfl(pref, lane0 + (first > 0 ? first : 0), 64);
+  if (c == 0) {
+    b = 0;
+    v = 0;
+  } else if (b >= set.n) {
+    b = set.n;
+    v = uint64_t(1) << (2 * k - 2);
+  }
+  if (!live) return;
+  if (j < 4) bounds[kTgtBounds * c + 2 + j] = lower_bound_kmer(set, (uint64_t(j) << (2 * k - 2)) + v);
+  if (j == 4) {
+    bounds[kTgtBounds * c] = b;
+    bounds[kTgtBounds * c + 1] = int64_t(v);
+  }
+}
+
+// One thread per window: rec[c] = its two cuts when its stream is short; else part 0 keeps the first cut, the
+// other parts become tasks (their workgroups: n_chunks + e, e from the counter) and k_tgt_subcuts fills the rest.
+__global__ __launch_bounds__(256) void k_tgt_split(const int64_t* __restrict__ cuts, int64_t n_chunks, int64_t cap,
+                                                    int64_t* __restrict__ rec, TgtTask* __restrict__ task,
+                                                    int* __restrict__ n_extra) {
+  const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  if (c >= n_chunks) return;
+  const int64_t* lo = cuts + kTgtBounds * c;
+  const int64_t* hi = lo + kTgtBounds;
+  int64_t stream = 0;
+#pragma unroll
+  for (int a = 0; a < 4; a++) stream += hi[2 + a] - lo[2 + a];
+  int64_t* r = rec + 2 * kTgtBounds * c;
+#pragma unroll
+  for (int i = 0; i < kTgtBounds; i++) r[i] = lo[i];
+  const int64_t m = (stream + kTgtStreamMax - 1) / kTgtStreamMax;
+  int64_t e = 0;
+  if (m > 1) {
+    e = int64_t(atomicAdd(n_extra, int(m - 1)));
+    if (e + m - 1 > cap) {  // (cannot happen: the streams add up to n, the parts beyond the first to less than n / kTgtStreamMax)
+      atomicSub(n_extra, int(m - 1));
+      e = -1;
+    }
+  }
+  if (m <= 1 || e < 0) {
+#pragma unroll
+    for (int i = 0; i < kTgtBounds; i++) r[kTgtBounds + i] = hi[i];
+    return;
+  }
+  for (int64_t j = 1; j < m; j++) task[e + j - 1] = TgtTask{c, int(j), int(m)};
+}
+
+// Eight lanes per task: the cut at v_c + j (v_c+1 - v_c) / m -- five searches -- is where part j begins and part
+// j - 1 ends.
+template <typename KeyT>
+__global__ __launch_bounds__(256) void k_tgt_subcuts(DevSet<KeyT> set, const int64_t* __restrict__ cuts, int64_t n_chunks,
+                                                      int64_t cap, const TgtTask* __restrict__ task,
+                                                      const int* __restrict__ n_extra, int64_t* __restrict__ rec) {
+  const int64_t id = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+  const int64_t e = id >> 3;
+  const int lane = int(id & 7);
+  const int64_t count = *n_extra < cap ? int64_t(*n_extra) : cap;
+  if (e >= count || lane > 4) return;
+  const TgtTask t = task[e];
+  const int k = set.k;
+  const uint64_t v0 = uint64_t(cuts[kTgtBounds * t.c + 1]), v1 = uint64_t(cuts[kTgtBounds * (t.c + 1) + 1]);
+  const uint64_t dv = v1 - v0, m = uint64_t(t.m), j = uint64_t(t.j);
+  const uint64_t v = v0 + (dv / m) * j + ((dv % m) * j) / m;  // (no overflow: dv < 2^62, m and j < 2^31)
+  const int64_t at = lane < 4 ? lower_bound_kmer(set, (uint64_t(lane) << (2 * k - 2)) + v) : lower_bound_kmer(set, v << 2);
+  const int slot = lane < 4 ? 2 + lane : 0;
+  int64_t* mine = rec + 2 * kTgtBounds * (n_chunks + e);                                  // part j begins here
+  int64_t* before = rec + 2 * kTgtBounds * (t.j == 1 ? t.c : n_chunks + e - 1) + kTgtBounds;  // part j - 1 ends here
+  mine[slot] = at;
+  before[slot] = at;
+  if (lane == 4) {
+    mine[1] = int64_t(v);
+    before[1] = int64_t(v);
+  }
+  if (t.j == t.m - 1) {  // the last part ends where the window does
+    const int64_t* hi = cuts + kTgtBounds * (t.c + 1);
+    mine[kTgtBounds + slot] = hi[slot];
+    if (lane == 4) mine[kTgtBounds + 1] = hi[1];
+  }
+}
+
+__device__ __forceinline__ uint32_t side_verdict(uint32_t direct, uint32_t through_rc) {
+  const int total = (direct == kNone ? 0 : (direct == kMulti ? 2 : 1)) + (through_rc == kNone ? 0 : (through_rc == kMulti ? 2 : 1));
+  return total == 0 ? kNone : (total > 1 ? kMulti : (direct != kNone ? direct : through_rc));
+}
+
+template <typename KeyT>
+__global__ __launch_bounds__(kTgtThreads, 8) void k_adj_fwd_targets(DevSet<KeyT> set, const int64_t* __restrict__ rec,
+                                                                   int64_t n_chunks, const int* __restrict__ n_extra,
+                                                                   const uint32_t* __restrict__ rc0,
+                                                                   const uint32_t* __restrict__ rc1,
+                                                                   uint32_t* __restrict__ nbr, int* __restrict__ self_rc) {
+  constexpr int kRounds = (kTgtChunk + 3 + kTgtThreads - 1) / kTgtThreads;  // staging rounds of the window
+  __shared__ KeyT s_keys[kRounds * kTgtThreads];
+  __shared__ uint32_t s_slot[kRounds * kTgtThreads];
+  __shared__ int64_t s_b[2 * kTgtBounds];
+  // where the buckets begin, relative to the range: [a] for the stream of top base a, [4] for the window
+  __shared__ int s_rel[5][kTgtSpan + 1];
+  const int tid = threadIdx.x;
+  const int64_t chunk = blockIdx.x;
+  const int k = set.k;
+  KSH_PMARK(0, 0);
+  if (chunk >= n_chunks && chunk - n_chunks >= int64_t(*n_extra)) return;  // a part nobody needed (uniform: no barrier yet)
+  if (tid < 2 * kTgtBounds) s_b[tid] = rec[2 * kTgtBounds * chunk + tid];
+  __syncthreads();
+  KSH_PMARK(0, 1);  // the cuts have arrived
+  const int64_t b = s_b[0];
+  const int len_w = int(s_b[kTgtBounds] - b);
+  const uint64_t v = uint64_t(s_b[1]);
+  // first bucket of: the stream of top base a (where a v lies), the window (where v A lies)
+  const auto first_bucket = [&](int r) {
+    return int((r == 4 ? (v << 2) : ((uint64_t(r) << (2 * k - 2)) | v)) >> set.key_bits);
+  };
+  const int fb_w = first_bucket(4);
+  if (tid < 5 * (kTgtSpan + 1)) {
+    const int r = tid / (kTgtSpan + 1), j = tid % (kTgtSpan + 1);
+    const int64_t bb = int64_t(first_bucket(r)) + j;
+    const int64_t at = bb <= set.n_buckets ? set.off[bb] : set.n;
+    const int64_t lo_r = r == 4 ? b : s_b[2 + r];
+    const int64_t len_r = r == 4 ? int64_t(len_w) : s_b[kTgtBounds + 2 + r] - lo_r;
+    int64_t rel = at - lo_r;
+    rel = rel < 0 ? 0 : (rel > len_r ? len_r : rel);
+    s_rel[r][j] = int(rel);
+  }
+  // the window, and what reaches its k-mers' side 0 through a reverse complement: all loads before the first store
+  KeyT wk[kRounds];
+  uint32_t wr[kRounds];
+#pragma unroll
+  for (int u = 0; u < kRounds; u++) {
+    const int i = tid + u * kTgtThreads;
+    wr[u] = kNone;
+    if (i < len_w) {
+      wk[u] = set.keys[b + i];
+      wr[u] = rc0[b + i];
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < kRounds; u++) {
+    const int i = tid + u * kTgtThreads;
+    if (i < len_w) s_keys[i] = wk[u];
+    s_slot[i] = kNone;
+  }
+  KSH_PMARK(0, 2);  // this wave's window loads have arrived and are in LDS
+  // the stream: four ranges one behind the other
+  const int64_t q0 = s_b[2], q1 = s_b[3], q2 = s_b[4], q3 = s_b[5];
+  const int c1 = int(s_b[kTgtBounds + 2] - q0), c2 = c1 + int(s_b[kTgtBounds + 3] - q1), c3 = c2 + int(s_b[kTgtBounds + 4] - q2);
+  const int total = c3 + int(s_b[kTgtBounds + 5] - q3);
+  const uint32_t b32 = uint32_t(b);
+  const bool even_k = (k & 1) == 0;
+  __syncthreads();
+  KSH_PMARK(0, 3);
+  // (position idx of the stream = index p of the set, in range a at r)
+  const auto place = [&](int idx, int* a, int* r) {
+    *a = (idx >= c1 ? 1 : 0) + (idx >= c2 ? 1 : 0) + (idx >= c3 ? 1 : 0);
+    *r = idx - (*a == 0 ? 0 : (*a == 1 ? c1 : (*a == 2 ? c2 : c3)));
+    return (*a == 0 ? q0 : (*a == 1 ? q1 : (*a == 2 ? q2 : q3))) + *r;
+  };
+  // the next k-mer of this thread is requested before this one's search
+  KeyT key_next = 0;
+  uint32_t rc_next = kNone;
+  if (tid < total) {
+    int a, r;
+    const int64_t p = place(tid, &a, &r);
+    key_next = set.keys[p];
+    rc_next = rc1[p];
+  }
+#pragma unroll 1
+  for (int idx = tid; idx < total; idx += kTgtThreads) {
+    int a, r;
+    const int64_t p = place(idx, &a, &r);
+    const KeyT key = key_next;
+    const uint32_t through_rc = rc_next;
+    if (idx + kTgtThreads < total) {
+      int a2, r2;
+      const int64_t p2 = place(idx + kTgtThreads, &a2, &r2);
+      key_next = set.keys[p2];
+      rc_next = rc1[p2];
+    }
+    // its bucket: the range's first, or one of the next few
+    int64_t my_b;
+    {
+      const int* rel = s_rel[a];
+      int j = 0;
+      while (j < kTgtSpan && rel[j + 1] <= r) j++;
+      my_b = j < kTgtSpan ? int64_t(first_bucket(a)) + j : set.bucket_of(p);
+    }
+    const uint64_t x = (uint64_t(my_b) << set.key_bits) | uint64_t(key);
+    if (even_k && revcomp(x, k) == x) *self_rc = 1;
+    const uint64_t g0 = kmer_next(x, k, 0);
+    const uint32_t p32 = uint32_t(p);
+    int cnt = 0;
+    uint32_t single = kNone;
+    const int jw = int(g0 >> set.key_bits) - fb_w;
+    if (jw >= 0 && jw < kTgtSpan) {
+      const int lo = s_rel[4][jw], hi = s_rel[4][jw + 1];
+      const KeyT gkey = KeyT(g0 & set.key_mask());
+      if (lo < hi) {
+        int i = lds_lower_bound(s_keys, lo, hi, gkey);
+        for (; i < hi && KeyT(s_keys[i] - gkey) < KeyT(4); i++) {  // (gkey ends in base A: no wrap below it)
+          const uint32_t at = b32 + uint32_t(i);
+          if (at == p32) continue;  // Next(x, c) == x
+          cnt++;
+          single = at << 1;
+          mark_hit(&s_slot[i], p32 << 1);
+        }
+      }
+    } else {
+      // the window spans more buckets than the table holds (a sparse stretch of the set): found in global memory,
+      // marked in the window all the same
+      set.for_group4(g0, [&](int64_t at) {
+        if (at == p) return;
+        cnt++;
+        single = uint32_t(at) << 1;
+        const int64_t i = at - b;
+        if (i >= 0 && i < len_w) mark_hit(&s_slot[i], p32 << 1);
+      });
+    }
+    const uint32_t direct = cnt == 0 ? kNone : (cnt == 1 ? single : kMulti);
+    nbr[2 * p + 1] = side_verdict(direct, through_rc);
+  }
+  KSH_PMARK(0, 4);  // the first wave's share of the stream
+  __syncthreads();
+  KSH_PMARK(0, 5);  // everybody's
+#pragma unroll
+  for (int u = 0; u < kRounds; u++) {
+    const int i = tid + u * kTgtThreads;
+    if (i < len_w) nbr[2 * (b + i)] = side_verdict(s_slot[i], wr[u]);
+  }
+  KSH_PMARK(0, 6);
+#ifdef KSH_TRACE
+  if (g_probe_trace && tid == 0 && chunk < g_probe_trace_rows) g_probe_trace[chunk * 16 + 7] = (unsigned long long)(total);
+#endif
+}
+
 // (Measured and dropped, round 3: workgroups that STAY and take chunks in turn with only the next chunk's bound
 // record on its way -- the light form of the software pipeline below, to take the first of a chunk's two
 // round trips off its path: the loop's state does not fit the 64 vector registers that four workgroups per
@@ -2964,7 +3249,7 @@ struct EncCtl {
   unsigned long long sc_used; // k_loop_cut's scratch cursor
   unsigned int long_count[2]; // WalkLog::long_count
   int rc_batched;             // k_adj_rc: a group's ranges took more than one batch of its LDS window
-  int pad2;
+  int tgt_extra;              // k_tgt_split: parts beyond the first of the windows with long streams
   int jump_live[kJumpRoundsMax + 1];
   int match_live[kMatchBatch + 1];
   int walk_live[kWalkRoundsMax + 1];
@@ -3296,12 +3581,34 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       else
         hipLaunchKernelGGL((k_adj_rc<KeyT, 64>), dim3(unsigned(ng)), dim3(64), rc_lds, st, set, gbits, goff,
                            rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched);
-      static const bool fwd_probe = [] {
+      // KSH_FWD=probe: the forward half in place; =staged: round 3's five staged windows per chunk; default: one
+      // window per workgroup, the probes marked at their targets (k_adj_fwd_targets)
+      static const int fwd_mode = [] {
         const char* e = getenv("KSH_FWD");
-        return e && std::string(e) == "probe";
+        return !e ? 0 : (std::string(e) == "probe" ? 1 : (std::string(e) == "staged" ? 2 : 0));
       }();
-      if (fwd_probe) {
+      if (fwd_mode == 1) {
         hipLaunchKernelGGL((k_adj_fwd<KeyT>), dim3(nblk(n)), dim3(256), 0, st, set, rc0, rc1, p->nbr, self_rc_flag);
+      } else if (fwd_mode == 0) {
+        p->routes |= KSH_ROUTE_FWD_TARGETS;
+        // the records are dead by now: the cuts take their place
+        const int64_t n_chunks = (n + kTgtChunk - 1) / kTgtChunk;
+        const int64_t cap = n / kTgtStreamMax + 1;  // parts beyond a window's first: fewer than its stream / kTgtStreamMax
+        // cuts | (lo, hi) cut pairs of the windows, then of the parts | the parts' tasks
+        // (a seventh of a byte per k-mer and 300 bytes: in the dead records, or for a set of a few k-mers in the arena)
+        const size_t cut_bytes = size_t((n_chunks + 1) * kTgtBounds + (n_chunks + cap) * 2 * kTgtBounds) * 8 + size_t(cap) * sizeof(TgtTask);
+        int64_t* cuts = cut_bytes <= al(size_t(2 * n) * 8) ? reinterpret_cast<int64_t*>(p->info)
+                                                           : static_cast<int64_t*>(arena_alloc(ctx, cut_bytes));
+        if (!cuts) return fail(KSH_INTERNAL, "scratch arena too small");
+        int64_t* rec = cuts + (n_chunks + 1) * kTgtBounds;
+        TgtTask* task = reinterpret_cast<TgtTask*>(rec + (n_chunks + cap) * 2 * kTgtBounds);
+        KSH_BOUND(n_chunks >= 1 && n_chunks * kTgtChunk >= n && n < (int64_t(1) << 31));  // indices travel as idx << 1 in 32 bits
+        hipLaunchKernelGGL((k_tgt_bounds<KeyT>), dim3(nblk((n_chunks + 1) * 8)), dim3(256), 0, st, set, n_chunks, cuts);
+        hipLaunchKernelGGL(k_tgt_split, dim3(nblk(n_chunks)), dim3(256), 0, st, cuts, n_chunks, cap, rec, task, &ctl->tgt_extra);
+        hipLaunchKernelGGL((k_tgt_subcuts<KeyT>), dim3(nblk(cap * 8)), dim3(256), 0, st, set, cuts, n_chunks, cap, task,
+                           &ctl->tgt_extra, rec);
+        hipLaunchKernelGGL((k_adj_fwd_targets<KeyT>), dim3(unsigned(n_chunks + cap)), dim3(kTgtThreads), 0, st, set, rec,
+                           n_chunks, &ctl->tgt_extra, rc0, rc1, p->nbr, self_rc_flag);
       } else {
         p->routes |= KSH_ROUTE_FWD_STAGED;
         // the records are dead by now: the chunk bounds take their place

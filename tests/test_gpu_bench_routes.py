@@ -51,7 +51,7 @@ def test_u32_1024_threads_batched_windows(ctx):
     n >= 2^20 -> the two-level rc scatter; 3 x 10^5 ruler walkers >= 2^18 -> all of them in one launch."""
     k, n = 19, 8
     a = synth.phylogeny_sets(k, 1, 5_000_000, seed=41)[0]
-    encode_vs_oracle(ctx, k, n, a, {"probe_staged", "rc_1024", "rc_batched", "scatter_two_level", "fwd_staged",
+    encode_vs_oracle(ctx, k, n, a, {"probe_staged", "rc_1024", "rc_batched", "scatter_two_level", "fwd_targets",
                                     "rank_one_launch", "emit_logs"}, {"rank_stamped"})
 
 
@@ -74,7 +74,7 @@ def test_u64_1024_threads_batched_windows(ctx):
     borrow nbr + link)."""
     k, n = 23, 8
     a = synth.phylogeny_sets(k, 1, 2_500_000, seed=47)[0]
-    encode_vs_oracle(ctx, k, n, a, {"probe_staged", "rc_1024", "rc_batched", "scatter_two_level", "fwd_staged",
+    encode_vs_oracle(ctx, k, n, a, {"probe_staged", "rc_1024", "rc_batched", "scatter_two_level", "fwd_targets",
                                     "emit_logs"}, {"rank_stamped"})
 
 
@@ -84,7 +84,7 @@ def test_bench_geometry_two_level_jumping(ctx):
     groups per super-group) and the emit from the logs with its long-stretch list."""
     k, n = 23, 14
     a = synth.phylogeny_sets(k, 1, 17_000_000, seed=53)[0]
-    encode_vs_oracle(ctx, k, n, a, {"probe_staged", "rc_512", "scatter_two_level", "fwd_staged", "rank_one_launch",
+    encode_vs_oracle(ctx, k, n, a, {"probe_staged", "rc_512", "scatter_two_level", "fwd_targets", "rank_one_launch",
                                     "jump_two_level", "emit_logs"}, {"rank_stamped"})
 
 
@@ -136,7 +136,7 @@ def test_route_differential_1e8(gpu):
     default = _run_route({}, size)
     other = _run_route({"KSH_ADJACENCY": "probe", "KSH_RANK": "stamp", "KSH_EMIT": "walk"}, size)
     r = set(default["genome"]["routes"])
-    assert {"probe_staged", "rc_1024", "rc_batched", "scatter_two_level", "fwd_staged", "rank_one_launch",
+    assert {"probe_staged", "rc_1024", "rc_batched", "scatter_two_level", "fwd_targets", "rank_one_launch",
             "jump_two_level", "emit_logs"} <= r, sorted(r)
     assert "probe_staged" not in other["genome"]["routes"] and "rank_stamped" in other["genome"]["routes"]
     for name in ("genome", "intersection", "difference"):

@@ -1199,9 +1199,23 @@ __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_
 // median window streams 800).  A window whose stream is longer than kTgtStreamMax is therefore cut again, evenly in
 // the prefix range (its stream is even there, its staged keys are not): k_tgt_split counts the parts and
 // k_tgt_subcuts searches their bounds, both on the device; the parts run as workgroups behind the windows'.
-constexpr int kTgtChunk = 1024;
-constexpr int kTgtThreads = 512;
-constexpr int kTgtStreamMax = 2048;
+#ifndef KSH_TGT_CHUNK
+#define KSH_TGT_CHUNK 2048
+#endif
+#ifndef KSH_TGT_CHUNK64
+#define KSH_TGT_CHUNK64 1024
+#endif
+// (window keys per workgroup; a stream longer than twice that is cut.  12 bytes of LDS per 4-byte key, 16 per 8-byte
+// key: four workgroups per CU either way)
+template <typename KeyT>
+struct TgtCfg {
+  static constexpr int kChunk = sizeof(KeyT) == 8 ? KSH_TGT_CHUNK64 : KSH_TGT_CHUNK;
+  static constexpr int kStreamMax = 2 * kChunk;
+};
+#ifndef KSH_TGT_THREADS
+#define KSH_TGT_THREADS 512
+#endif
+constexpr int kTgtThreads = KSH_TGT_THREADS;
 constexpr int kTgtSpan = 16;    // bucket offsets kept per range
 constexpr int kTgtBounds = 6;   // per cut: [0] index b of the cut, [1] v = the (K-1)-base prefix there, [2 + a] first index >= a v
 struct TgtTask {
@@ -1219,7 +1233,7 @@ __global__ __launch_bounds__(256) void k_tgt_bounds(DevSet<KeyT> set, int64_t n_
   const int j = int(id & 7);
   const bool live = c <= n_chunks;
   const int k = set.k;
-  const int64_t base = (live ? c : 0) * kTgtChunk;
+  const int64_t base = (live ? c : 0) * TgtCfg<KeyT>::kChunk;
   // prefix of the k-mer at base - 1 + j (j = 0 .. 4); past the end: none
   const int64_t p = base - 1 + j;
   uint64_t pref = ~uint64_t(0);
@@ -1250,8 +1264,8 @@ __global__ __launch_bounds__(256) void k_tgt_bounds(DevSet<KeyT> set, int64_t n_
 // One thread per window: rec[c] = its two cuts when its stream is short; else part 0 keeps the first cut, the
 // other parts become tasks (their workgroups: n_chunks + e, e from the counter) and k_tgt_subcuts fills the rest.
 __global__ __launch_bounds__(256) void k_tgt_split(const int64_t* __restrict__ cuts, int64_t n_chunks, int64_t cap,
-                                                    int64_t* __restrict__ rec, TgtTask* __restrict__ task,
-                                                    int* __restrict__ n_extra) {
+                                                    int stream_max, int64_t* __restrict__ rec,
+                                                    TgtTask* __restrict__ task, int* __restrict__ n_extra) {
   const int64_t c = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
   if (c >= n_chunks) return;
   const int64_t* lo = cuts + kTgtBounds * c;
@@ -1262,11 +1276,11 @@ __global__ __launch_bounds__(256) void k_tgt_split(const int64_t* __restrict__ c
   int64_t* r = rec + 2 * kTgtBounds * c;
 #pragma unroll
   for (int i = 0; i < kTgtBounds; i++) r[i] = lo[i];
-  const int64_t m = (stream + kTgtStreamMax - 1) / kTgtStreamMax;
+  const int64_t m = (stream + stream_max - 1) / stream_max;
   int64_t e = 0;
   if (m > 1) {
     e = int64_t(atomicAdd(n_extra, int(m - 1)));
-    if (e + m - 1 > cap) {  // (cannot happen: the streams add up to n, the parts beyond the first to less than n / kTgtStreamMax)
+    if (e + m - 1 > cap) {  // (cannot happen: the streams add up to n, the parts beyond the first to less than n / stream_max)
       atomicSub(n_extra, int(m - 1));
       e = -1;
     }
@@ -1323,12 +1337,12 @@ __global__ __launch_bounds__(kTgtThreads, 8) void k_adj_fwd_targets(DevSet<KeyT>
                                                                    const uint32_t* __restrict__ rc0,
                                                                    const uint32_t* __restrict__ rc1,
                                                                    uint32_t* __restrict__ nbr, int* __restrict__ self_rc) {
-  constexpr int kRounds = (kTgtChunk + 3 + kTgtThreads - 1) / kTgtThreads;  // staging rounds of the window
+  constexpr int kRounds = (TgtCfg<KeyT>::kChunk + 3 + kTgtThreads - 1) / kTgtThreads;  // staging rounds of the window
   __shared__ KeyT s_keys[kRounds * kTgtThreads];
   __shared__ uint32_t s_slot[kRounds * kTgtThreads];
   __shared__ int64_t s_b[2 * kTgtBounds];
   // where the buckets begin, relative to the range: [a] for the stream of top base a, [4] for the window
-  __shared__ int s_rel[5][kTgtSpan + 1];
+  __shared__ int s_rel[5 * (kTgtSpan + 1)];  // row r at r * (kTgtSpan + 1)
   const int tid = threadIdx.x;
   const int64_t chunk = blockIdx.x;
   const int k = set.k;
@@ -1353,7 +1367,7 @@ __global__ __launch_bounds__(kTgtThreads, 8) void k_adj_fwd_targets(DevSet<KeyT>
     const int64_t len_r = r == 4 ? int64_t(len_w) : s_b[kTgtBounds + 2 + r] - lo_r;
     int64_t rel = at - lo_r;
     rel = rel < 0 ? 0 : (rel > len_r ? len_r : rel);
-    s_rel[r][j] = int(rel);
+    s_rel[r * (kTgtSpan + 1) + j] = int(rel);
   }
   // the window, and what reaches its k-mers' side 0 through a reverse complement: all loads before the first store
   KeyT wk[kRounds];
@@ -1371,61 +1385,66 @@ __global__ __launch_bounds__(kTgtThreads, 8) void k_adj_fwd_targets(DevSet<KeyT>
   for (int u = 0; u < kRounds; u++) {
     const int i = tid + u * kTgtThreads;
     if (i < len_w) s_keys[i] = wk[u];
-    s_slot[i] = kNone;
+    s_slot[i] = wr[u];  // a mark starts as what reaches the side through a reverse complement: none -> the one -> several
   }
   KSH_PMARK(0, 2);  // this wave's window loads have arrived and are in LDS
-  // the stream: four ranges one behind the other
-  const int64_t q0 = s_b[2], q1 = s_b[3], q2 = s_b[4], q3 = s_b[5];
-  const int c1 = int(s_b[kTgtBounds + 2] - q0), c2 = c1 + int(s_b[kTgtBounds + 3] - q1), c3 = c2 + int(s_b[kTgtBounds + 4] - q2);
-  const int total = c3 + int(s_b[kTgtBounds + 5] - q3);
+  // the stream: four ranges one behind the other; position idx of the stream is index s_qbase[a] + idx of the set
+  // and the (idx - s_cum[a])-th k-mer of range a.  (Per-range values are read from LDS by a: selected among four
+  // registers they cost a nest of branches per k-mer.)
+  __shared__ uint32_t s_qbase[4];
+  __shared__ int s_cum[4], s_fb[4];
+  const int c1 = int(s_b[kTgtBounds + 2] - s_b[2]), c2 = c1 + int(s_b[kTgtBounds + 3] - s_b[3]),
+            c3 = c2 + int(s_b[kTgtBounds + 4] - s_b[4]);
+  const int total = c3 + int(s_b[kTgtBounds + 5] - s_b[5]);
+  if (tid < 4) {
+    const int cum = tid == 0 ? 0 : (tid == 1 ? c1 : (tid == 2 ? c2 : c3));
+    s_cum[tid] = cum;
+    s_qbase[tid] = uint32_t(s_b[2 + tid]) - uint32_t(cum);  // (>= 0: the ranges ascend in the set)
+    s_fb[tid] = first_bucket(tid);
+  }
   const uint32_t b32 = uint32_t(b);
   const bool even_k = (k & 1) == 0;
   __syncthreads();
   KSH_PMARK(0, 3);
-  // (position idx of the stream = index p of the set, in range a at r)
-  const auto place = [&](int idx, int* a, int* r) {
-    *a = (idx >= c1 ? 1 : 0) + (idx >= c2 ? 1 : 0) + (idx >= c3 ? 1 : 0);
-    *r = idx - (*a == 0 ? 0 : (*a == 1 ? c1 : (*a == 2 ? c2 : c3)));
-    return (*a == 0 ? q0 : (*a == 1 ? q1 : (*a == 2 ? q2 : q3))) + *r;
-  };
+  const auto range_of = [&](int idx) { return (idx >= c1 ? 1 : 0) + (idx >= c2 ? 1 : 0) + (idx >= c3 ? 1 : 0); };
   // the next k-mer of this thread is requested before this one's search
   KeyT key_next = 0;
   uint32_t rc_next = kNone;
   if (tid < total) {
-    int a, r;
-    const int64_t p = place(tid, &a, &r);
+    const uint32_t p = s_qbase[range_of(tid)] + uint32_t(tid);
     key_next = set.keys[p];
     rc_next = rc1[p];
   }
 #pragma unroll 1
   for (int idx = tid; idx < total; idx += kTgtThreads) {
-    int a, r;
-    const int64_t p = place(idx, &a, &r);
+    const int a = range_of(idx);
+    const int r = idx - s_cum[a];
+    const uint32_t p32 = s_qbase[a] + uint32_t(idx);
     const KeyT key = key_next;
     const uint32_t through_rc = rc_next;
     if (idx + kTgtThreads < total) {
-      int a2, r2;
-      const int64_t p2 = place(idx + kTgtThreads, &a2, &r2);
+      const uint32_t p2 = s_qbase[range_of(idx + kTgtThreads)] + uint32_t(idx + kTgtThreads);
       key_next = set.keys[p2];
       rc_next = rc1[p2];
     }
     // its bucket: the range's first, or one of the next few
     int64_t my_b;
     {
-      const int* rel = s_rel[a];
+      const int row = a * (kTgtSpan + 1);
+      // (a step-halving search over the row -- four dependent reads of s_rel[row + j + step] -- does not get through
+      // this compiler: "Illegal instruction detected: V_CMP_NE_U32_e32 0, $src_shared_base")
       int j = 0;
-      while (j < kTgtSpan && rel[j + 1] <= r) j++;
-      my_b = j < kTgtSpan ? int64_t(first_bucket(a)) + j : set.bucket_of(p);
+      while (j < kTgtSpan && s_rel[row + j + 1] <= r) j++;
+      my_b = j < kTgtSpan ? int64_t(s_fb[a] + j) : set.bucket_of(int64_t(p32));
     }
     const uint64_t x = (uint64_t(my_b) << set.key_bits) | uint64_t(key);
     if (even_k && revcomp(x, k) == x) *self_rc = 1;
     const uint64_t g0 = kmer_next(x, k, 0);
-    const uint32_t p32 = uint32_t(p);
     int cnt = 0;
     uint32_t single = kNone;
     const int jw = int(g0 >> set.key_bits) - fb_w;
     if (jw >= 0 && jw < kTgtSpan) {
-      const int lo = s_rel[4][jw], hi = s_rel[4][jw + 1];
+      const int lo = s_rel[4 * (kTgtSpan + 1) + jw], hi = s_rel[4 * (kTgtSpan + 1) + jw + 1];
       const KeyT gkey = KeyT(g0 & set.key_mask());
       if (lo < hi) {
         int i = lds_lower_bound(s_keys, lo, hi, gkey);
@@ -1441,7 +1460,7 @@ __global__ __launch_bounds__(kTgtThreads, 8) void k_adj_fwd_targets(DevSet<KeyT>
       // the window spans more buckets than the table holds (a sparse stretch of the set): found in global memory,
       // marked in the window all the same
       set.for_group4(g0, [&](int64_t at) {
-        if (at == p) return;
+        if (uint32_t(at) == p32) return;
         cnt++;
         single = uint32_t(at) << 1;
         const int64_t i = at - b;
@@ -1449,7 +1468,7 @@ __global__ __launch_bounds__(kTgtThreads, 8) void k_adj_fwd_targets(DevSet<KeyT>
       });
     }
     const uint32_t direct = cnt == 0 ? kNone : (cnt == 1 ? single : kMulti);
-    nbr[2 * p + 1] = side_verdict(direct, through_rc);
+    nbr[2 * size_t(p32) + 1] = side_verdict(direct, through_rc);
   }
   KSH_PMARK(0, 4);  // the first wave's share of the stream
   __syncthreads();
@@ -1457,7 +1476,7 @@ __global__ __launch_bounds__(kTgtThreads, 8) void k_adj_fwd_targets(DevSet<KeyT>
 #pragma unroll
   for (int u = 0; u < kRounds; u++) {
     const int i = tid + u * kTgtThreads;
-    if (i < len_w) nbr[2 * (b + i)] = side_verdict(s_slot[i], wr[u]);
+    if (i < len_w) nbr[2 * (b + i)] = s_slot[i];
   }
   KSH_PMARK(0, 6);
 #ifdef KSH_TRACE
@@ -3592,6 +3611,7 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       } else if (fwd_mode == 0) {
         p->routes |= KSH_ROUTE_FWD_TARGETS;
         // the records are dead by now: the cuts take their place
+        constexpr int kTgtChunk = TgtCfg<KeyT>::kChunk, kTgtStreamMax = TgtCfg<KeyT>::kStreamMax;
         const int64_t n_chunks = (n + kTgtChunk - 1) / kTgtChunk;
         const int64_t cap = n / kTgtStreamMax + 1;  // parts beyond a window's first: fewer than its stream / kTgtStreamMax
         // cuts | (lo, hi) cut pairs of the windows, then of the parts | the parts' tasks
@@ -3604,7 +3624,8 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
         TgtTask* task = reinterpret_cast<TgtTask*>(rec + (n_chunks + cap) * 2 * kTgtBounds);
         KSH_BOUND(n_chunks >= 1 && n_chunks * kTgtChunk >= n && n < (int64_t(1) << 31));  // indices travel as idx << 1 in 32 bits
         hipLaunchKernelGGL((k_tgt_bounds<KeyT>), dim3(nblk((n_chunks + 1) * 8)), dim3(256), 0, st, set, n_chunks, cuts);
-        hipLaunchKernelGGL(k_tgt_split, dim3(nblk(n_chunks)), dim3(256), 0, st, cuts, n_chunks, cap, rec, task, &ctl->tgt_extra);
+        hipLaunchKernelGGL(k_tgt_split, dim3(nblk(n_chunks)), dim3(256), 0, st, cuts, n_chunks, cap, kTgtStreamMax, rec, task,
+                           &ctl->tgt_extra);
         hipLaunchKernelGGL((k_tgt_subcuts<KeyT>), dim3(nblk(cap * 8)), dim3(256), 0, st, set, cuts, n_chunks, cap, task,
                            &ctl->tgt_extra, rec);
         hipLaunchKernelGGL((k_adj_fwd_targets<KeyT>), dim3(unsigned(n_chunks + cap)), dim3(kTgtThreads), 0, st, set, rec,

@@ -1203,10 +1203,12 @@ __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_
 #define KSH_TGT_CHUNK 2048
 #endif
 #ifndef KSH_TGT_CHUNK64
-#define KSH_TGT_CHUNK64 1024
+#define KSH_TGT_CHUNK64 2048
 #endif
-// (window keys per workgroup; a stream longer than twice that is cut.  12 bytes of LDS per 4-byte key, 16 per 8-byte
-// key: four workgroups per CU either way)
+// (window keys per workgroup; a stream longer than twice that is cut.  8 bytes of LDS per 4-byte key, 12 per 8-byte
+// key -- 20 and 30 KB per workgroup: four workgroups per CU, as many as its 2048 threads allow, either way.  Measured
+// at 4-byte keys, 512 threads, 10^8-k-mer genome set / 9 x 10^6 difference set: 1024 keys 1038 / 85 us, 1536 keys
+// 896 / 76, 2048 keys 865 / 75; 2048 keys and 256 threads 925 / 80, 1024 keys and 128 threads 955 / 82.)
 template <typename KeyT>
 struct TgtCfg {
   static constexpr int kChunk = sizeof(KeyT) == 8 ? KSH_TGT_CHUNK64 : KSH_TGT_CHUNK;

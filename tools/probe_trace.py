@@ -39,11 +39,12 @@ def main():
                  "barrier", "Next search", "Prev searches", "verdict + store"]
     rc_names = ["plan (record range + bounds arrive)", "stage: loads -> LDS", "barrier", "slice index + barrier",
                 "record look-ups (this wave)", "barrier", "store marks"]
-    f = t[0][t[0][:, 6] != 0]
-    print("k_adj_fwd_staged: %d workgroups, cycles first mark -> last: mean %.0f" % (f.shape[0], float((f[:, 6] - f[:, 0]).double().mean())))
-    for ph in range(6):
-        d = (f[:, ph + 1] - f[:, ph]).double()
-        print("   %-50s mean %8.0f  p50 %8.0f  p90 %8.0f" % (fwd_names[ph], d.mean(), d.median(), d.quantile(0.9)))
+    if os.environ.get("KSH_FWD") == "staged":  # (the default forward kernel has its own tool: tools/tgt_trace.py)
+        f = t[0][t[0][:, 6] != 0]
+        print("k_adj_fwd_staged: %d workgroups, cycles first mark -> last: mean %.0f" % (f.shape[0], float((f[:, 6] - f[:, 0]).double().mean())))
+        for ph in range(6):
+            d = (f[:, ph + 1] - f[:, ph]).double()
+            print("   %-50s mean %8.0f  p50 %8.0f  p90 %8.0f" % (fwd_names[ph], d.mean(), d.median(), d.quantile(0.9)))
     r = t[1][(t[1][:, 7] != 0) & (t[1][:, 14] != 0)]
     print("k_adj_rc: %d workgroups with both passes, cycles first mark -> last: mean %.0f" % (r.shape[0], float((r[:, 14] - r[:, 0]).double().mean())))
     for p in range(2):

@@ -647,7 +647,7 @@ template <typename KeyT, int kRcThreads>
 __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 512 ? 8 : (kRcThreads >= 128 ? kRcThreads / 128 : 1))) void k_adj_rc(
     DevSet<KeyT> set, int gbits, const int64_t* __restrict__ goff, const RcRecord<KeyT>* __restrict__ rec,
     const int64_t* __restrict__ pb, const int64_t* __restrict__ pb0, int cap, uint32_t* __restrict__ rc0,
-    uint32_t* __restrict__ rc1, int* __restrict__ batched) {
+    uint32_t* __restrict__ rc1, int* __restrict__ batched, int pass1_cap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   KeyT* skeys = reinterpret_cast<KeyT*>(lds_raw);
   uint32_t* slots = reinterpret_cast<uint32_t*>(lds_raw + size_t(cap) * sizeof(KeyT));
@@ -670,7 +670,9 @@ __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 512 ? 8 : (kRcThreads >=
   KSH_PMARK_WAVE(2);  // when each wave of the workgroup started
   if (tid < 2 * kRcSegs) prev_bounds[tid] = pb[2 * kRcSegs * grp + tid];
   KSH_PMARK(1, 0);
-  for (int pass = 0; pass < 2; pass++) {
+  // (pass 1 of a group with at most pass1_cap records is k_adj_rc1's)
+  const int n_pass = r1 - r0 <= int64_t(pass1_cap) ? 1 : 2;
+  for (int pass = 0; pass < n_pass; pass++) {
     const int n_seg = pass == 0 ? 1 : kRcSegs;
     // key bits that vary inside a range: all below the group's in its own range, four fewer in [c][tb][G]
     const int seg_bits = (pass == 0 ? set.key_bits : set.key_bits - 4) - extra;
@@ -860,6 +862,139 @@ __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 512 ? 8 : (kRcThreads >=
       __syncthreads();
       if (tid == 0) plan_serial();
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------- E1b, pass 1 turned round
+// Pass 1 above asks, per record x, for the four Prev(rx, c): up to four look-ups in sixteen staged and indexed
+// ranges, and every edge is found from both of its ends.  Turned round (round 4, after k_adj_fwd_targets): z is
+// reached on its side 1 by the records with rx = Next(z, c') -- FOUR CONSECUTIVE record keys, one look-up -- and
+// the z that can be reached by group G's records are exactly the k-mers of G's sixteen ranges [c][tb][G].  So a
+// workgroup puts the group's RECORDS in LDS (chained by a hash of the key without its last base: arrival order,
+// one exchange per record, no sort), streams the sixteen ranges once, coalesced, and every z counts what it
+// finds: its own verdict, no marks, no staging or slice index of the ranges, no canonical test (z is in the set).
+// Needs the group's records in one piece (cap records); denser groups keep pass 1 above.
+constexpr int kRc1Slices = 2048;
+constexpr int kRc1LdsBytes = 78 << 10;
+template <typename KeyT>
+struct Rc1Cfg {
+  // heads (4 bytes a slice) | record t (4) | record key | next (2)
+  static constexpr int kCap = int((kRc1LdsBytes - kRc1Slices * 4) / (sizeof(KeyT) + 6)) & ~7;
+  static_assert(kCap < 65535, "chain links are 16-bit");
+};
+
+template <typename KeyT, int kThreads>
+__global__ __launch_bounds__(kThreads) void k_adj_rc1(DevSet<KeyT> set, int gbits, const int64_t* __restrict__ goff,
+                                                      const RcRecord<KeyT>* __restrict__ rec,
+                                                      const int64_t* __restrict__ pb, int cap, int n_slices,
+                                                      uint32_t* __restrict__ rc1) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+  uint32_t* head = reinterpret_cast<uint32_t*>(lds_raw);
+  uint32_t* rt = head + n_slices;
+  KeyT* rkey = reinterpret_cast<KeyT*>(rt + cap);
+  uint16_t* nxt = reinterpret_cast<uint16_t*>(rkey + cap);
+  __shared__ int64_t s_lo[kRcSegs];
+  __shared__ __attribute__((aligned(16))) int s_cum[kRcSegs + 4];
+  const int tid = threadIdx.x;
+  const int64_t grp = blockIdx.x;
+  const int64_t r0 = goff[grp], r1 = goff[grp + 1];
+  if (r1 - r0 > int64_t(cap)) return;  // k_adj_rc's pass 1 has this group
+  const int n_rec = int(r1 - r0);
+  const int rest_bits = 2 * set.k - 4 - gbits;  // bits of z below [c][tb][G] = bits of a record key between tb and the last base
+  const uint64_t rest_mask = (uint64_t(1) << rest_bits) - 1;
+  const uint32_t slice_mask = uint32_t(n_slices - 1);
+  for (int sl = tid; sl < n_slices; sl += kThreads) head[sl] = 0xFFFFFFFFu;
+  if (tid < 64) {
+    int64_t lo = 0, hi = 0;
+    if (tid < kRcSegs) {
+      lo = pb[2 * kRcSegs * grp + 2 * tid];
+      hi = pb[2 * kRcSegs * grp + 2 * tid + 1];
+      s_lo[tid] = lo;
+    }
+    int inc = int(hi - lo);  // (a range of the set: < 2^31)
+#pragma unroll
+    for (int d = 1; d < kRcSegs; d <<= 1) {
+      const int o = __shfl_up(inc, d, 64);
+      if (tid >= d) inc += o;
+    }
+    if (tid < kRcSegs) s_cum[tid + 1] = inc;
+    if (tid == 0) s_cum[0] = 0;
+  }
+  // four records of a thread are requested together, then chained in; the first four before the barrier
+  RcRecord<KeyT> r[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) {
+    const int i = u * kThreads + tid;
+    if (i < n_rec) r[u] = rec[r0 + i];
+  }
+  __syncthreads();
+  // (the thread's first k-mer of the stream is requested before the records are chained in: one round trip less on
+  // the workgroup's path)
+  const int total = s_cum[kRcSegs];
+  const int c4 = s_cum[4], c8 = s_cum[8], c12 = s_cum[12];
+  // position idx of the stream -> index of the set, top base tb of its range: by c (three compares), then by tb within
+  // the four ranges of that c (one 16-byte read)
+  const auto place = [&](int idx, int* tb) {
+    const int c = (idx >= c4 ? 1 : 0) + (idx >= c8 ? 1 : 0) + (idx >= c12 ? 1 : 0);
+    const int4 cq = *reinterpret_cast<const int4*>(&s_cum[4 * c]);
+    *tb = (idx >= cq.y ? 1 : 0) + (idx >= cq.z ? 1 : 0) + (idx >= cq.w ? 1 : 0);
+    const int before = *tb == 0 ? cq.x : (*tb == 1 ? cq.y : (*tb == 2 ? cq.z : cq.w));
+    return s_lo[4 * c + *tb] + (idx - before);
+  };
+  // the next k-mer of this thread is requested before this one's look-up
+  int tb_next = 0;
+  int64_t i_next = 0;
+  KeyT key_next = 0;
+  if (tid < total) {
+    i_next = place(tid, &tb_next);
+    key_next = set.keys[i_next];
+  }
+  for (int base = 0; base < n_rec; base += 4 * kThreads) {
+    if (base > 0) {
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = base + u * kThreads + tid;
+        if (i < n_rec) r[u] = rec[r0 + i];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = base + u * kThreads + tid;
+      if (i < n_rec) {
+        rkey[i] = r[u].key;
+        rt[i] = r[u].t;
+        const uint32_t sl = uint32_t(uint64_t(r[u].key) >> 2) & slice_mask;
+        nxt[i] = uint16_t(atomicExch(&head[sl], uint32_t(i)));  // (none = all ones either way)
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll 1
+  for (int idx = tid; idx < total; idx += kThreads) {
+    const int tb = tb_next;
+    const int64_t i = i_next;
+    const KeyT key = key_next;
+    if (idx + kThreads < total) {
+      i_next = place(idx + kThreads, &tb_next);
+      key_next = set.keys[i_next];
+    }
+    const uint64_t q = (uint64_t(tb) << rest_bits) | (uint64_t(key) & rest_mask);  // Next(z, .) >> 2, as a record key
+    int cnt = 0;
+    uint32_t single = kNone;
+    uint32_t j = head[uint32_t(q) & slice_mask];
+    while (j != 0xFFFFFFFFu) {
+      const uint64_t kq = uint64_t(rkey[j]) >> 2;
+      const uint32_t nj = nxt[j];
+      if (kq == q) {
+        const uint32_t t = rt[j];
+        if (t != uint32_t(i)) {  // (t == i: rc(z) = Next(z, c'), the k-mer itself)
+          cnt++;
+          single = (t << 1) | 1u;
+        }
+      }
+      j = nj == 0xFFFFu ? 0xFFFFFFFFu : nj;
+    }
+    rc1[i] = cnt == 0 ? kNone : (cnt == 1 ? single : kMulti);
   }
 }
 
@@ -3537,6 +3672,14 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
           KSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc<KeyT, 64>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+          KSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc1<KeyT, 1024>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kRc1LdsBytes));
+          KSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc1<KeyT, 512>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kRc1LdsBytes));
+          KSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc1<KeyT, 256>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kRc1LdsBytes));
+          KSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_adj_rc1<KeyT, 64>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, kRc1LdsBytes));
           KSH_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_rc_hist<KeyT>),
                                       hipFuncAttributeMaxDynamicSharedMemorySize, int(size_t(4) << 15)));
           ctx->lds_opt_in |= bit;
@@ -3590,18 +3733,45 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
                          gbits, pb, pb0);
       p->routes |= per_group > 4096 ? KSH_ROUTE_RC_1024 : per_group > 1024 ? KSH_ROUTE_RC_512
                    : per_group > 256 ? KSH_ROUTE_RC_256 : KSH_ROUTE_RC_64;
-      if (per_group > 4096)
+      // pass 1 turned round (k_adj_rc1) for the groups whose records fit its LDS; KSH_RC1=marks: pass 1 as it was
+      static const bool rc1_marks = [] {
+        const char* e = getenv("KSH_RC1");
+        return e && std::string(e) == "marks";
+      }();
+      // (LDS for the average group and a quarter, so that small groups share a CU many at a time -- the records of a
+      // group are a Poisson count; a group beyond it keeps pass 1 as it was, both kernels decide by the same number)
+      const int rc1_cap = rc1_marks ? 0 : int(std::min<int64_t>(Rc1Cfg<KeyT>::kCap, (per_group * 5 / 4 + 263) & ~int64_t(7)));
+      const int pass1_cap = rc1_marks ? -1 : rc1_cap;  // (k_adj_rc: groups of at most that many records leave pass 1 out)
+      int rc1_slices = 64;                             // about a slice per two records
+      while (rc1_slices < kRc1Slices && 2 * rc1_slices < rc1_cap) rc1_slices <<= 1;
+      const size_t rc1_lds = size_t(rc1_slices) * 4 + size_t(rc1_cap) * (sizeof(KeyT) + 6);
+      KSH_BOUND(rc1_lds <= size_t(kRc1LdsBytes) && rc1_cap % 8 == 0 && (rc1_slices & (rc1_slices - 1)) == 0);
+      if (!rc1_marks) p->routes |= KSH_ROUTE_RC1_STREAMED;
+      if (per_group > 4096) {
         hipLaunchKernelGGL((k_adj_rc<KeyT, 1024>), dim3(unsigned(ng)), dim3(1024), rc_lds, st, set, gbits, goff,
-                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched);
-      else if (per_group > 1024)
+                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched, pass1_cap);
+        if (!rc1_marks)
+          hipLaunchKernelGGL((k_adj_rc1<KeyT, 1024>), dim3(unsigned(ng)), dim3(1024), rc1_lds, st, set, gbits, goff, rec,
+                             pb, rc1_cap, rc1_slices, rc1);
+      } else if (per_group > 1024) {
         hipLaunchKernelGGL((k_adj_rc<KeyT, 512>), dim3(unsigned(ng)), dim3(512), rc_lds, st, set, gbits, goff,
-                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched);
-      else if (per_group > 256)
+                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched, pass1_cap);
+        if (!rc1_marks)
+          hipLaunchKernelGGL((k_adj_rc1<KeyT, 512>), dim3(unsigned(ng)), dim3(512), rc1_lds, st, set, gbits, goff, rec,
+                             pb, rc1_cap, rc1_slices, rc1);
+      } else if (per_group > 256) {
         hipLaunchKernelGGL((k_adj_rc<KeyT, 256>), dim3(unsigned(ng)), dim3(256), rc_lds, st, set, gbits, goff,
-                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched);
-      else
+                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched, pass1_cap);
+        if (!rc1_marks)
+          hipLaunchKernelGGL((k_adj_rc1<KeyT, 256>), dim3(unsigned(ng)), dim3(256), rc1_lds, st, set, gbits, goff, rec,
+                             pb, rc1_cap, rc1_slices, rc1);
+      } else {
         hipLaunchKernelGGL((k_adj_rc<KeyT, 64>), dim3(unsigned(ng)), dim3(64), rc_lds, st, set, gbits, goff,
-                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched);
+                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched, pass1_cap);
+        if (!rc1_marks)
+          hipLaunchKernelGGL((k_adj_rc1<KeyT, 64>), dim3(unsigned(ng)), dim3(64), rc1_lds, st, set, gbits, goff, rec,
+                             pb, rc1_cap, rc1_slices, rc1);
+      }
       // KSH_FWD=probe: the forward half in place; =staged: round 3's five staged windows per chunk; default: one
       // window per workgroup, the probes marked at their targets (k_adj_fwd_targets)
       static const int fwd_mode = [] {

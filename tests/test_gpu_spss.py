@@ -424,7 +424,7 @@ def test_u16_keys_medium_and_large_sets(ctx):
     assert odd >= 1  # (the sizes above are chosen so that the case that faulted is among them)
 
 
-@pytest.mark.parametrize("knob", ["KSH_RANK=stamp", "KSH_EMIT=walk", "KSH_L2_MIN=4096", "KSH_ADJACENCY=probe", "KSH_FWD=probe", "KSH_FWD=staged", "KSH_RC_SCATTER=direct", "KSH_RC_GROUPS=half", "KSH_RANK_PHASES=1"])
+@pytest.mark.parametrize("knob", ["KSH_RANK=stamp", "KSH_EMIT=walk", "KSH_L2_MIN=4096", "KSH_ADJACENCY=probe", "KSH_FWD=probe", "KSH_FWD=staged", "KSH_RC1=marks", "KSH_RC_SCATTER=direct", "KSH_RC_GROUPS=half", "KSH_RANK_PHASES=1"])
 def test_encode_alternative_paths(gpu, knob):
     """The encoder's other routes give the oracle's strings too: the stamping ranking walks with
     k_choose / k_emit per k-mer (what a set with a non-branching loop falls back to), the strings

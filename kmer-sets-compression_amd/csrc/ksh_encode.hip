@@ -663,6 +663,7 @@ __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 512 ? 8 : (kRcThreads >=
   const uint64_t low_mask = (uint64_t(1) << low_bits) - 1;
   const uint64_t kmask = kmer_mask(k);
   const int64_t r0 = goff[grp], r1 = goff[grp + 1];
+  if (r1 - r0 <= int64_t(pass1_cap)) return;  // a group of at most that many records is k_adj_rc1's, both passes
   // pass 0's range: the bucket's offsets, or the searched bounds of a finer group
   const int64_t p0_lo = pb0 ? pb0[2 * grp] : set.off[grp], p0_hi = pb0 ? pb0[2 * grp + 1] : set.off[grp + 1];
   // the bits of a bucket key that a pass-0 target of this group starts with (the group bits below the bucket's)
@@ -670,9 +671,7 @@ __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 512 ? 8 : (kRcThreads >=
   KSH_PMARK_WAVE(2);  // when each wave of the workgroup started
   if (tid < 2 * kRcSegs) prev_bounds[tid] = pb[2 * kRcSegs * grp + tid];
   KSH_PMARK(1, 0);
-  // (pass 1 of a group with at most pass1_cap records is k_adj_rc1's)
-  const int n_pass = r1 - r0 <= int64_t(pass1_cap) ? 1 : 2;
-  for (int pass = 0; pass < n_pass; pass++) {
+  for (int pass = 0; pass < 2; pass++) {
     const int n_seg = pass == 0 ? 1 : kRcSegs;
     // key bits that vary inside a range: all below the group's in its own range, four fewer in [c][tb][G]
     const int seg_bits = (pass == 0 ? set.key_bits : set.key_bits - 4) - extra;
@@ -865,31 +864,47 @@ __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 512 ? 8 : (kRcThreads >=
   }
 }
 
-// ---------------------------------------------------------------------------------- E1b, pass 1 turned round
-// Pass 1 above asks, per record x, for the four Prev(rx, c): up to four look-ups in sixteen staged and indexed
-// ranges, and every edge is found from both of its ends.  Turned round (round 4, after k_adj_fwd_targets): z is
-// reached on its side 1 by the records with rx = Next(z, c') -- FOUR CONSECUTIVE record keys, one look-up -- and
-// the z that can be reached by group G's records are exactly the k-mers of G's sixteen ranges [c][tb][G].  So a
-// workgroup puts the group's RECORDS in LDS (chained by a hash of the key without its last base: arrival order,
-// one exchange per record, no sort), streams the sixteen ranges once, coalesced, and every z counts what it
-// finds: its own verdict, no marks, no staging or slice index of the ranges, no canonical test (z is in the set).
-// Needs the group's records in one piece (cap records); denser groups keep pass 1 above.
-constexpr int kRc1Slices = 2048;
-constexpr int kRc1LdsBytes = 78 << 10;
+// ---------------------------------------------------------------------------------- E1b turned round
+// k_adj_rc asks, per record x, for the members of Next(rx, .) in the group's own range (pass 0) and for the four
+// Prev(rx, c) in sixteen staged and indexed ranges (pass 1), and leaves marks at what it finds.  Turned round
+// (round 4, after k_adj_fwd_targets): every edge through a reverse complement is seen from both of its ends, so
+// instead of the records looking for k-mers, the k-mers of those ranges look for records:
+//   pass 1: z is reached on its side 1 by the records with rx = Next(z, c') -- the four record keys that differ in
+//           their last base only -- and the z that group G's records can reach are the k-mers of G's sixteen
+//           ranges [c][tb][G];
+//   pass 0: y of the group's own range is reached on its side 0 by the records with rx = Prev(y, a) -- the four
+//           record keys that differ in their top base only.
+// So a workgroup puts the group's RECORDS in LDS, chained by the bits of the key between its top and its last base
+// (what both passes know of the records they look for; arrival order, one exchange per record, no sort), streams
+// the group's range and the sixteen ranges once each, coalesced, and every k-mer walks one chain and counts what
+// it finds: its own verdict, written in place.  No staging or slice index of the ranges, no marks, no canonical
+// test (a streamed k-mer IS in the set), no batches for the dense A-led buckets (the streams have no capacity;
+// what has to fit is the group's records, and those are spread evenly: +-19 % by the first base of G).
+// A chain entry of a 2- or 4-byte key is ONE 8-byte word: the key without the bits the chain implies | t | next.
+// Groups whose records do not fit (10^8 k-mers in 2^10 buckets, 5 x 10^8 in 2^14) stay with k_adj_rc.
+constexpr int kRc1SlicesMax = 4096;
+constexpr int kRc1LdsBytes = 81408;  // two workgroups and their static LDS in a CU's 160 KB
 template <typename KeyT>
 struct Rc1Cfg {
-  // heads (4 bytes a slice) | record t (4) | record key | next (2)
-  static constexpr int kCap = int((kRc1LdsBytes - kRc1Slices * 4) / (sizeof(KeyT) + 6)) & ~7;
-  static_assert(kCap < 65535, "chain links are 16-bit");
+  static constexpr bool kPacked = sizeof(KeyT) <= 4;
+  // heads (4 bytes a slice) | entries: one word, or key | t | next (2 bytes)
+  static constexpr int kEntryBytes = kPacked ? 8 : int(sizeof(KeyT)) + 6;
+  static constexpr int kCap = int((kRc1LdsBytes - kRc1SlicesMax * 4) / kEntryBytes) & ~7;
+  static_assert(kCap < 2 * kRc1SlicesMax - 1, "chain links have one bit more than the slices");
 };
 
 template <typename KeyT, int kThreads>
 __global__ __launch_bounds__(kThreads) void k_adj_rc1(DevSet<KeyT> set, int gbits, const int64_t* __restrict__ goff,
                                                       const RcRecord<KeyT>* __restrict__ rec,
-                                                      const int64_t* __restrict__ pb, int cap, int n_slices,
+                                                      const int64_t* __restrict__ pb, const int64_t* __restrict__ pb0,
+                                                      int cap, int sbits, uint32_t* __restrict__ rc0,
                                                       uint32_t* __restrict__ rc1) {
+  constexpr bool kPacked = Rc1Cfg<KeyT>::kPacked;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   uint32_t* head = reinterpret_cast<uint32_t*>(lds_raw);
+  const int n_slices = 1 << sbits;
+  // packed: entry[i]; else rt[i], rkey[i], nxt[i]
+  unsigned long long* entry = reinterpret_cast<unsigned long long*>(head + n_slices);
   uint32_t* rt = head + n_slices;
   KeyT* rkey = reinterpret_cast<KeyT*>(rt + cap);
   uint16_t* nxt = reinterpret_cast<uint16_t*>(rkey + cap);
@@ -898,12 +913,22 @@ __global__ __launch_bounds__(kThreads) void k_adj_rc1(DevSet<KeyT> set, int gbit
   const int tid = threadIdx.x;
   const int64_t grp = blockIdx.x;
   const int64_t r0 = goff[grp], r1 = goff[grp + 1];
-  if (r1 - r0 > int64_t(cap)) return;  // k_adj_rc's pass 1 has this group
+  if (r1 - r0 > int64_t(cap)) return;  // k_adj_rc has this group
   const int n_rec = int(r1 - r0);
-  const int rest_bits = 2 * set.k - 4 - gbits;  // bits of z below [c][tb][G] = bits of a record key between tb and the last base
+  const int rest_bits = 2 * set.k - 4 - gbits;  // bits of a record key between its top base and its last base
   const uint64_t rest_mask = (uint64_t(1) << rest_bits) - 1;
-  const uint32_t slice_mask = uint32_t(n_slices - 1);
-  for (int sl = tid; sl < n_slices; sl += kThreads) head[sl] = 0xFFFFFFFFu;
+  const uint64_t low_mask = (uint64_t(1) << (rest_bits + 2)) - 1;  // a record key without its top base
+  // the chain of a record: the low e_sbits of those bits
+  const int e_sbits = sbits < rest_bits ? sbits : rest_bits;
+  const uint32_t slice_mask = (1u << e_sbits) - 1u;
+  // a packed entry: [t : 31][next : sbits + 1][the key without the chain's bits: its last base below the rest]
+  const int kf_bits = 2 * set.k - gbits - e_sbits;  // (key bits 2 + rest_bits + 2, less the chain's: <= 32 - sbits when they matter)
+  const int t_shift = kf_bits + sbits + 1;
+  const uint32_t none = (2u << sbits) - 1u;  // "no next": all ones in sbits + 1 bits (cap < that)
+  const uint64_t kf_mask = (uint64_t(1) << kf_bits) - 1;
+  // pass 0's range: the bucket's offsets, or the searched bounds of a finer group
+  const int64_t p0_lo = pb0 ? pb0[2 * grp] : set.off[grp], p0_hi = pb0 ? pb0[2 * grp + 1] : set.off[grp + 1];
+  for (int sl = tid; sl < n_slices; sl += kThreads) head[sl] = none;
   if (tid < 64) {
     int64_t lo = 0, hi = 0;
     if (tid < kRcSegs) {
@@ -928,12 +953,12 @@ __global__ __launch_bounds__(kThreads) void k_adj_rc1(DevSet<KeyT> set, int gbit
     if (i < n_rec) r[u] = rec[r0 + i];
   }
   __syncthreads();
-  // (the thread's first k-mer of the stream is requested before the records are chained in: one round trip less on
-  // the workgroup's path)
+  // (the thread's first k-mers of both streams are requested before the records are chained in: a round trip less
+  // on the workgroup's path)
   const int total = s_cum[kRcSegs];
   const int c4 = s_cum[4], c8 = s_cum[8], c12 = s_cum[12];
-  // position idx of the stream -> index of the set, top base tb of its range: by c (three compares), then by tb within
-  // the four ranges of that c (one 16-byte read)
+  // position idx of pass 1's stream -> index of the set, top base tb of its range: by c (three compares), then by
+  // tb within the four ranges of that c (one 16-byte read)
   const auto place = [&](int idx, int* tb) {
     const int c = (idx >= c4 ? 1 : 0) + (idx >= c8 ? 1 : 0) + (idx >= c12 ? 1 : 0);
     const int4 cq = *reinterpret_cast<const int4*>(&s_cum[4 * c]);
@@ -941,7 +966,8 @@ __global__ __launch_bounds__(kThreads) void k_adj_rc1(DevSet<KeyT> set, int gbit
     const int before = *tb == 0 ? cq.x : (*tb == 1 ? cq.y : (*tb == 2 ? cq.z : cq.w));
     return s_lo[4 * c + *tb] + (idx - before);
   };
-  // the next k-mer of this thread is requested before this one's look-up
+  KeyT y_next = 0;
+  if (p0_lo + tid < p0_hi) y_next = set.keys[p0_lo + tid];
   int tb_next = 0;
   int64_t i_next = 0;
   KeyT key_next = 0;
@@ -961,14 +987,58 @@ __global__ __launch_bounds__(kThreads) void k_adj_rc1(DevSet<KeyT> set, int gbit
     for (int u = 0; u < 4; u++) {
       const int i = base + u * kThreads + tid;
       if (i < n_rec) {
-        rkey[i] = r[u].key;
-        rt[i] = r[u].t;
-        const uint32_t sl = uint32_t(uint64_t(r[u].key) >> 2) & slice_mask;
-        nxt[i] = uint16_t(atomicExch(&head[sl], uint32_t(i)));  // (none = all ones either way)
+        const uint64_t key = uint64_t(r[u].key);
+        const uint32_t sl = uint32_t(key >> 2) & slice_mask;
+        const uint32_t before = atomicExch(&head[sl], uint32_t(i));  // (none = all ones in sbits + 1 bits)
+        if (kPacked) {
+          const uint64_t kf = ((key >> (2 + e_sbits)) << 2) | (key & 3);
+          entry[i] = (uint64_t(r[u].t) << t_shift) | (uint64_t(before) << kf_bits) | kf;
+        } else {
+          rkey[i] = r[u].key;
+          rt[i] = r[u].t;
+          nxt[i] = uint16_t(before);
+        }
       }
     }
   }
   __syncthreads();
+  // One chain walk: f(key without the chain's bits [the rest above e_sbits, tb on top][last base], t) per entry.
+  const auto walk = [&](uint32_t sl, auto f) {
+    uint32_t j = head[sl];
+    while (j != none) {
+      if (kPacked) {
+        const uint64_t e = entry[j];
+        f(e & kf_mask, uint32_t(e >> t_shift));
+        j = uint32_t(e >> kf_bits) & none;
+      } else {
+        const uint64_t key = uint64_t(rkey[j]);
+        const uint32_t nj = nxt[j];
+        f(((key >> (2 + e_sbits)) << 2) | (key & 3), rt[j]);
+        j = uint32_t(nj);  // (none fits 16 bits)
+      }
+    }
+  };
+  // pass 0: y of the group's own range against the records [a][y without its last base], whatever a
+  {
+    const uint64_t hi_mask = (uint64_t(1) << (rest_bits - e_sbits)) - 1;  // (the rest above the chain's bits, without tb)
+#pragma unroll 1
+    for (int64_t i = p0_lo + tid; i < p0_hi; i += kThreads) {
+      const KeyT ykey = y_next;
+      if (i + kThreads < p0_hi) y_next = set.keys[i + kThreads];
+      const uint64_t low = (uint64_t(ykey) >> 2) & low_mask;  // the records' key below their top base
+      const uint64_t want = ((low >> (2 + e_sbits)) << 2) | (low & 3);
+      int cnt = 0;
+      uint32_t single = kNone;
+      walk(uint32_t(low >> 2) & slice_mask, [&](uint64_t kf, uint32_t t) {
+        if ((((kf >> 2) & hi_mask) << 2 | (kf & 3)) == want && t != uint32_t(i)) {  // (t == i: y = Next(rc(y), c), the k-mer itself)
+          cnt++;
+          single = (t << 1) | 1u;
+        }
+      });
+      rc0[i] = cnt == 0 ? kNone : (cnt == 1 ? single : kMulti);
+    }
+  }
+  // pass 1: z of range [c][tb][G] against the records [tb][z's rest][c'], whatever c'
 #pragma unroll 1
   for (int idx = tid; idx < total; idx += kThreads) {
     const int tb = tb_next;
@@ -979,21 +1049,15 @@ __global__ __launch_bounds__(kThreads) void k_adj_rc1(DevSet<KeyT> set, int gbit
       key_next = set.keys[i_next];
     }
     const uint64_t q = (uint64_t(tb) << rest_bits) | (uint64_t(key) & rest_mask);  // Next(z, .) >> 2, as a record key
+    const uint64_t want = q >> e_sbits;
     int cnt = 0;
     uint32_t single = kNone;
-    uint32_t j = head[uint32_t(q) & slice_mask];
-    while (j != 0xFFFFFFFFu) {
-      const uint64_t kq = uint64_t(rkey[j]) >> 2;
-      const uint32_t nj = nxt[j];
-      if (kq == q) {
-        const uint32_t t = rt[j];
-        if (t != uint32_t(i)) {  // (t == i: rc(z) = Next(z, c'), the k-mer itself)
-          cnt++;
-          single = (t << 1) | 1u;
-        }
+    walk(uint32_t(q) & slice_mask, [&](uint64_t kf, uint32_t t) {
+      if ((kf >> 2) == want && t != uint32_t(i)) {  // (t == i: rc(z) = Next(z, c'), the k-mer itself)
+        cnt++;
+        single = (t << 1) | 1u;
       }
-      j = nj == 0xFFFFu ? 0xFFFFFFFFu : nj;
-    }
+    });
     rc1[i] = cnt == 0 ? kNone : (cnt == 1 ? single : kMulti);
   }
 }
@@ -3733,44 +3797,45 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
                          gbits, pb, pb0);
       p->routes |= per_group > 4096 ? KSH_ROUTE_RC_1024 : per_group > 1024 ? KSH_ROUTE_RC_512
                    : per_group > 256 ? KSH_ROUTE_RC_256 : KSH_ROUTE_RC_64;
-      // pass 1 turned round (k_adj_rc1) for the groups whose records fit its LDS; KSH_RC1=marks: pass 1 as it was
+      // both passes turned round (k_adj_rc1) for the groups whose records fit its LDS; KSH_RC1=marks: k_adj_rc for all
       static const bool rc1_marks = [] {
         const char* e = getenv("KSH_RC1");
         return e && std::string(e) == "marks";
       }();
-      // (LDS for the average group and a quarter, so that small groups share a CU many at a time -- the records of a
-      // group are a Poisson count; a group beyond it keeps pass 1 as it was, both kernels decide by the same number)
-      const int rc1_cap = rc1_marks ? 0 : int(std::min<int64_t>(Rc1Cfg<KeyT>::kCap, (per_group * 5 / 4 + 263) & ~int64_t(7)));
-      const int pass1_cap = rc1_marks ? -1 : rc1_cap;  // (k_adj_rc: groups of at most that many records leave pass 1 out)
-      int rc1_slices = 64;                             // about a slice per two records
-      while (rc1_slices < kRc1Slices && 2 * rc1_slices < rc1_cap) rc1_slices <<= 1;
-      const size_t rc1_lds = size_t(rc1_slices) * 4 + size_t(rc1_cap) * (sizeof(KeyT) + 6);
-      KSH_BOUND(rc1_lds <= size_t(kRc1LdsBytes) && rc1_cap % 8 == 0 && (rc1_slices & (rc1_slices - 1)) == 0);
+      // (LDS for the average group and a third -- the records of a group are a Poisson count around +-19 % by the first
+      // base of G -- so that small groups share a CU many at a time; a group beyond it stays with k_adj_rc, both kernels
+      // decide by the same number)
+      const int rc1_cap = rc1_marks ? 0 : int(std::min<int64_t>(Rc1Cfg<KeyT>::kCap, (per_group * 4 / 3 + 263) & ~int64_t(7)));
+      const int pass1_cap = rc1_marks ? -1 : rc1_cap;  // (k_adj_rc: groups of at most that many records are k_adj_rc1's)
+      int rc1_sbits = 6;                               // a slice per one or two records; a chain link has sbits + 1 bits
+      while ((1 << rc1_sbits) < kRc1SlicesMax && (2 << rc1_sbits) <= rc1_cap + 1) rc1_sbits++;
+      const size_t rc1_lds = (size_t(4) << rc1_sbits) + size_t(rc1_cap) * Rc1Cfg<KeyT>::kEntryBytes;
+      KSH_BOUND(rc1_lds <= size_t(kRc1LdsBytes) && rc1_cap % 8 == 0 && rc1_cap < (2 << rc1_sbits) - 1);
       if (!rc1_marks) p->routes |= KSH_ROUTE_RC1_STREAMED;
       if (per_group > 4096) {
         hipLaunchKernelGGL((k_adj_rc<KeyT, 1024>), dim3(unsigned(ng)), dim3(1024), rc_lds, st, set, gbits, goff,
                            rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched, pass1_cap);
         if (!rc1_marks)
           hipLaunchKernelGGL((k_adj_rc1<KeyT, 1024>), dim3(unsigned(ng)), dim3(1024), rc1_lds, st, set, gbits, goff, rec,
-                             pb, rc1_cap, rc1_slices, rc1);
+                             pb, pb0, rc1_cap, rc1_sbits, rc0, rc1);
       } else if (per_group > 1024) {
         hipLaunchKernelGGL((k_adj_rc<KeyT, 512>), dim3(unsigned(ng)), dim3(512), rc_lds, st, set, gbits, goff,
                            rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched, pass1_cap);
         if (!rc1_marks)
           hipLaunchKernelGGL((k_adj_rc1<KeyT, 512>), dim3(unsigned(ng)), dim3(512), rc1_lds, st, set, gbits, goff, rec,
-                             pb, rc1_cap, rc1_slices, rc1);
+                             pb, pb0, rc1_cap, rc1_sbits, rc0, rc1);
       } else if (per_group > 256) {
         hipLaunchKernelGGL((k_adj_rc<KeyT, 256>), dim3(unsigned(ng)), dim3(256), rc_lds, st, set, gbits, goff,
                            rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched, pass1_cap);
         if (!rc1_marks)
           hipLaunchKernelGGL((k_adj_rc1<KeyT, 256>), dim3(unsigned(ng)), dim3(256), rc1_lds, st, set, gbits, goff, rec,
-                             pb, rc1_cap, rc1_slices, rc1);
+                             pb, pb0, rc1_cap, rc1_sbits, rc0, rc1);
       } else {
         hipLaunchKernelGGL((k_adj_rc<KeyT, 64>), dim3(unsigned(ng)), dim3(64), rc_lds, st, set, gbits, goff,
                            rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched, pass1_cap);
         if (!rc1_marks)
           hipLaunchKernelGGL((k_adj_rc1<KeyT, 64>), dim3(unsigned(ng)), dim3(64), rc1_lds, st, set, gbits, goff, rec,
-                             pb, rc1_cap, rc1_slices, rc1);
+                             pb, pb0, rc1_cap, rc1_sbits, rc0, rc1);
       }
       // KSH_FWD=probe: the forward half in place; =staged: round 3's five staged windows per chunk; default: one
       // window per workgroup, the probes marked at their targets (k_adj_fwd_targets)

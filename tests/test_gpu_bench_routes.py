@@ -128,7 +128,8 @@ def _run_route(env_add, size):
 
 def test_route_differential_1e8(gpu):
     """At the bench's size -- a 10^8-k-mer genome set, its intersection with a sibling and the difference set --
-    the default route (k_adj_rc<u32, 1024> with two batches for the dense groups, two-level scatter and jumping,
+    the default route (k_adj_rc1<u32, 1024>: the groups' records chained in LDS, their ranges streamed; k_adj_rc for
+    the groups that do not fit; k_adj_fwd_targets; two-level scatter and jumping,
     one-launch ranking, strings from the walk logs) and the route of independent, size-independent kernels
     (k_adjacency probing in global memory, stamping walks + k_choose, k_emit) write the same SPSS words and
     lengths, byte for byte.  The switches are read once per process: two processes."""
@@ -136,7 +137,7 @@ def test_route_differential_1e8(gpu):
     default = _run_route({}, size)
     other = _run_route({"KSH_ADJACENCY": "probe", "KSH_RANK": "stamp", "KSH_EMIT": "walk"}, size)
     r = set(default["genome"]["routes"])
-    assert {"probe_staged", "rc_1024", "rc_batched", "scatter_two_level", "fwd_targets", "rank_one_launch",
+    assert {"probe_staged", "rc_1024", "rc1_streamed", "scatter_two_level", "fwd_targets", "rank_one_launch",
             "jump_two_level", "emit_logs"} <= r, sorted(r)
     assert "probe_staged" not in other["genome"]["routes"] and "rank_stamped" in other["genome"]["routes"]
     for name in ("genome", "intersection", "difference"):

@@ -31,7 +31,7 @@ rocprofv3 --kernel-trace --output-format csv --pmc WRITE_SIZE -d $O/${TAG}_pmc_w
 echo write done
 F=$(find $O/${TAG}_pmc_fetch -name "*counter_collection.csv" | head -1)
 W=$(find $O/${TAG}_pmc_write -name "*counter_collection.csv" | head -1)
-STAGE=k_rc_hist,k_rc_columns,k_rc_scatter,k_rc_scatter_l1,k_rc_scatter_l2,k_rc_bounds,k_adj_rc,k_tgt_bounds,k_tgt_split,k_tgt_subcuts,k_adj_fwd_targets
+STAGE=k_rc_hist,k_rc_columns,k_rc_scatter,k_rc_scatter_l1,k_rc_scatter_l2,k_rc_bounds,k_adj_rc,k_adj_rc1,k_tgt_bounds,k_tgt_split,k_tgt_subcuts,k_adj_fwd_targets
 python3 $R/tools/pmc_kernel.py $F $W $STAGE $O/${TAG}_pmc_adjacency_stage.json --units-from k_link_cut
 python3 $R/tools/pmc_kernel.py $F $W k_rank_walk,k_rank_heads,k_rank_unset,k_ruler_jump,k_l2_walk,k_l2_jump,k_l2_resolve $O/${TAG}_pmc_ranking_walks.json --units-from k_link_cut
 python3 $R/tools/pmc_kernel.py $F $W k_emit_log_rulers,k_emit_log_heads $O/${TAG}_pmc_emit_from_logs.json --units-from k_link_cut

@@ -22,7 +22,7 @@ device buffers.
 
 Prints ONE JSON line on rank 0.
   roofline     the loop's dominant stage, the neighbour probe of the SPSS encode (the rc partition,
-               k_adj_rc and k_adj_fwd_targets; one timed "launch" = the stage of one encode):
+               k_adj_rc1 and k_adj_fwd_targets; one timed "launch" = the stage of one encode):
                algorithmic bytes = 5.3 B per k-mer (read key + write adjacency byte
                + packed bases) x the k-mers of a launch, over its HIP-event duration on the
                context's stream, against the 8 TB/s HBM peak; the probe-inclusive figure
@@ -521,7 +521,7 @@ def main():
             "roofline": {
                 "bound": "hbm",
                 "kernel": "neighbour-probe stage of the SPSS encode (k_rc_hist / k_rc_columns / k_rc_scatter_l1+l2 / k_rc_bounds / "
-                          "k_adj_rc / k_tgt_bounds / k_tgt_split / k_tgt_subcuts / k_adj_fwd_targets; the in-place k_adjacency for sets outside their range): "
+                          "k_adj_rc1 (k_adj_rc for groups whose records do not fit it) / k_tgt_bounds / k_tgt_split / k_tgt_subcuts / k_adj_fwd_targets; the in-place k_adjacency for sets outside their range): "
                           "one timed launch = the whole stage of one encode",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,

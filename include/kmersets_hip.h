@@ -325,7 +325,8 @@ enum {
   KSH_ROUTE_LONG_STRETCHES = 1 << 13,    /* ... and some stretch outgrew its log (the long list) */
   KSH_ROUTE_MATCH_MORE_ROUNDS = 1 << 14, /* the matching needed more than its first batch of rounds */
   KSH_ROUTE_FWD_TARGETS = 1 << 15,       /* k_adj_fwd_targets: forward probes marked at their targets, one search per k-mer */
-  KSH_ROUTE_RC1_STREAMED = 1 << 16       /* k_adj_rc1: pass 1 of k_adj_rc turned round (records in LDS, the ranges streamed) */
+  KSH_ROUTE_RC1_STREAMED = 1 << 16,      /* k_adj_rc1: k_adj_rc turned round (a group's records in LDS, its ranges streamed) */
+  KSH_ROUTE_RC_MARKS_GROUPS = 1 << 17    /* ... and k_adj_rc ran for some group whose records did not fit k_adj_rc1 */
 };
 int ksh_spss_encode_routes(ksh_ctx* ctx, int64_t* routes);
 /* Frees the current plan's device memory (also done by the next plan / ctx_destroy). */

@@ -647,7 +647,7 @@ template <typename KeyT, int kRcThreads>
 __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 512 ? 8 : (kRcThreads >= 128 ? kRcThreads / 128 : 1))) void k_adj_rc(
     DevSet<KeyT> set, int gbits, const int64_t* __restrict__ goff, const RcRecord<KeyT>* __restrict__ rec,
     const int64_t* __restrict__ pb, const int64_t* __restrict__ pb0, int cap, uint32_t* __restrict__ rc0,
-    uint32_t* __restrict__ rc1, int* __restrict__ batched, int pass1_cap) {
+    uint32_t* __restrict__ rc1, int* __restrict__ batched, int pass1_cap, int* __restrict__ taken) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   KeyT* skeys = reinterpret_cast<KeyT*>(lds_raw);
   uint32_t* slots = reinterpret_cast<uint32_t*>(lds_raw + size_t(cap) * sizeof(KeyT));
@@ -664,6 +664,7 @@ __global__ __launch_bounds__(kRcThreads, (kRcThreads >= 512 ? 8 : (kRcThreads >=
   const uint64_t kmask = kmer_mask(k);
   const int64_t r0 = goff[grp], r1 = goff[grp + 1];
   if (r1 - r0 <= int64_t(pass1_cap)) return;  // a group of at most that many records is k_adj_rc1's, both passes
+  if (pass1_cap >= 0 && threadIdx.x == 0) *taken = 1;  // (ksh_spss_encode_routes: some group did not fit k_adj_rc1)
   // pass 0's range: the bucket's offsets, or the searched bounds of a finer group
   const int64_t p0_lo = pb0 ? pb0[2 * grp] : set.off[grp], p0_hi = pb0 ? pb0[2 * grp + 1] : set.off[grp + 1];
   // the bits of a bucket key that a pass-0 target of this group starts with (the group bits below the bucket's)
@@ -3463,7 +3464,7 @@ struct EncCtl {
   int64_t tot[3 + kLenSums];  // [0..1] unitig counts by class, [2 .. 2 + kLenSums) k-mers the unitigs account
                               // for (partial sums), [2 + kLenSums] (as an int) a ruler on a loop
   int self_rc;                // a canonical set holds a k-mer equal to its own reverse complement
-  int pad;
+  int rc_marks;               // k_adj_rc ran for a group whose records did not fit k_adj_rc1
   int64_t t2[2];              // strings by class: class 0 | class 1 << 32, class 2
   int64_t n_bases;            // total of the string lengths in bases
   unsigned long long sc_used; // k_loop_cut's scratch cursor
@@ -3814,25 +3815,25 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
       if (!rc1_marks) p->routes |= KSH_ROUTE_RC1_STREAMED;
       if (per_group > 4096) {
         hipLaunchKernelGGL((k_adj_rc<KeyT, 1024>), dim3(unsigned(ng)), dim3(1024), rc_lds, st, set, gbits, goff,
-                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched, pass1_cap);
+                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched, pass1_cap, &ctl->rc_marks);
         if (!rc1_marks)
           hipLaunchKernelGGL((k_adj_rc1<KeyT, 1024>), dim3(unsigned(ng)), dim3(1024), rc1_lds, st, set, gbits, goff, rec,
                              pb, pb0, rc1_cap, rc1_sbits, rc0, rc1);
       } else if (per_group > 1024) {
         hipLaunchKernelGGL((k_adj_rc<KeyT, 512>), dim3(unsigned(ng)), dim3(512), rc_lds, st, set, gbits, goff,
-                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched, pass1_cap);
+                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched, pass1_cap, &ctl->rc_marks);
         if (!rc1_marks)
           hipLaunchKernelGGL((k_adj_rc1<KeyT, 512>), dim3(unsigned(ng)), dim3(512), rc1_lds, st, set, gbits, goff, rec,
                              pb, pb0, rc1_cap, rc1_sbits, rc0, rc1);
       } else if (per_group > 256) {
         hipLaunchKernelGGL((k_adj_rc<KeyT, 256>), dim3(unsigned(ng)), dim3(256), rc_lds, st, set, gbits, goff,
-                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched, pass1_cap);
+                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched, pass1_cap, &ctl->rc_marks);
         if (!rc1_marks)
           hipLaunchKernelGGL((k_adj_rc1<KeyT, 256>), dim3(unsigned(ng)), dim3(256), rc1_lds, st, set, gbits, goff, rec,
                              pb, pb0, rc1_cap, rc1_sbits, rc0, rc1);
       } else {
         hipLaunchKernelGGL((k_adj_rc<KeyT, 64>), dim3(unsigned(ng)), dim3(64), rc_lds, st, set, gbits, goff,
-                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched, pass1_cap);
+                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched, pass1_cap, &ctl->rc_marks);
         if (!rc1_marks)
           hipLaunchKernelGGL((k_adj_rc1<KeyT, 64>), dim3(unsigned(ng)), dim3(64), rc1_lds, st, set, gbits, goff, rec,
                              pb, pb0, rc1_cap, rc1_sbits, rc0, rc1);
@@ -4054,6 +4055,8 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
     if (*reinterpret_cast<int*>(ctx->h_pinned + 3 + kLenSums))
       return fail(KSH_INVALID_ARGUMENT, "the canonical set holds a k-mer that is its own reverse "
                                         "complement (even k): not supported");
+    static_assert(offsetof(EncCtl, rc_marks) == offsetof(EncCtl, self_rc) + 4, "the word behind self_rc, in the same copy");
+    if (reinterpret_cast<int*>(ctx->h_pinned + 3 + kLenSums)[1]) p->routes |= KSH_ROUTE_RC_MARKS_GROUPS;
     p->stamped = stamped;
     p->rinfo = rinfo;
     p->chain_info = chain_info;

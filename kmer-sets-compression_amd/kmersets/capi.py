@@ -578,7 +578,7 @@ class Context:
 
     ROUTES = ("probe_staged", "rc_1024", "rc_512", "rc_256", "rc_64", "rc_batched", "scatter_two_level",
               "fwd_staged", "rank_one_launch", "heads_one_launch", "jump_two_level", "rank_stamped", "emit_logs",
-              "long_stretches", "match_more_rounds", "fwd_targets", "rc1_streamed")
+              "long_stretches", "match_more_rounds", "fwd_targets", "rc1_streamed", "rc_marks_groups")
 
     def spss_encode_routes(self):
         """The kernel variants the last encode plan ran (KSH_ROUTE_* of include/kmersets_hip.h), as a set of names."""

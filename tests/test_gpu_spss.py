@@ -376,6 +376,33 @@ def test_encode_branching_sets(ctx):
             assert st["unitigs"] > 700 and st["strings"] < st["unitigs"]
 
 
+def test_encode_skewed_rc_groups(ctx):
+    """k_adj_rc1 takes the groups whose reverse-complement records fit its LDS -- sized from the AVERAGE group -- and
+    k_adj_rc the others, in the same encode: a genome's k-mers (a dozen records per group) plus 6000 k-mers that
+    carry one fixed 7-base block where the group id is read (bases k-8 .. k-2 of x, i.e. 1 .. 7 of rc(x)): those
+    that stay canonical crowd one group far beyond the window.  Strings == the oracle's, both routes reported."""
+    k, n, kb = 23, 14, 4
+    rng = np.random.default_rng(23)
+    base = synth.phylogeny_sets(k, 1, 200000, seed=19)[0]
+    x = rng.integers(0, 4 ** k, size=6000, dtype=np.uint64)
+    block = np.uint64(0b10_01_11_00_01_10_11)  # G C T A C G T
+    x = (x & ~np.uint64(0xFFFC)) | (block << np.uint64(2))
+    kmers = np.unique(np.concatenate([base, synth.canonical(x, k)]))
+    d = capi.DeviceSet.from_kmers(capi.geom(k, n), kmers, ctx.device)
+    sp = ctx.spss_encode(d, mode=0)
+    routes = ctx.spss_encode_routes()
+    assert {"probe_staged", "rc1_streamed", "rc_marks_groups", "fwd_targets"} <= routes, sorted(routes)
+    want = ol.Set.from_kmers(k, n, kb, kmers).spss()
+    assert sp.to_strings() == want
+    back = ctx.spss_decode(sp)
+    assert back.n_keys == d.n_keys and ctx.set_diff(back, d) == 0
+    # a set without the crowd takes k_adj_rc1 alone
+    d2 = capi.DeviceSet.from_kmers(capi.geom(k, n), base, ctx.device)
+    sp2 = ctx.spss_encode(d2, mode=0)
+    assert "rc_marks_groups" not in ctx.spss_encode_routes()
+    assert sp2.to_strings() == ol.Set.from_kmers(k, n, kb, base).spss()
+
+
 def test_encode_repeat_rich(ctx):
     """A repeat-rich family (synth.plant_repeats: stretches of 50..500 bases copied to several loci): the unitig
     graph branches at both ends of every copy -- tens of thousands of unitigs, junctions with several candidate

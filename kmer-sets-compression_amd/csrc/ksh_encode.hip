@@ -1609,7 +1609,10 @@ __global__ __launch_bounds__(kTgtThreads, 8) void k_adj_fwd_targets(DevSet<KeyT>
   __syncthreads();
   KSH_PMARK(0, 3);
   const auto range_of = [&](int idx) { return (idx >= c1 ? 1 : 0) + (idx >= c2 ? 1 : 0) + (idx >= c3 ? 1 : 0); };
-  // the next k-mer of this thread is requested before this one's search
+  // the next k-mer of this thread is requested before this one's search.  (Measured and dropped: TWO k-mers of the
+  // stream per thread and turn, their searches step by step side by side -- the waves of this kernel wait 75 % of their
+  // cycles and issue 16 %, `tools/pmc_stalls.sh` -- 891 / 78 / 794 us on the genome / difference / intersection sets
+  // against 895 / 70 / 815: what the waves wait for is not the one search's chain of LDS reads alone.)
   KeyT key_next = 0;
   uint32_t rc_next = kNone;
   if (tid < total) {

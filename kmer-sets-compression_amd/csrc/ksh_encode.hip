@@ -16,10 +16,14 @@
 //
 //   neighbour probe: per side none / the single neighbour / many, from the 8 candidates of a k-mer
 //                 (4 Next, 4 Prev, forward or reverse complement).  Canonical sets: k_rc_* deal the
-//                 k-mers out by the bucket their reverse complement's successors lie in, k_adj_rc
-//                 marks the targets in an LDS window, k_adj_fwd_staged probes the forward half in
-//                 five LDS windows per 512 k-mers; k_adjacency: the same by searches in global
-//                 memory (non-canonical sets, geometries outside the staged kernels' range)
+//                 k-mers out (as records) by the bucket their reverse complement's successors lie in;
+//                 k_adj_rc1 chains a group's records in LDS and lets the k-mers of the group's ranges
+//                 look for them (k_adj_rc, for groups too large for that: the records look for the
+//                 k-mers in staged windows and mark them); k_adj_fwd_targets does the forward half with
+//                 one search per k-mer, the Prev side read off the marks the Next probes leave at their
+//                 targets (k_adj_fwd_staged: five searches in five windows); k_adjacency: all of it by
+//                 searches in global memory (non-canonical sets, geometries outside the staged kernels'
+//                 range)
 //   k_link_cut    mutual singles: the k-mers with several neighbours on a side cut the facing entries
 //   k_end_*       the end k-mers (a side without a link), compacted once
 //   k_rank_walk / k_rank_heads / k_ruler_jump / k_l2_*   chains of states ranked through a sparse ruler

@@ -2106,13 +2106,19 @@ __global__ __launch_bounds__(256) void k_ruler_jump(int64_t n_dense,
 // ---- the same result in two levels (ranking without stamps): pointer jumping costs a cache-missing
 // read per ruler per round (the ruler records of a 10^8-k-mer set are 50 MB) for log2(rulers per
 // chain) rounds -- 24 for a genome.  The ruler records form linked lists themselves, so they are
-// ranked the way the k-mers are: every 32nd sampled k-mer is a level-2 ruler, the level-2 rulers
+// ranked the way the k-mers are: every 16th sampled k-mer is a level-2 ruler, the level-2 rulers
 // and the first ruler of every chain (the one whose mirror image reaches a chain end without
 // meeting a ruler: nothing comes before it) walk along the records to the next level-2 ruler or
 // the end, stamping what they pass with (walker, distance so far); pointer jumping then runs over
-// the level-2 rulers only (1/32 of the records, L2-resident), and k_l2_resolve gives every record
+// the level-2 rulers only (1/16 of the records, L2-resident), and k_l2_resolve gives every record
 // its end and distance through its stamp.  Records on a loop of rulers stay without an end.
-constexpr int kL2Shift = 5;
+// (every 16th: measured per 10^8-k-mer genome / 9 x 10^7 intersection set, the four k_l2_* kernels together: every
+// 32nd 462 / 371 us -- 2 x 10^5 walkers of 32 dependent steps do not fill the GPU --, every 16th 392 / 353, every 8th
+// 393 / 340: the jumping rounds over more level-2 records take back what the shorter walks give)
+#ifndef KSH_L2_SHIFT
+#define KSH_L2_SHIFT 4
+#endif
+constexpr int kL2Shift = KSH_L2_SHIFT;
 __device__ __forceinline__ bool is_level2(int64_t i) { return ((i >> 1) & ((1 << kL2Shift) - 1)) == 0; }
 __device__ __forceinline__ int64_t level2_index(int64_t i) { return ((i >> (kL2Shift + 1)) << 1) | (i & 1); }
 __device__ __forceinline__ int64_t level2_entry(int64_t j) { return ((j >> 1) << (kL2Shift + 1)) | (j & 1); }
@@ -2121,8 +2127,8 @@ __device__ __forceinline__ int64_t level2_entry(int64_t j) { return ((j >> 1) <<
 //   r2[j]    (level-2 ruler j): end:1 | dist:31 | ref:32 -- the next level-2 ruler (record index) or the end state
 //   head[i]  (chain head i, not level 2): the same
 //   stamp[e] (everything they pass): dist:32 | walker record:32
-// (two launches: the level-2 rulers, one thread each -- they are every 32nd pair of records and all of
-// them walk some 32 steps -- and the chain heads, found by a thread per record)
+// (two launches: the level-2 rulers, one thread each -- they are every 16th pair of records and all of
+// them walk some 16 steps -- and the chain heads, found by a thread per record)
 template <bool kLevel2>
 __global__ __launch_bounds__(256) void k_l2_walk(const unsigned long long* __restrict__ rinfo, int64_t n_dense,
                                                   unsigned long long* __restrict__ r2,

@@ -314,7 +314,7 @@ enum {
   KSH_ROUTE_RC_512 = 1 << 2,
   KSH_ROUTE_RC_256 = 1 << 3,
   KSH_ROUTE_RC_64 = 1 << 4,
-  KSH_ROUTE_RC_BATCHED = 1 << 5,         /* some group's ranges took several batches of its LDS window */
+  KSH_ROUTE_RC_BATCHED = 1 << 5,         /* some group took several batches: of its records (k_adj_rc1) or of its ranges (k_adj_rc) */
   KSH_ROUTE_SCATTER_TWO_LEVEL = 1 << 6,  /* k_rc_scatter_l1 / _l2 instead of k_rc_scatter */
   KSH_ROUTE_FWD_STAGED = 1 << 7,         /* k_adj_fwd_staged (KSH_FWD=staged) instead of k_adj_fwd */
   KSH_ROUTE_RANK_ONE_LAUNCH = 1 << 8,    /* all ruler walkers in one launch (mirror images racing) */

@@ -902,8 +902,8 @@ template <typename KeyT, int kThreads>
 __global__ __launch_bounds__(kThreads) void k_adj_rc1(DevSet<KeyT> set, int gbits, const int64_t* __restrict__ goff,
                                                       const RcRecord<KeyT>* __restrict__ rec,
                                                       const int64_t* __restrict__ pb, const int64_t* __restrict__ pb0,
-                                                      int cap, int sbits, uint32_t* __restrict__ rc0,
-                                                      uint32_t* __restrict__ rc1) {
+                                                      int cap, int sbits, int batched, uint32_t* __restrict__ rc0,
+                                                      uint32_t* __restrict__ rc1, int* __restrict__ took_batches) {
   constexpr bool kPacked = Rc1Cfg<KeyT>::kPacked;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
   uint32_t* head = reinterpret_cast<uint32_t*>(lds_raw);
@@ -918,8 +918,11 @@ __global__ __launch_bounds__(kThreads) void k_adj_rc1(DevSet<KeyT> set, int gbit
   const int tid = threadIdx.x;
   const int64_t grp = blockIdx.x;
   const int64_t r0 = goff[grp], r1 = goff[grp + 1];
-  if (r1 - r0 > int64_t(cap)) return;  // k_adj_rc has this group
-  const int n_rec = int(r1 - r0);
+  if (!batched && r1 - r0 > int64_t(cap)) return;  // k_adj_rc has this group
+  // (KSH_RC1=batched) a group of more records than fit is taken in batches of `cap`: the streams run once per batch, a
+  // k-mer's verdict of the batches before is read back and merged (none -> the single neighbour -> several)
+  const int n_rec = int(r1 - r0 < int64_t(cap) ? r1 - r0 : int64_t(cap));
+  if (r1 - r0 > int64_t(cap) && threadIdx.x == 0) *took_batches = 1;  // (ksh_spss_encode_routes)
   const int rest_bits = 2 * set.k - 4 - gbits;  // bits of a record key between its top base and its last base
   const uint64_t rest_mask = (uint64_t(1) << rest_bits) - 1;
   const uint64_t low_mask = (uint64_t(1) << (rest_bits + 2)) - 1;  // a record key without its top base
@@ -980,6 +983,19 @@ __global__ __launch_bounds__(kThreads) void k_adj_rc1(DevSet<KeyT> set, int gbit
     i_next = place(tid, &tb_next);
     key_next = set.keys[i_next];
   }
+  const auto chain_in = [&](int i, const RcRecord<KeyT>& rr) {
+    const uint64_t key = uint64_t(rr.key);
+    const uint32_t sl = uint32_t(key >> 2) & slice_mask;
+    const uint32_t before = atomicExch(&head[sl], uint32_t(i));  // (none = all ones in sbits + 1 bits)
+    if (kPacked) {
+      const uint64_t kf = ((key >> (2 + e_sbits)) << 2) | (key & 3);
+      entry[i] = (uint64_t(rr.t) << t_shift) | (uint64_t(before) << kf_bits) | kf;
+    } else {
+      rkey[i] = rr.key;
+      rt[i] = rr.t;
+      nxt[i] = uint16_t(before);
+    }
+  };
   for (int base = 0; base < n_rec; base += 4 * kThreads) {
     if (base > 0) {
 #pragma unroll
@@ -991,19 +1007,7 @@ __global__ __launch_bounds__(kThreads) void k_adj_rc1(DevSet<KeyT> set, int gbit
 #pragma unroll
     for (int u = 0; u < 4; u++) {
       const int i = base + u * kThreads + tid;
-      if (i < n_rec) {
-        const uint64_t key = uint64_t(r[u].key);
-        const uint32_t sl = uint32_t(key >> 2) & slice_mask;
-        const uint32_t before = atomicExch(&head[sl], uint32_t(i));  // (none = all ones in sbits + 1 bits)
-        if (kPacked) {
-          const uint64_t kf = ((key >> (2 + e_sbits)) << 2) | (key & 3);
-          entry[i] = (uint64_t(r[u].t) << t_shift) | (uint64_t(before) << kf_bits) | kf;
-        } else {
-          rkey[i] = r[u].key;
-          rt[i] = r[u].t;
-          nxt[i] = uint16_t(before);
-        }
-      }
+      if (i < n_rec) chain_in(i, r[u]);
     }
   }
   __syncthreads();
@@ -1023,36 +1027,23 @@ __global__ __launch_bounds__(kThreads) void k_adj_rc1(DevSet<KeyT> set, int gbit
       }
     }
   };
-  // pass 0: y of the group's own range against the records [a][y without its last base], whatever a
-  {
-    const uint64_t hi_mask = (uint64_t(1) << (rest_bits - e_sbits)) - 1;  // (the rest above the chain's bits, without tb)
-#pragma unroll 1
-    for (int64_t i = p0_lo + tid; i < p0_hi; i += kThreads) {
-      const KeyT ykey = y_next;
-      if (i + kThreads < p0_hi) y_next = set.keys[i + kThreads];
-      const uint64_t low = (uint64_t(ykey) >> 2) & low_mask;  // the records' key below their top base
-      const uint64_t want = ((low >> (2 + e_sbits)) << 2) | (low & 3);
-      int cnt = 0;
-      uint32_t single = kNone;
-      walk(uint32_t(low >> 2) & slice_mask, [&](uint64_t kf, uint32_t t) {
-        if ((((kf >> 2) & hi_mask) << 2 | (kf & 3)) == want && t != uint32_t(i)) {  // (t == i: y = Next(rc(y), c), the k-mer itself)
-          cnt++;
-          single = (t << 1) | 1u;
-        }
-      });
-      rc0[i] = cnt == 0 ? kNone : (cnt == 1 ? single : kMulti);
-    }
-  }
-  // pass 1: z of range [c][tb][G] against the records [tb][z's rest][c'], whatever c'
-#pragma unroll 1
-  for (int idx = tid; idx < total; idx += kThreads) {
-    const int tb = tb_next;
-    const int64_t i = i_next;
-    const KeyT key = key_next;
-    if (idx + kThreads < total) {
-      i_next = place(idx + kThreads, &tb_next);
-      key_next = set.keys[i_next];
-    }
+  const uint64_t hi_mask = (uint64_t(1) << (rest_bits - e_sbits)) - 1;  // (the rest above the chain's bits, without tb)
+  // pass 0: y (index i, key ykey) of the group's own range against the records [a][y without its last base], whatever a
+  const auto look0 = [&](int64_t i, KeyT ykey) {
+    const uint64_t low = (uint64_t(ykey) >> 2) & low_mask;  // the records' key below their top base
+    const uint64_t want = ((low >> (2 + e_sbits)) << 2) | (low & 3);
+    int cnt = 0;
+    uint32_t single = kNone;
+    walk(uint32_t(low >> 2) & slice_mask, [&](uint64_t kf, uint32_t t) {
+      if ((((kf >> 2) & hi_mask) << 2 | (kf & 3)) == want && t != uint32_t(i)) {  // (t == i: y = Next(rc(y), c), the k-mer itself)
+        cnt++;
+        single = (t << 1) | 1u;
+      }
+    });
+    return cnt == 0 ? kNone : (cnt == 1 ? single : kMulti);
+  };
+  // pass 1: z (index i, key) of range [c][tb][G] against the records [tb][z's rest][c'], whatever c'
+  const auto look1 = [&](int64_t i, int tb, KeyT key) {
     const uint64_t q = (uint64_t(tb) << rest_bits) | (uint64_t(key) & rest_mask);  // Next(z, .) >> 2, as a record key
     const uint64_t want = q >> e_sbits;
     int cnt = 0;
@@ -1063,7 +1054,49 @@ __global__ __launch_bounds__(kThreads) void k_adj_rc1(DevSet<KeyT> set, int gbit
         single = (t << 1) | 1u;
       }
     });
-    rc1[i] = cnt == 0 ? kNone : (cnt == 1 ? single : kMulti);
+    return cnt == 0 ? kNone : (cnt == 1 ? single : kMulti);
+  };
+  // what a batch found, added to what the batches before it found
+  const auto merged = [](uint32_t now, uint32_t before) {
+    const int total = (now == kNone ? 0 : (now == kMulti ? 2 : 1)) + (before == kNone ? 0 : (before == kMulti ? 2 : 1));
+    return total == 0 ? kNone : (total > 1 ? kMulti : (now != kNone ? now : before));
+  };
+#pragma unroll 1
+  for (int64_t i = p0_lo + tid; i < p0_hi; i += kThreads) {
+    const KeyT ykey = y_next;
+    if (i + kThreads < p0_hi) y_next = set.keys[i + kThreads];
+    rc0[i] = look0(i, ykey);
+  }
+#pragma unroll 1
+  for (int idx = tid; idx < total; idx += kThreads) {
+    const int tb = tb_next;
+    const int64_t i = i_next;
+    const KeyT key = key_next;
+    if (idx + kThreads < total) {
+      i_next = place(idx + kThreads, &tb_next);
+      key_next = set.keys[i_next];
+    }
+    rc1[i] = look1(i, tb, key);
+  }
+  // the batches after the first (groups of 30 000 records: 5 x 10^8 k-mers in 2^14 buckets, 10^8 in 2^10)
+#pragma unroll 1
+  for (int64_t rb = r0 + cap; rb < r1; rb += cap) {
+    const int n_b = int(r1 - rb < int64_t(cap) ? r1 - rb : int64_t(cap));
+    __syncthreads();  // everybody is through with the chains of the batch before
+    for (int sl = tid; sl < n_slices; sl += kThreads) head[sl] = none;
+    __syncthreads();
+    for (int i = tid; i < n_b; i += kThreads) chain_in(i, rec[rb + i]);
+    __syncthreads();
+    for (int64_t i = p0_lo + tid; i < p0_hi; i += kThreads) {
+      const uint32_t now = look0(i, set.keys[i]);
+      if (now != kNone) rc0[i] = merged(now, rc0[i]);
+    }
+    for (int idx = tid; idx < total; idx += kThreads) {
+      int tb;
+      const int64_t i = place(idx, &tb);
+      const uint32_t now = look1(i, tb, set.keys[i]);
+      if (now != kNone) rc1[i] = merged(now, rc1[i]);
+    }
   }
 }
 
@@ -3811,46 +3844,46 @@ int encode_plan_t(ksh_ctx* ctx, const ksh_geom* g, const ksh_set_view* sv, bool 
                          gbits, pb, pb0);
       p->routes |= per_group > 4096 ? KSH_ROUTE_RC_1024 : per_group > 1024 ? KSH_ROUTE_RC_512
                    : per_group > 256 ? KSH_ROUTE_RC_256 : KSH_ROUTE_RC_64;
-      // both passes turned round (k_adj_rc1) for the groups whose records fit its LDS; KSH_RC1=marks: k_adj_rc for all
-      static const bool rc1_marks = [] {
+      // k_adj_rc1 (the k-mers look for the records) for the groups whose records fit its LDS, k_adj_rc for the others;
+      // KSH_RC1=batched: k_adj_rc1 for every group, a group of more records than fit in batches -- measured at the end of
+      // round 4 and not the default: the streams run once per batch, and 8 x 5 x 10^8 k = 31 (30 000 16-byte records per
+      // group, seven batches) takes 0.757 s against 0.742, 4 x 2 x 10^7 (19, 8) 20.4 ms against 19.9, 4 x 10^8 k = 31
+      // (two batches) 62.3 against 59.4; KSH_RC1=marks: k_adj_rc for all (rounds 2-3)
+      static const int rc1_mode = [] {
         const char* e = getenv("KSH_RC1");
-        return e && std::string(e) == "marks";
+        return !e ? 1 : (std::string(e) == "marks" ? 2 : (std::string(e) == "batched" ? 0 : 1));
       }();
+      const bool rc1_marks = rc1_mode == 2;
       // (LDS for the average group and a third -- the records of a group are a Poisson count around +-19 % by the first
-      // base of G -- so that small groups share a CU many at a time; a group beyond it stays with k_adj_rc, both kernels
-      // decide by the same number)
+      // base of G -- so that small groups share a CU many at a time; both kernels decide by the same number)
       const int rc1_cap = rc1_marks ? 0 : int(std::min<int64_t>(Rc1Cfg<KeyT>::kCap, (per_group * 4 / 3 + 263) & ~int64_t(7)));
-      const int pass1_cap = rc1_marks ? -1 : rc1_cap;  // (k_adj_rc: groups of at most that many records are k_adj_rc1's)
+      // (k_adj_rc: groups of at most that many records are k_adj_rc1's)
+      const int pass1_cap = rc1_marks ? -1 : rc1_cap;
+      const bool with_rc = rc1_mode != 0;  // k_adj_rc is launched at all
       int rc1_sbits = 6;                               // a slice per one or two records; a chain link has sbits + 1 bits
       while ((1 << rc1_sbits) < kRc1SlicesMax && (2 << rc1_sbits) <= rc1_cap + 1) rc1_sbits++;
       const size_t rc1_lds = (size_t(4) << rc1_sbits) + size_t(rc1_cap) * Rc1Cfg<KeyT>::kEntryBytes;
       KSH_BOUND(rc1_lds <= size_t(kRc1LdsBytes) && rc1_cap % 8 == 0 && rc1_cap < (2 << rc1_sbits) - 1);
       if (!rc1_marks) p->routes |= KSH_ROUTE_RC1_STREAMED;
-      if (per_group > 4096) {
-        hipLaunchKernelGGL((k_adj_rc<KeyT, 1024>), dim3(unsigned(ng)), dim3(1024), rc_lds, st, set, gbits, goff,
-                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched, pass1_cap, &ctl->rc_marks);
-        if (!rc1_marks)
-          hipLaunchKernelGGL((k_adj_rc1<KeyT, 1024>), dim3(unsigned(ng)), dim3(1024), rc1_lds, st, set, gbits, goff, rec,
-                             pb, pb0, rc1_cap, rc1_sbits, rc0, rc1);
-      } else if (per_group > 1024) {
-        hipLaunchKernelGGL((k_adj_rc<KeyT, 512>), dim3(unsigned(ng)), dim3(512), rc_lds, st, set, gbits, goff,
-                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched, pass1_cap, &ctl->rc_marks);
-        if (!rc1_marks)
-          hipLaunchKernelGGL((k_adj_rc1<KeyT, 512>), dim3(unsigned(ng)), dim3(512), rc1_lds, st, set, gbits, goff, rec,
-                             pb, pb0, rc1_cap, rc1_sbits, rc0, rc1);
-      } else if (per_group > 256) {
-        hipLaunchKernelGGL((k_adj_rc<KeyT, 256>), dim3(unsigned(ng)), dim3(256), rc_lds, st, set, gbits, goff,
-                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched, pass1_cap, &ctl->rc_marks);
-        if (!rc1_marks)
-          hipLaunchKernelGGL((k_adj_rc1<KeyT, 256>), dim3(unsigned(ng)), dim3(256), rc1_lds, st, set, gbits, goff, rec,
-                             pb, pb0, rc1_cap, rc1_sbits, rc0, rc1);
-      } else {
-        hipLaunchKernelGGL((k_adj_rc<KeyT, 64>), dim3(unsigned(ng)), dim3(64), rc_lds, st, set, gbits, goff,
-                           rec, pb, pb0, cap, rc0, rc1, &ctl->rc_batched, pass1_cap, &ctl->rc_marks);
-        if (!rc1_marks)
-          hipLaunchKernelGGL((k_adj_rc1<KeyT, 64>), dim3(unsigned(ng)), dim3(64), rc1_lds, st, set, gbits, goff, rec,
-                             pb, pb0, rc1_cap, rc1_sbits, rc0, rc1);
-      }
+      const int rc1_batched = rc1_mode == 0 ? 1 : 0;
+#define KSH_LAUNCH_RC(T)                                                                                              \
+  do {                                                                                                                \
+    if (with_rc)                                                                                                      \
+      hipLaunchKernelGGL((k_adj_rc<KeyT, T>), dim3(unsigned(ng)), dim3(T), rc_lds, st, set, gbits, goff, rec, pb, pb0, \
+                         cap, rc0, rc1, &ctl->rc_batched, pass1_cap, &ctl->rc_marks);                                 \
+    if (!rc1_marks)                                                                                                   \
+      hipLaunchKernelGGL((k_adj_rc1<KeyT, T>), dim3(unsigned(ng)), dim3(T), rc1_lds, st, set, gbits, goff, rec, pb,   \
+                         pb0, rc1_cap, rc1_sbits, rc1_batched, rc0, rc1, &ctl->rc_batched);                           \
+  } while (0)
+      if (per_group > 4096)
+        KSH_LAUNCH_RC(1024);
+      else if (per_group > 1024)
+        KSH_LAUNCH_RC(512);
+      else if (per_group > 256)
+        KSH_LAUNCH_RC(256);
+      else
+        KSH_LAUNCH_RC(64);
+#undef KSH_LAUNCH_RC
       // KSH_FWD=probe: the forward half in place; =staged: round 3's five staged windows per chunk; default: one
       // window per workgroup, the probes marked at their targets (k_adj_fwd_targets)
       static const int fwd_mode = [] {

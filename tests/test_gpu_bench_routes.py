@@ -46,13 +46,13 @@ def encode_vs_oracle(ctx, k, n, kmers, must, must_not=()):
 
 
 def test_u32_1024_threads_batched_windows(ctx):
-    """(19, 8, uint32_t), 5 x 10^6 k-mers: 19 500 k-mers per group > 4096 -> k_adj_rc<u32, 1024>; a window holds
-    7 976 keys, so every group's pass 0 (and pass 1 for most) takes several batches; N = 8 > kSgBits and
-    n >= 2^20 -> the two-level rc scatter; 3 x 10^5 ruler walkers >= 2^18 -> all of them in one launch."""
+    """(19, 8, uint32_t), 5 x 10^6 k-mers: 19 500 records per group, more than k_adj_rc1's LDS holds -> k_adj_rc<u32,
+    1024>; a window holds 7 976 keys, so every group's pass 0 (and pass 1 for most) takes several batches; N = 8 >
+    kSgBits and n >= 2^20 -> the two-level rc scatter; 3 x 10^5 ruler walkers >= 2^18 -> all of them in one launch."""
     k, n = 19, 8
     a = synth.phylogeny_sets(k, 1, 5_000_000, seed=41)[0]
-    encode_vs_oracle(ctx, k, n, a, {"probe_staged", "rc_1024", "rc_batched", "scatter_two_level", "fwd_targets",
-                                    "rank_one_launch", "emit_logs"}, {"rank_stamped"})
+    encode_vs_oracle(ctx, k, n, a, {"probe_staged", "rc_1024", "rc_marks_groups", "rc_batched", "scatter_two_level",
+                                    "fwd_targets", "rank_one_launch", "emit_logs"}, {"rank_stamped"})
 
 
 def test_u32_fragmented_heads_one_launch(ctx):
@@ -69,13 +69,13 @@ def test_u32_fragmented_heads_one_launch(ctx):
 
 
 def test_u64_1024_threads_batched_windows(ctx):
-    """(23, 8, uint64_t), 2.5 x 10^6 k-mers: 9 800 k-mers per group -> k_adj_rc<u64, 1024>, a window of 5 700
-    8-byte keys -> several batches; 16-byte records through the two-level scatter (the intermediate records
-    borrow nbr + link)."""
+    """(23, 8, uint64_t), 2.5 x 10^6 k-mers: 9 800 records per group (k_adj_rc1 holds 4 644 of an 8-byte key's) ->
+    k_adj_rc<u64, 1024>, a window of 5 700 8-byte keys -> several batches; 16-byte records through the two-level
+    scatter (the intermediate records borrow nbr + link)."""
     k, n = 23, 8
     a = synth.phylogeny_sets(k, 1, 2_500_000, seed=47)[0]
-    encode_vs_oracle(ctx, k, n, a, {"probe_staged", "rc_1024", "rc_batched", "scatter_two_level", "fwd_targets",
-                                    "emit_logs"}, {"rank_stamped"})
+    encode_vs_oracle(ctx, k, n, a, {"probe_staged", "rc_1024", "rc_marks_groups", "rc_batched", "scatter_two_level",
+                                    "fwd_targets", "emit_logs"}, {"rank_stamped"})
 
 
 def test_bench_geometry_two_level_jumping(ctx):
@@ -132,16 +132,21 @@ def test_route_differential_1e8(gpu):
     the groups that do not fit; k_adj_fwd_targets; two-level scatter and jumping,
     one-launch ranking, strings from the walk logs) and the route of independent, size-independent kernels
     (k_adjacency probing in global memory, stamping walks + k_choose, k_emit) write the same SPSS words and
-    lengths, byte for byte.  The switches are read once per process: two processes."""
+    lengths, byte for byte -- and so does round 3's probe (k_adj_rc with two batches of windows for the dense groups,
+    k_adj_fwd_staged).  The switches are read once per process: three processes."""
     size = 100_000_000
     default = _run_route({}, size)
     other = _run_route({"KSH_ADJACENCY": "probe", "KSH_RANK": "stamp", "KSH_EMIT": "walk"}, size)
+    round3 = _run_route({"KSH_RC1": "marks", "KSH_FWD": "staged"}, size)
     r = set(default["genome"]["routes"])
     assert {"probe_staged", "rc_1024", "rc1_streamed", "scatter_two_level", "fwd_targets", "rank_one_launch",
             "jump_two_level", "emit_logs"} <= r, sorted(r)
     assert "probe_staged" not in other["genome"]["routes"] and "rank_stamped" in other["genome"]["routes"]
+    r3 = set(round3["genome"]["routes"])
+    assert {"rc_1024", "rc_batched", "fwd_staged"} <= r3 and not ({"rc1_streamed", "fwd_targets"} & r3), sorted(r3)
     for name in ("genome", "intersection", "difference"):
-        d, o = default[name], other[name]
-        assert d["roundtrip"] and o["roundtrip"], name
-        assert (d["n"], d["strings"], d["bases"], d["sha256"]) == (o["n"], o["strings"], o["bases"], o["sha256"]), name
+        d = default[name]
+        for o in (other[name], round3[name]):
+            assert d["roundtrip"] and o["roundtrip"], name
+            assert (d["n"], d["strings"], d["bases"], d["sha256"]) == (o["n"], o["strings"], o["bases"], o["sha256"]), name
     assert default["difference"]["strings"] > 1000 and default["genome"]["n"] > 99_000_000

@@ -380,7 +380,9 @@ def test_encode_skewed_rc_groups(ctx):
     """k_adj_rc1 takes the groups whose reverse-complement records fit its LDS -- sized from the AVERAGE group -- and
     k_adj_rc the others, in the same encode: a genome's k-mers (a dozen records per group) plus 6000 k-mers that
     carry one fixed 7-base block where the group id is read (bases k-8 .. k-2 of x, i.e. 1 .. 7 of rc(x)): those
-    that stay canonical crowd one group far beyond the window.  Strings == the oracle's, both routes reported."""
+    that stay canonical crowd one group far beyond the window.  Strings == the oracle's, both routes reported.
+    (With KSH_RC1=batched that group is k_adj_rc1's too, a dozen batches deep: test_encode_alternative_paths has the
+    same set.)"""
     k, n, kb = 23, 14, 4
     rng = np.random.default_rng(23)
     base = synth.phylogeny_sets(k, 1, 200000, seed=19)[0]
@@ -451,7 +453,7 @@ def test_u16_keys_medium_and_large_sets(ctx):
     assert odd >= 1  # (the sizes above are chosen so that the case that faulted is among them)
 
 
-@pytest.mark.parametrize("knob", ["KSH_RANK=stamp", "KSH_EMIT=walk", "KSH_L2_MIN=4096", "KSH_ADJACENCY=probe", "KSH_FWD=probe", "KSH_FWD=staged", "KSH_RC1=marks", "KSH_RC_SCATTER=direct", "KSH_RC_GROUPS=half", "KSH_RANK_PHASES=1"])
+@pytest.mark.parametrize("knob", ["KSH_RANK=stamp", "KSH_EMIT=walk", "KSH_L2_MIN=4096", "KSH_ADJACENCY=probe", "KSH_FWD=probe", "KSH_FWD=staged", "KSH_RC1=marks", "KSH_RC1=batched", "KSH_RC_SCATTER=direct", "KSH_RC_GROUPS=half", "KSH_RANK_PHASES=1"])
 def test_encode_alternative_paths(gpu, knob):
     """The encoder's other routes give the oracle's strings too: the stamping ranking walks with
     k_choose / k_emit per k-mer (what a set with a non-branching loop falls back to), the strings
@@ -483,6 +485,9 @@ def test_encode_alternative_paths(gpu, knob):
         "check(23, 14, 4, synth.genome_with_tips(23, 150000, seed=7, every=150), (0, 2))\n"
         "big = synth.phylogeny_sets(23, 2, 400000, seed=5); check(23, 14, 4, big[0]); check(23, 14, 4, np.intersect1d(big[0], big[1]))\n"
         "a, b = synth.phylogeny_sets(23, 2, 60000, seed=77, rate=0.004); check(23, 14, 4, np.union1d(a, b))\n"
+        "x = np.random.default_rng(23).integers(0, 4 ** 23, size=6000, dtype=np.uint64)\n"
+        "x = (x & ~np.uint64(0xFFFC)) | (np.uint64(0b10011100011011) << np.uint64(2))  # one reverse-complement group crowded\n"
+        "check(23, 14, 4, np.unique(np.concatenate([big[1][:200000], synth.canonical(x, 23)])))\n"
         "for seed in range(24):\n"
         "    k = [5, 7, 9, 11][seed %% 4]\n"
         "    check(k, min(10, 2 * k - 4), 4, synth.circular_with_tails(k, 20 + (seed * 7) %% 150, seed %% 5, 1 + seed %% 4, seed))\n"

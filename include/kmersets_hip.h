@@ -309,8 +309,8 @@ int ksh_spss_encode_stats(ksh_ctx* ctx, int64_t stats[4]);
 /* Which variants of the encode's kernels the current plan ran (they are chosen by set size and geometry;
  * the parity tests assert the route so that a case cannot silently take another one): a mask of KSH_ROUTE_*. */
 enum {
-  KSH_ROUTE_PROBE_STAGED = 1 << 0,       /* neighbour probe staged in LDS (k_rc_*, k_adj_rc), not k_adjacency */
-  KSH_ROUTE_RC_1024 = 1 << 1,            /* k_adj_rc with 1024 / 512 / 256 / 64 threads per group */
+  KSH_ROUTE_PROBE_STAGED = 1 << 0,       /* neighbour probe staged in LDS (k_rc_*, k_adj_rc1 / k_adj_rc), not k_adjacency */
+  KSH_ROUTE_RC_1024 = 1 << 1,            /* k_adj_rc1 / k_adj_rc with 1024 / 512 / 256 / 64 threads per group */
   KSH_ROUTE_RC_512 = 1 << 2,
   KSH_ROUTE_RC_256 = 1 << 3,
   KSH_ROUTE_RC_64 = 1 << 4,

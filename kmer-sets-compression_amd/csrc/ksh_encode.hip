@@ -1433,9 +1433,9 @@ __global__ __launch_bounds__(kFwdChunk, (sizeof(KeyT) <= 4 ? 8 : 4)) void k_adj_
 // counts of Q vary: a canonical set keeps a k-mer that starts with T^j only if it ends in A^j, so the window
 // over the last prefixes of the set spans a wide range of them and its stream is long (measured: 1.8 x 10^5 k-mers
 // for the last window of a 10^8-k-mer genome set, 473 us of one workgroup at the end of a 1.37 ms kernel; a
-// median window streams 800).  A window whose stream is longer than kTgtStreamMax is therefore cut again, evenly in
-// the prefix range (its stream is even there, its staged keys are not): k_tgt_split counts the parts and
-// k_tgt_subcuts searches their bounds, both on the device; the parts run as workgroups behind the windows'.
+// median window streams 800).  A window whose stream is longer than kTgtStreamMax is therefore cut again, at the
+// quantiles of its longest stream range: k_tgt_split counts the parts and k_tgt_subcuts searches their bounds, both
+// on the device; the parts run as workgroups behind the windows'.
 #ifndef KSH_TGT_CHUNK
 #define KSH_TGT_CHUNK 2048
 #endif
@@ -1532,8 +1532,7 @@ __global__ __launch_bounds__(256) void k_tgt_split(const int64_t* __restrict__ c
   for (int64_t j = 1; j < m; j++) task[e + j - 1] = TgtTask{c, int(j), int(m)};
 }
 
-// Eight lanes per task: the cut at v_c + j (v_c+1 - v_c) / m -- five searches -- is where part j begins and part
-// j - 1 ends.
+// Eight lanes per task: the cut of part j of m -- five searches -- is where part j begins and part j - 1 ends.
 template <typename KeyT>
 __global__ __launch_bounds__(256) void k_tgt_subcuts(DevSet<KeyT> set, const int64_t* __restrict__ cuts, int64_t n_chunks,
                                                       int64_t cap, const TgtTask* __restrict__ task,
@@ -1545,9 +1544,24 @@ __global__ __launch_bounds__(256) void k_tgt_subcuts(DevSet<KeyT> set, const int
   if (e >= count || lane > 4) return;
   const TgtTask t = task[e];
   const int k = set.k;
-  const uint64_t v0 = uint64_t(cuts[kTgtBounds * t.c + 1]), v1 = uint64_t(cuts[kTgtBounds * (t.c + 1) + 1]);
-  const uint64_t dv = v1 - v0, m = uint64_t(t.m), j = uint64_t(t.j);
-  const uint64_t v = v0 + (dv / m) * j + ((dv % m) * j) / m;  // (no overflow: dv < 2^62, m and j < 2^31)
+  // the cut: the suffix of the k-mer a j-th of the way through the LONGEST of the window's four stream ranges -- that
+  // range is cut into equal parts whatever its k-mers' spread (a range ascends in its suffixes: the cuts ascend with
+  // j), the other three where their suffixes fall.  (The first version cut the prefix range [v_c, v_c+1) evenly:
+  // right for k-mers spread like a genome's, one part for a stream clustered in a corner of a mostly empty range.)
+  const int64_t* lo_c = cuts + kTgtBounds * t.c;
+  const int64_t* hi_c = lo_c + kTgtBounds;
+  int best = 0;
+  int64_t best_len = hi_c[2] - lo_c[2];
+#pragma unroll
+  for (int a = 1; a < 4; a++) {
+    const int64_t len = hi_c[2 + a] - lo_c[2 + a];
+    if (len > best_len) {
+      best_len = len;
+      best = a;
+    }
+  }
+  const int64_t pos = lo_c[2 + best] + int64_t((uint64_t(best_len) * uint64_t(t.j)) / uint64_t(t.m));  // (< 2^31 * 2^31)
+  const uint64_t v = set.kmer(pos) & ((uint64_t(1) << (2 * k - 2)) - 1);
   const int64_t at = lane < 4 ? lower_bound_kmer(set, (uint64_t(lane) << (2 * k - 2)) + v) : lower_bound_kmer(set, v << 2);
   const int slot = lane < 4 ? 2 + lane : 0;
   int64_t* mine = rec + 2 * kTgtBounds * (n_chunks + e);                                  // part j begins here

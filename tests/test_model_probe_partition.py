@@ -1,0 +1,114 @@
+"""CPU model of how round 4's probe kernels deal the neighbour look-ups out (no GPU): the facts
+k_adj_fwd_targets and k_adj_rc1 (csrc/ksh_encode.hip) rest on, checked with numpy on seeded sets against the
+definition the oracle restates (lib/core/spss.h:238-272: the neighbours of a side are the canonical forms of
+Next(x, .) / Prev(x, .) that the set holds).
+
+  * windows and streams: the set is cut into windows of C consecutive k-mers where the (K-1)-base prefix changes; the
+    k-mers whose SUFFIX lies in a window's prefix range are its stream.  Every k-mer is in exactly one window and in
+    exactly one stream; every Next(q, c) that the set holds lies in the window that streams q; and the marks the
+    stream leaves (q at its found targets) are, per target y, exactly the Prev(y, a) that the set holds.
+  * records and ranges: x's record is rx = rc(x), grouped by the bits below its top base.  z is reached on its side 1
+    through a reverse complement by the records with rx = Next(z, c') -- four record keys that differ in their last
+    base -- and y on its side 0 by the records with rx = Prev(y, a) -- four that differ in their top base; both
+    agree with the definition (the canonical form of the neighbour is its reverse complement, and it is in the set).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "kmer-sets-compression_amd"))
+from kmersets import synth  # noqa: E402
+
+U = np.uint64
+
+
+def nexts(x, k):
+    mask = U((1 << (2 * k)) - 1)
+    return [((x << U(2)) & mask) | U(c) for c in range(4)]
+
+
+def prevs(x, k):
+    return [(x >> U(2)) | (U(a) << U(2 * (k - 1))) for a in range(4)]
+
+
+def cuts_of(s, k, chunk):
+    """(b, v) per cut as k_tgt_bounds finds them: b = the first index >= c * chunk where the prefix changes."""
+    pref = s >> U(2)
+    n = s.size
+    n_chunks = (n + chunk - 1) // chunk
+    b, v = [0], [0]
+    for c in range(1, n_chunks + 1):
+        at = c * chunk
+        while at < n and pref[at] == pref[at - 1]:
+            at += 1
+        if at >= n:
+            b.append(n)
+            v.append(1 << (2 * k - 2))
+        else:
+            b.append(at)
+            v.append(int(pref[at]))
+    return b, v
+
+
+@pytest.mark.parametrize("k,size,chunk,seed", [(9, 3000, 64, 1), (11, 20000, 256, 2), (15, 50000, 1024, 3), (7, 900, 16, 4)])
+def test_windows_and_streams(k, size, chunk, seed):
+    s = synth.random_read_kmers(k, size, seed=seed, canonical=True) if k <= 9 else synth.phylogeny_sets(k, 1, size, seed=seed)[0]
+    s = np.unique(np.asarray(s, dtype=U))
+    n = s.size
+    member = set(int(x) for x in s)
+    index = {int(x): i for i, x in enumerate(s)}
+    b, v = cuts_of(s, k, chunk)
+    assert b[0] == 0 and b[-1] == n and all(b[i] < b[i + 1] or b[i] == n for i in range(len(b) - 1))
+    suffix = s & U((1 << (2 * k - 2)) - 1)
+    streamed = np.zeros(n, dtype=np.int64)
+    marks = [set() for _ in range(n)]  # per target: who marked it
+    for c in range(len(b) - 1):
+        lo, hi = b[c], b[c + 1]
+        # the window is all k-mers whose prefix lies in [v_c, v_c+1)
+        if hi > lo:
+            assert int(s[lo] >> U(2)) >= v[c] and int(s[hi - 1] >> U(2)) < v[c + 1]
+        q = np.nonzero((suffix >= U(v[c])) & (suffix < U(v[c + 1])))[0]
+        streamed[q] += 1
+        # the stream is four ranges of the set, one per top base
+        for a in range(4):
+            qa = q[(s[q] >> U(2 * k - 2)) == U(a)]
+            assert qa.size == 0 or (np.diff(qa) == 1).all()
+        for i in q:
+            for y in nexts(s[i], k):
+                if int(y) in member and int(y) != int(s[i]):
+                    t = index[int(y)]
+                    assert lo <= t < hi, "a Next target outside the window that streams its k-mer"
+                    marks[t].add(int(i))
+    assert (streamed == 1).all()
+    for t in range(n):
+        want = {index[int(p)] for p in prevs(s[t], k) if int(p) in member and int(p) != int(s[t])}
+        assert marks[t] == want
+
+
+@pytest.mark.parametrize("k,gbits,size,seed", [(9, 6, 3000, 5), (11, 8, 20000, 6), (15, 14, 40000, 7)])
+def test_records_and_ranges(k, gbits, size, seed):
+    s = synth.random_read_kmers(k, size, seed=seed, canonical=True) if k <= 9 else synth.phylogeny_sets(k, 1, size, seed=seed)[0]
+    s = np.unique(np.asarray(s, dtype=U))
+    n = s.size
+    index = {int(x): i for i, x in enumerate(s)}
+    rx = synth.revcomp(s, k)
+    low_bits = 2 * k - 2 - gbits
+    grp = (rx >> U(low_bits)) & U((1 << gbits) - 1)  # the bits below the top base
+    by_rx = {int(r): i for i, r in enumerate(rx)}
+    for t in range(n):
+        z = s[t]
+        # side 1 through a reverse complement, by the definition: rc(Next(z, c)) in the set, not z itself
+        want1 = {index[int(r)] for r in synth.revcomp(np.array(nexts(z, k), dtype=U), k) if int(r) in index and int(r) != int(z)}
+        # ... turned round: the records with rx = Next(z, c')
+        got1 = {by_rx[int(y)] for y in nexts(z, k) if int(y) in by_rx and by_rx[int(y)] != t}
+        assert got1 == want1
+        # they all sit in ONE group, the one z's range [c][tb][G] belongs to: G = z's bits below its top two bases
+        g_of_z = (int(z) >> (2 * k - 4 - gbits)) & ((1 << gbits) - 1)
+        assert all(int(grp[i]) == g_of_z for i in got1)
+        # side 0: rc(Prev(y, a)) in the set <-> the records with rx = Prev(y, a), all in the group of y's top bits
+        want0 = {index[int(r)] for r in synth.revcomp(np.array(prevs(z, k), dtype=U), k) if int(r) in index and int(r) != int(z)}
+        got0 = {by_rx[int(p)] for p in prevs(z, k) if int(p) in by_rx and by_rx[int(p)] != t}
+        assert got0 == want0
+        assert all(int(grp[i]) == (int(z) >> (2 * k - gbits)) for i in got0)

@@ -112,3 +112,46 @@ def test_records_and_ranges(k, gbits, size, seed):
         got0 = {by_rx[int(p)] for p in prevs(z, k) if int(p) in by_rx and by_rx[int(p)] != t}
         assert got0 == want0
         assert all(int(grp[i]) == (int(z) >> (2 * k - gbits)) for i in got0)
+
+
+@pytest.mark.parametrize("k,size,chunk,stream_max,seed", [(11, 20000, 256, 128, 8), (15, 60000, 512, 200, 9)])
+def test_long_streams_cut_at_quantiles(k, size, chunk, stream_max, seed):
+    """k_tgt_split / k_tgt_subcuts: a window whose stream is longer than stream_max is cut into m parts at the
+    suffixes of the k-mers j / m of the way through its LONGEST stream range.  The parts tile the window (keys and
+    stream), every k-mer is still streamed once, every Next target still lies in the part that streams its k-mer,
+    and the longest range is cut into equal shares."""
+    s = np.unique(np.asarray(synth.phylogeny_sets(k, 1, size, seed=seed)[0], dtype=U))
+    n = s.size
+    member = {int(x): i for i, x in enumerate(s)}
+    b, v = cuts_of(s, k, chunk)
+    suffix = s & U((1 << (2 * k - 2)) - 1)
+    top = s >> U(2 * k - 2)
+    streamed = np.zeros(n, dtype=np.int64)
+    n_split = 0
+    for c in range(len(b) - 1):
+        q = np.nonzero((suffix >= U(v[c])) & (suffix < U(v[c + 1])))[0]
+        m = (q.size + stream_max - 1) // stream_max
+        edges = [v[c]]
+        if m > 1:
+            n_split += 1
+            ranges = [q[top[q] == U(a)] for a in range(4)]
+            best = max(range(4), key=lambda a: (ranges[a].size, -a))  # the first of the longest
+            r = ranges[best]
+            for j in range(1, m):
+                edges.append(int(suffix[r[(r.size * j) // m]]))
+            assert edges == sorted(edges)
+            shares = np.diff([0] + [(r.size * j) // m for j in range(1, m)] + [r.size])
+            assert shares.max() - shares.min() <= 1
+        edges.append(v[c + 1])
+        for lo_v, hi_v in zip(edges[:-1], edges[1:]):
+            part = q[(suffix[q] >= U(lo_v)) & (suffix[q] < U(hi_v))]
+            streamed[part] += 1
+            w_lo = int(np.searchsorted(s, U(lo_v << 2)))
+            w_hi = n if hi_v >= (1 << (2 * k - 2)) else int(np.searchsorted(s, U(hi_v << 2)))
+            assert b[c] <= w_lo <= w_hi <= b[c + 1]
+            for i in part:
+                for y in nexts(s[i], k):
+                    t = member.get(int(y))
+                    if t is not None and t != int(i):
+                        assert w_lo <= t < w_hi
+    assert (streamed == 1).all() and n_split > 0
